@@ -1,0 +1,114 @@
+"""ctypes binding of libdgcn.so (the C ABI declared in include/dgcn.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module
+raises, and every hot-path op of the package fails loudly with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (must be imported first: libdgcn binds to the HIP runtime torch loaded)
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdgcn.so"
+
+# aggregation modes / flags (include/dgcn.h)
+AGGR_ADD, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4
+MSG_IDENTITY, MSG_RELU_EPS = 0, 1
+FLAG_LEARN_T, FLAG_LEARN_P = 1, 2
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+
+
+class DgcnGraph(C.Structure):
+    """struct dgcn_graph (include/dgcn.h)."""
+
+    _fields_ = [
+        ("n_dst", C.c_int32), ("n_src", C.c_int32), ("n_edges", C.c_int32), ("reserved", C.c_int32),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("eperm", C.c_void_p),
+        ("t_rowptr", C.c_void_p), ("t_col", C.c_void_p), ("t_eperm", C.c_void_p),
+        ("n_work", C.c_int32), ("n_slots", C.c_int32),
+        ("work_row", C.c_void_p), ("work_beg", C.c_void_p), ("work_end", C.c_void_p), ("work_slot", C.c_void_p),
+        ("t_n_work", C.c_int32), ("t_n_slots", C.c_int32),
+        ("t_work_row", C.c_void_p), ("t_work_beg", C.c_void_p), ("t_work_end", C.c_void_p), ("t_work_slot", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+_SIGNATURES = {
+    "dgcn_version": (C.c_int, []),
+    "dgcn_strerror": (C.c_char_p, [C.c_int]),
+    "dgcn_selftest_axpy_f32": (C.c_int, [C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dgcn_gen_aggr_fwd_workspace_bytes": (C.c_size_t, [C.POINTER(DgcnGraph), C.c_int32]),
+    "dgcn_gen_aggr_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(DgcnGraph), C.c_int32]),
+    "dgcn_gen_aggr_fwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_gen_aggr_bwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libdgcn.so once and declare every prototype.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build it with `python -m deep_gcns_torch_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU/eager fallback for the hot path.")
+    lib = C.CDLL(os.fspath(_LIB_PATH), mode=C.RTLD_LOCAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dgcn_strerror(rc)
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int | None:
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(*tensors) -> torch.device:
+    """All hot-path ops need device tensors; this is an error check, not a dispatch."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "deep_gcns_torch_amd: the message-passing hot path runs only as HIP kernels on an "
+                "MI355X (got a CPU tensor). There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

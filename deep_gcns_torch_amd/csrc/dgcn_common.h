@@ -1,0 +1,93 @@
+// Shared device/host helpers for libdgcn (gfx950 only; wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "dgcn.h"
+
+namespace dgcn {
+
+constexpr int kWave = 64;
+constexpr int kWgThreads = 256;           // 4 waves, one per SIMD
+constexpr int kWavesPerWg = kWgThreads / kWave;
+constexpr int kNumCU = 256;               // MI355X
+constexpr int kNumXCD = 8;
+
+#define DGCN_NEG_INF (-__builtin_inff())
+
+// Launch-error helper: kernel launches are asynchronous; hipGetLastError() reports
+// configuration errors (bad grid, missing code object) without synchronising.
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DGCN_OK : static_cast<int>(e);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// Force a wave-uniform value into an SGPR so address math on it is scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&r)[VEC], const float* __restrict__ p) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    r[0] = t.x; r[1] = t.y;
+  } else {
+    r[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
+  } else {
+    *p = r[0];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_i(int32_t* __restrict__ p, const int (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<int4*>(p) = make_int4(r[0], r[1], r[2], r[3]);
+  } else {
+    *p = r[0];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec_i(int (&r)[VEC], const int32_t* __restrict__ p) {
+  if constexpr (VEC == 4) {
+    const int4 t = *reinterpret_cast<const int4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+    r[0] = *p;
+  }
+}
+
+// Hardware transcendentals (v_exp_f32 / v_log_f32 are base-2, ~1 ulp).  Used instead of libm
+// calls on the hot paths; accuracy is far inside the 1e-4 relative parity budget.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+// Grid size for a wave-per-item kernel: enough workgroups to keep every CU's 32 wave
+// slots busy, capped so very large inputs grid-stride instead of launching millions
+// of tiny workgroups.
+inline int grid_for_waves(int64_t n_items, int waves_per_cu_target = 32) {
+  int64_t wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * waves_per_cu_target / kWavesPerWg * 4;
+  if (wgs > cap) wgs = cap;
+  if (wgs < 1) wgs = 1;
+  return static_cast<int>(wgs);
+}
+
+}  // namespace dgcn

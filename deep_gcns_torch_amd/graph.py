@@ -1,0 +1,163 @@
+"""Device-resident graph structure consumed by libdgcn (struct dgcn_graph, include/dgcn.h).
+
+The reference hands every layer the same COO ``edge_index`` (2,E) int64 tensor
+(examples/ogb/ogbn_arxiv/main.py:72-75 builds it once; gcn_lib/sparse/torch_vertex.py:68
+passes it to ``propagate``) and lets torch_scatter rediscover the segments with atomics on
+every call.  Here the segment structure is built ONCE per distinct ``edge_index``:
+
+  * CSR keyed by destination (``edge_index[1]``) -> forward walk, one wave per row;
+  * CSC keyed by source      (``edge_index[0]``) -> backward walk, deterministic, no atomics;
+  * both are STABLE sorts, so edges of a row keep their original order (first-max semantics
+    of scatter_max, duplicate edges counted twice, self-loops kept);
+  * rows longer than ``2*HUB_CHUNK`` edges are split into ``HUB_CHUNK``-edge work items whose
+    partial results are merged by a second tiny kernel (degree skew: SURVEY.md §7 hard-part 4).
+
+Index arrays are int32 (E < 2^31).  Built with device-side torch sort/scan (plumbing, run
+once); the per-layer hot path never touches COO again.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+HUB_CHUNK = 256
+
+
+def _work_list(rowptr: torch.Tensor, chunk: int):
+    """Split rows with more than 2*chunk edges.  Returns (n_work, n_slots, row, beg, end, slot)
+    as int32 device tensors, or None when no row needs splitting."""
+    deg = rowptr[1:] - rowptr[:-1]
+    if deg.numel() == 0 or int(deg.max()) <= 2 * chunk:
+        return None
+    n_rows = deg.numel()
+    nchunk = torch.where(deg > 2 * chunk, (deg + chunk - 1) // chunk, torch.ones_like(deg)).long()
+    rows = torch.arange(n_rows, device=rowptr.device)
+    work_row = torch.repeat_interleave(rows, nchunk)
+    first = torch.cumsum(nchunk, 0) - nchunk                      # first work item of each row
+    k = torch.arange(work_row.numel(), device=rowptr.device) - first[work_row]
+    split = nchunk[work_row] > 1
+    beg = rowptr[work_row].long() + k * chunk
+    end = torch.where(split, torch.minimum(beg + chunk, rowptr[work_row + 1].long()),
+                      rowptr[work_row + 1].long())
+    slot = torch.where(split, torch.cumsum(split.long(), 0) - 1, torch.full_like(k, -1))
+    n_slots = int(split.sum())
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return work_row.numel(), n_slots, i32(work_row), i32(beg), i32(end), i32(slot)
+
+
+class Graph:
+    """CSR-by-destination + CSC-by-source of one edge list, plus the ctypes view of it."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_src: int, n_dst: int,
+                 need_transpose: bool = True, hub_chunk: int = HUB_CHUNK):
+        dev = src.device  # structure building is index plumbing and also runs on CPU tensors (host-logic tests)
+        if src.dim() != 1 or src.shape != dst.shape:
+            raise ValueError("src/dst must be 1-D tensors of equal length")
+        E = src.numel()
+        if E >= 2 ** 31 or max(n_src, n_dst) >= 2 ** 31:
+            raise ValueError("graph too large for int32 indices")
+        self.device = dev
+        self.n_src, self.n_dst, self.n_edges = int(n_src), int(n_dst), int(E)
+        src = src.long()
+        dst = dst.long()
+        if E:
+            lo = int(torch.minimum(src.min(), dst.min()))
+            if lo < 0 or int(src.max()) >= n_src or int(dst.max()) >= n_dst:
+                raise ValueError("edge_index out of range")
+
+        # --- CSR by destination (stable) ---
+        if E and bool((dst[1:] >= dst[:-1]).all()):
+            perm = None
+            col = src
+        else:
+            perm = torch.sort(dst, stable=True).indices
+            col = src[perm]
+        counts = torch.bincount(dst, minlength=n_dst) if E else torch.zeros(n_dst, dtype=torch.long, device=dev)
+        rowptr = torch.zeros(n_dst + 1, dtype=torch.long, device=dev)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        self.rowptr = rowptr.to(torch.int32)
+        self.col = col.to(torch.int32).contiguous()
+        self.eperm = None if perm is None else perm.to(torch.int32).contiguous()
+        self.deg = counts.to(torch.float32)                      # in-degree, float like PyG degree()
+        self.work = _work_list(self.rowptr, hub_chunk)
+
+        # --- CSC by source (stable) ---
+        self.t_rowptr = self.t_col = self.t_eperm = None
+        self.t_work = None
+        if need_transpose:
+            tperm = torch.sort(src, stable=True).indices if E else torch.zeros(0, dtype=torch.long, device=dev)
+            tcounts = torch.bincount(src, minlength=n_src) if E else torch.zeros(n_src, dtype=torch.long, device=dev)
+            t_rowptr = torch.zeros(n_src + 1, dtype=torch.long, device=dev)
+            torch.cumsum(tcounts, 0, out=t_rowptr[1:])
+            self.t_rowptr = t_rowptr.to(torch.int32)
+            self.t_col = dst[tperm].to(torch.int32).contiguous()
+            self.t_eperm = tperm.to(torch.int32).contiguous()
+            self.t_work = _work_list(self.t_rowptr, hub_chunk)
+
+        self._c = self._make_struct()
+
+    # ------------------------------------------------------------------
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, **kw) -> "Graph":
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must have shape (2, E)")
+        return cls(edge_index[0], edge_index[1], num_nodes, num_nodes, **kw)
+
+    def _make_struct(self) -> _lib.DgcnGraph:
+        g = _lib.DgcnGraph()
+        g.n_dst, g.n_src, g.n_edges = self.n_dst, self.n_src, self.n_edges
+        p = _lib.ptr
+        g.rowptr, g.col, g.eperm = p(self.rowptr), p(self.col), p(self.eperm)
+        g.t_rowptr, g.t_col, g.t_eperm = p(self.t_rowptr), p(self.t_col), p(self.t_eperm)
+        if self.work is not None:
+            g.n_work, g.n_slots = self.work[0], self.work[1]
+            g.work_row, g.work_beg, g.work_end, g.work_slot = (p(t) for t in self.work[2:])
+        if self.t_work is not None:
+            g.t_n_work, g.t_n_slots = self.t_work[0], self.t_work[1]
+            g.t_work_row, g.t_work_beg, g.t_work_end, g.t_work_slot = (p(t) for t in self.t_work[2:])
+        return g
+
+    @property
+    def c_struct(self):
+        return C.byref(self._c)
+
+    def nbytes(self) -> int:
+        tot = 0
+        for t in (self.rowptr, self.col, self.eperm, self.t_rowptr, self.t_col, self.t_eperm):
+            if t is not None:
+                tot += t.numel() * t.element_size()
+        return tot
+
+
+# ----------------------------------------------------------------------------------------
+# cache: one Graph per live edge_index tensor object (same object reused by every layer and
+# epoch in the reference's training loops).  Keyed by the tensor OBJECT through a weak
+# reference, never by data_ptr: a recycled allocation must not resurrect a stale structure.
+# ----------------------------------------------------------------------------------------
+_cache: dict = {}   # id(tensor) -> (weakref to tensor, key, Graph)
+
+
+def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
+    """Return the cached Graph for ``edge_index`` (a (2,E) tensor) or pass a Graph through."""
+    if isinstance(edge_index, Graph):
+        return edge_index
+    if num_nodes is None:
+        raise ValueError("num_nodes is required to build a Graph from edge_index")
+    ident = id(edge_index)
+    key = (edge_index._version, int(num_nodes), edge_index.data_ptr(), tuple(edge_index.shape))
+    hit = _cache.get(ident)
+    if hit is not None and hit[0]() is edge_index and hit[1] == key:
+        return hit[2]
+    g = Graph.from_edge_index(edge_index, int(num_nodes))
+    ref = weakref.ref(edge_index, lambda _r, ident=ident: _cache.pop(ident, None))
+    _cache[ident] = (ref, key, g)
+    return g
+
+
+def clear_cache() -> None:
+    _cache.clear()

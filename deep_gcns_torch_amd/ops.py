@@ -1,0 +1,177 @@
+"""Autograd-aware wrappers around the libdgcn C ABI (sparse aggregation).
+
+``gen_aggregate`` is the fused replacement of the reference's
+``propagate -> message -> aggregate`` chain
+(gcn_lib/sparse/torch_vertex.py:68,78-85; gcn_lib/sparse/torch_message.py:44-85).
+All arithmetic on E-sized data happens inside the HIP kernels; the few N-sized
+coefficient tensors (gradient pre-scaling, d/dt, d/dp reductions) are plain torch ops.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+
+from . import _lib
+from .graph import Graph, graph_of
+
+_MODES = {
+    "add": _lib.AGGR_ADD, "sum": _lib.AGGR_ADD, "mean": _lib.AGGR_MEAN, "max": _lib.AGGR_MAX,
+    "softmax": _lib.AGGR_SOFTMAX, "softmax_sg": _lib.AGGR_SOFTMAX, "softmax_sum": _lib.AGGR_SOFTMAX,
+    "power": _lib.AGGR_POWER, "power_sum": _lib.AGGR_POWER,
+}
+POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
+
+
+def _scalar_arg(v):
+    """(host float, device pointer or None) for a python float or a 1-element device tensor."""
+    if isinstance(v, torch.Tensor):
+        return 0.0, v
+    return float(v), None
+
+
+def _rows_f32(x: torch.Tensor) -> torch.Tensor:
+    """fp32, unit channel stride (row stride may be anything >= C)."""
+    if x.dtype != torch.float32:
+        x = x.float()  # autocast / half inputs are computed in fp32
+    if x.dim() != 2:
+        raise ValueError("expected a (rows, channels) tensor")
+    if x.stride(1) != 1 or x.stride(0) < x.size(1):
+        x = x.contiguous()
+    return x
+
+
+class _GenAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_attr, t_param, p_param, graph: Graph, mode: int, msg: int,
+                eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool):
+        lib = _lib.load()
+        dev = _lib.require_device(x, edge_attr)
+        if dev != graph.device:
+            raise RuntimeError("graph and features live on different devices")
+        x = _rows_f32(x)
+        C = x.size(1)
+        if x.size(0) != graph.n_src:
+            raise ValueError(f"x has {x.size(0)} rows, graph expects {graph.n_src}")
+        if edge_attr is not None:
+            edge_attr = edge_attr.float().contiguous()
+            if edge_attr.shape != (graph.n_edges, C):
+                raise ValueError("edge_attr must be (E, C) matching x's channels")
+        need_grad = any(ctx.needs_input_grad[:4])
+        out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+        aux1 = aux2 = None
+        if need_grad:
+            if mode == _lib.AGGR_MAX:
+                aux1 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.int32)
+            elif mode in (_lib.AGGR_SOFTMAX, _lib.AGGR_POWER):
+                aux1 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+            if (mode == _lib.AGGR_SOFTMAX and learn_t) or (mode == _lib.AGGR_POWER and learn_p):
+                aux2 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+        flags = (_lib.FLAG_LEARN_T if learn_t else 0) | (_lib.FLAG_LEARN_P if learn_p else 0)
+        ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+        with torch.cuda.device(dev):
+            rc = lib.dgcn_gen_aggr_fwd_f32(
+                graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
+                t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
+                _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(ws), ws_bytes,
+                _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_gen_aggr_fwd_f32")
+        if need_grad:
+            ctx.save_for_backward(x, edge_attr, t_param, p_param, aux1, aux2, out)
+            ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
+            ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
+            ctx.learn_t, ctx.learn_p = learn_t, learn_p
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, edge_attr, t_param, p_param, aux1, aux2, out = ctx.saved_tensors
+        graph, mode = ctx.graph, ctx.mode
+        dev = x.device
+        C = x.size(1)
+        g = grad_out.float().contiguous()
+        p = p_param if p_param is not None else ctx.p_val
+        deg1 = graph.deg.clamp(min=1.0).unsqueeze(1)
+
+        grad_t = grad_p = None
+        if mode == _lib.AGGR_MEAN:
+            gcoef = g / deg1
+        elif mode == _lib.AGGR_POWER:
+            q = aux1
+            r = q.clamp(POW_LO, POW_HI)
+            inr = ((q >= POW_LO) & (q <= POW_HI)).to(g.dtype)
+            gcoef = g * r.pow(1.0 / p - 1.0) * inr / deg1
+            if ctx.learn_p and ctx.needs_input_grad[3]:
+                # d o/d p = o * ( -ln r / p^2 + 1[q in range] * S2 / (p * deg * r) ),  S2 = sum u^p ln u
+                dodp = out * (-torch.log(r) / (p * p) + inr * aux2 / (p * deg1 * r))
+                grad_p = (g * dodp).sum().reshape(p_param.shape)
+        else:
+            gcoef = g
+        if mode == _lib.AGGR_SOFTMAX and ctx.learn_t and ctx.needs_input_grad[2]:
+            # d L/d t = sum g * (sum_e w m^2 - out^2)      
+            grad_t = (g * (aux2 - out * out)).sum().reshape(t_param.shape)
+
+        grad_x = grad_ea = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gcoef = gcoef.contiguous()
+            grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
+            if edge_attr is not None and ctx.needs_input_grad[1]:
+                grad_ea = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)
+            ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+            with torch.cuda.device(dev):
+                rc = lib.dgcn_gen_aggr_bwd_f32(
+                    graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
+                    ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                    gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), grad_x.data_ptr(),
+                    _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+            _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
+            if not ctx.needs_input_grad[0]:
+                grad_x = None
+        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 8
+
+
+def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
+                  edge_attr: Optional[torch.Tensor] = None, aggr: str = "softmax",
+                  t: Union[float, torch.Tensor] = 1.0, p: Union[float, torch.Tensor] = 1.0,
+                  learn_t: bool = False, learn_p: bool = False, relu_eps: bool = True,
+                  eps: float = 1e-7, dim_size: Optional[int] = None) -> torch.Tensor:
+    """out_i = AGGR_{e: dst(e)=i} m_e with m_e = relu(x[src(e)] (+edge_attr_e)) + eps.
+
+    ``aggr`` in {add, mean, max, softmax, softmax_sg, softmax_sum, power, power_sum}; the
+    ``*_sum`` degree scaling (torch_message.py:60-63,77-80) is applied by the caller.
+    ``t`` / ``p`` may be python floats or 1-element device tensors (learnable parameters are
+    read on the device, no host synchronisation).  ``relu_eps=False`` aggregates raw rows.
+    """
+    if aggr not in _MODES:
+        raise NotImplementedError("To be implemented")  # torch_message.py:85
+    graph = graph_of(edge_index, x.size(0) if dim_size is None else dim_size)
+    mode = _MODES[aggr]
+    t_val, t_param = _scalar_arg(t)
+    p_val, p_param = _scalar_arg(p)
+    learn_t = bool(learn_t and t_param is not None and mode == _lib.AGGR_SOFTMAX)
+    learn_p = bool(learn_p and p_param is not None and mode == _lib.AGGR_POWER)
+    if t_param is not None and not learn_t:
+        t_param = t_param.detach()
+    if p_param is not None and not learn_p:
+        p_param = p_param.detach()
+    msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    return _GenAggregate.apply(x, edge_attr, t_param, p_param, graph, mode, msg, float(eps),
+                               t_val, p_val, learn_t, learn_p)
+
+
+def selftest(device="cuda:0") -> None:
+    """Prove libdgcn launches on torch's stream and sees torch's allocations."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    x = torch.arange(1000, device=dev, dtype=torch.float32)
+    y = torch.ones(1000, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = lib.dgcn_selftest_axpy_f32(2.0, x.data_ptr(), y.data_ptr(), x.numel(),
+                                        _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_selftest_axpy_f32")
+    exp = 2.0 * torch.arange(1000, dtype=torch.float32) + 1.0
+    if not torch.equal(y.cpu(), exp):
+        raise RuntimeError("libdgcn selftest produced wrong values: HIP runtime mismatch?")

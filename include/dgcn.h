@@ -1,0 +1,150 @@
+/*
+ * dgcn.h -- C ABI of libdgcn.so, the MI355X (gfx950) message-passing library.
+ *
+ * Every entry point replaces one hot-path call site of lightaime/deep_gcns_torch
+ * (paths below are relative to the reference root).  The library is torch-free:
+ * callers hand over raw device pointers, sizes and a hipStream_t.  Rules that hold
+ * for EVERY function:
+ *
+ *   - the caller owns all buffers (inputs, outputs, saved-for-backward, workspace);
+ *     the library never allocates, frees or keeps a pointer after returning;
+ *   - work is enqueued asynchronously on `stream`; nothing synchronises;
+ *   - no mutable global state: safe from one host thread per GPU (nn.DataParallel);
+ *   - return 0 on success, a negative DGCN_E_* for a rejected argument (nothing was
+ *     launched), a positive hipError_t if a launch failed.  dgcn_strerror() names it.
+ *
+ * Index tensors are int32 on the device (E < 2^31); node features are fp32 rows.
+ */
+#ifndef DGCN_H
+#define DGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGCN_VERSION 100 /* 0.1.0 */
+
+/* error codes (negative = argument error, nothing launched) */
+#define DGCN_OK 0
+#define DGCN_E_NULL (-1)      /* required pointer is NULL */
+#define DGCN_E_SHAPE (-2)     /* size/shape out of the supported range */
+#define DGCN_E_ALIGN (-3)     /* pointer or stride not aligned as required */
+#define DGCN_E_MODE (-4)      /* unknown mode / flag combination */
+#define DGCN_E_WORKSPACE (-5) /* workspace too small */
+
+/* aggregation modes: gcn_lib/sparse/torch_message.py:44-85 */
+#define DGCN_AGGR_ADD 0     /* :46-47 -> PyG base scatter(reduce='add')  */
+#define DGCN_AGGR_MEAN 1    /* :46-47 -> scatter(reduce='mean')          */
+#define DGCN_AGGR_MAX 2     /* :46-47 -> scatter(reduce='max'), empty->0 */
+#define DGCN_AGGR_SOFTMAX 3 /* :49-58  softmax / softmax_sg / softmax_sum (deg scaling done by caller) */
+#define DGCN_AGGR_POWER 4   /* :68-74  power / power_sum                 */
+
+/* message flags: how the per-edge message m_e is formed from the gathered row z_e */
+#define DGCN_MSG_IDENTITY 0 /* m_e = z_e            (utils/pyg_util.py:26 scatter_ of an edge tensor) */
+#define DGCN_MSG_RELU_EPS 1 /* m_e = relu(z_e)+eps  (gcn_lib/sparse/torch_vertex.py:78-85 GENConv.message) */
+
+/* extra behaviour bits for dgcn_gen_aggr_{fwd,bwd}_f32 */
+#define DGCN_FLAG_LEARN_T 1 /* softmax weights are differentiated (torch_message.py:51-52) */
+#define DGCN_FLAG_LEARN_P 2 /* power exponent is differentiated  (torch_message.py:33-34) */
+
+/*
+ * Graph structure, built once per distinct edge_index and reused by every layer
+ * (SURVEY.md a16).  "CSR" is keyed by DESTINATION (edge_index[1]); "CSC" by SOURCE
+ * (edge_index[0]).  Both are stable sorts of the original edge list, so edges of a
+ * row keep their original relative order.  All arrays live on the device.
+ */
+typedef struct dgcn_graph {
+  int32_t n_dst;         /* number of destination rows (dim_size of the scatter)          */
+  int32_t n_src;         /* number of source rows (x.size(0)); == n_dst for square graphs */
+  int32_t n_edges;       /* E                                                            */
+  int32_t reserved;
+  const int32_t* rowptr; /* [n_dst+1]  CSR offsets by destination                         */
+  const int32_t* col;    /* [E]        source node of CSR position e                      */
+  const int32_t* eperm;  /* [E] or NULL: original edge id of CSR position e (NULL=identity)*/
+  const int32_t* t_rowptr; /* [n_src+1] CSC offsets by source        (backward only)      */
+  const int32_t* t_col;    /* [E]       destination node of CSC position e                */
+  const int32_t* t_eperm;  /* [E]       original edge id of CSC position e                */
+  /* Optional work list that splits high-degree rows into chunks (deterministic hub
+   * handling).  n_work == 0 means "one work item per row".                               */
+  int32_t n_work;
+  int32_t n_slots;         /* number of partial-result slots used by split rows            */
+  const int32_t* work_row; /* [n_work] row of each item                                    */
+  const int32_t* work_beg; /* [n_work] first CSR position                                  */
+  const int32_t* work_end; /* [n_work] one past last CSR position                          */
+  const int32_t* work_slot;/* [n_work] -1: item covers the whole row; >=0: partial slot id */
+  /* same for the transposed walk */
+  int32_t t_n_work;
+  int32_t t_n_slots;
+  const int32_t* t_work_row;
+  const int32_t* t_work_beg;
+  const int32_t* t_work_end;
+  const int32_t* t_work_slot;
+} dgcn_graph;
+
+int dgcn_version(void);
+const char* dgcn_strerror(int rc);
+
+/* Device smoke test: y[i] = a*x[i] + y[i] on `stream`.  Used by the loader to prove the
+ * library shares the caller's HIP runtime (same stream handles, same allocations). */
+int dgcn_selftest_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sparse generalized aggregation.
+ * Replaces  GENConv.propagate -> message -> GenMessagePassing.aggregate
+ *           (gcn_lib/sparse/torch_vertex.py:68,78-85; gcn_lib/sparse/torch_message.py:44-85)
+ * and the torch_scatter kernels underneath (scatter / scatter_softmax / scatter_max).
+ *
+ *   z_e   = x[col[e]] (+ edge_attr[eperm[e]])           row gather, C channels
+ *   m_e   = relu(z_e) + eps        (DGCN_MSG_RELU_EPS)  |  z_e  (DGCN_MSG_IDENTITY)
+ *   out_i = AGGR_{e in row i} m_e                       per destination, per channel
+ *
+ *   x          [n_src, C] fp32, row stride x_stride floats
+ *   edge_attr  [E, C] fp32 contiguous in ORIGINAL edge order, or NULL
+ *   t_dev/p_dev  optional device scalars overriding t / p (learnable parameters: no host sync)
+ *   out        [n_dst, C] contiguous
+ *   aux1       [n_dst, C] or NULL.  SOFTMAX: logsumexp L_i = M_i + log D_i of t*m_e.
+ *              POWER: the pre-clamp mean q_i.  MAX: int32 original edge id of the arg-max
+ *              (-1 for an empty row).  ADD/MEAN: unused.
+ *   aux2       [n_dst, C] or NULL.  SOFTMAX+LEARN_T: sum_e w_e m_e^2.
+ *              POWER+LEARN_P: sum_e u_e^p ln u_e.  Otherwise unused.
+ *   workspace  >= dgcn_gen_aggr_fwd_workspace_bytes(g, C) bytes (0 unless rows are split).
+ */
+size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
+
+int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                          const float* edge_attr, int32_t channels, int32_t mode,
+                          int32_t msg, int32_t flags, float t, float p, float eps,
+                          const float* t_dev, const float* p_dev, float* out, void* aux1,
+                          float* aux2, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/*
+ * Backward of the above w.r.t. x (and edge_attr), one deterministic walk over the CSC:
+ *   grad_x[s] = sum_{e: src(e)=s} dL/dz_e ,  grad_edge_attr[orig(e)] = dL/dz_e
+ * with dL/dz_e = 1[z_e>0] * dL/dm_e (RELU_EPS) and dL/dm_e per SURVEY.md Appendix A.
+ *
+ *   gcoef   [n_dst, C] per-destination coefficient prepared by the caller:
+ *             ADD: g_i        MEAN: g_i/max(deg_i,1)      MAX: g_i
+ *             SOFTMAX: g_i    POWER: g_i * r_i^(1/p-1) / max(deg_i,1) * 1[lo<=q_i<=hi]
+ *   aux1    as written by the forward (SOFTMAX: L_i, MAX: arg-max edge ids)
+ *   out     forward output (only read for SOFTMAX with DGCN_FLAG_LEARN_T)
+ *   grad_x  [n_src, C] contiguous, fully overwritten
+ *   grad_edge_attr [E, C] in original edge order or NULL
+ */
+size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
+
+int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                          const float* edge_attr, int32_t channels, int32_t mode,
+                          int32_t msg, int32_t flags, float t, float p, float eps,
+                          const float* t_dev, const float* p_dev, const float* gcoef,
+                          const void* aux1, const float* out, float* grad_x,
+                          float* grad_edge_attr, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGCN_H */

@@ -1,0 +1,227 @@
+"""ORACLE / TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.pt by executing the REAL
+reference code (/root/reference, imported through oracle/refshim.py) on seeded inputs.
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Runs only in the build container (the reference tree does not exist on the GPU box); the
+fixtures it writes are committed and are what every parity test compares against.
+Each fixture stores inputs, parameters (state_dict) and the reference's outputs and
+input/parameter gradients for the scalar loss  L = sum(out * probe).
+"""
+from __future__ import annotations
+
+import os
+import zlib
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from deep_gcns_torch_amd import synth  # noqa: E402
+from oracle import refshim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _probe(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def sparse_aggregate_cases(sparse):
+    """GENConv.propagate (message + aggregate) of the reference for every aggregator."""
+    cases = []
+    ei = synth.tricky_graph()
+    N = 257
+
+    small = synth.tricky_graph(n=64, e=700, hub_deg=300, seed=7)
+    graphs = {"tricky": ei, "small": small}
+
+    def run(name, C, aggr, edge_attr=None, gname="tricky", **kw):
+        graph = graphs[gname]
+        n = 257 if gname == "tricky" else 64
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % (2 ** 31))
+        x = torch.randn(n, C, generator=g).requires_grad_(True)
+        conv = sparse.GENConv(C, C, aggr=aggr, norm="batch", **kw)
+        ea = None
+        if edge_attr:
+            ea = torch.randn(graph.size(1), C, generator=g).requires_grad_(True)
+        out = conv.propagate(graph, x=x, edge_attr=ea)
+        if aggr.endswith("_sum"):
+            pass  # degree scaling already applied inside aggregate (torch_message.py:60-63)
+        probe = _probe(out.shape, 1234)
+        params = {k: v for k, v in (("t", getattr(conv, "t", None)), ("p", getattr(conv, "p", None)),
+                                    ("y", getattr(conv, "y", None))) if isinstance(v, torch.nn.Parameter)}
+        wrt = [x] + ([ea] if ea is not None else []) + [v for v in params.values() if v.requires_grad]
+        grads = torch.autograd.grad((out * probe).sum(), wrt, allow_unused=True)
+        rec = dict(name=name, C=C, aggr=aggr, kw=kw, n=n, graph=gname, x=x.detach(),
+                   edge_attr=None if ea is None else ea.detach(), probe=probe, out=out.detach(),
+                   grad_x=grads[0])
+        gi = 1
+        if ea is not None:
+            rec["grad_edge_attr"] = grads[gi]; gi += 1
+        for k, v in params.items():
+            if v.requires_grad:
+                rec["grad_" + k] = grads[gi]; gi += 1
+        cases.append(rec)
+
+    for aggr in ["add", "mean", "max", "softmax", "softmax_sg", "power"]:
+        run(f"tricky64_{aggr}", 64, aggr)
+    run("tricky64_softmax_t0.1", 64, "softmax_sg", t=0.1)
+    run("tricky64_softmax_learn_t", 64, "softmax", t=0.7, learn_t=True)
+    run("tricky64_softmax_sum_learn", 64, "softmax_sum", t=0.5, learn_t=True, y=0.3, learn_y=True)
+    run("tricky64_power_learn_p", 64, "power", p=2.0, learn_p=True)
+    run("tricky64_power_p3", 64, "power", p=3.0)
+    run("tricky64_power_sum", 64, "power_sum", p=1.5, learn_p=True, y=-0.2, learn_y=True)
+    run("small128_softmax_sg", 128, "softmax_sg", gname="small", t=0.1)
+    run("small20_softmax", 20, "softmax", gname="small")          # 5 of 8 lanes active
+    run("small112_power", 112, "power", gname="small", p=2.0, learn_p=True)   # RevGCN-wide group width
+    run("small50_max", 50, "max", gname="small")                  # C % 4 != 0 -> scalar path
+    run("small50_softmax", 50, "softmax_sg", gname="small", t=2.0)
+    run("small256_mean", 256, "mean", gname="small")
+    run("small264_softmax", 264, "softmax_sg", gname="small")     # more than one channel block
+    for aggr, kw in [("softmax", dict(t=0.9, learn_t=True)), ("softmax_sg", dict(t=0.1)),
+                     ("power", dict(p=2.0, learn_p=True)), ("max", {}), ("add", {}), ("mean", {})]:
+        run(f"small16_ea_{aggr}", 16, aggr, edge_attr=True, gname="small", **kw)
+    return dict(graphs=graphs, cases=cases)
+
+
+def sparse_module_cases(sparse):
+    cases = []
+    ei = synth.tricky_graph()
+    N = 257
+
+    def finish(name, mod, x, out, extra=None):
+        probe = _probe(out.shape, 99)
+        ps = [p for p in mod.parameters() if p.requires_grad]
+        grads = torch.autograd.grad((out * probe).sum(), [x] + ps, allow_unused=True)
+        rec = dict(name=name, edge_index=ei, x=x.detach(), probe=probe, out=out.detach(),
+                   grad_x=grads[0], state_dict={k: v.clone() for k, v in mod.state_dict().items()},
+                   param_grads={n: g for (n, p), g in zip([(n, p) for n, p in mod.named_parameters()
+                                                           if p.requires_grad], grads[1:])})
+        rec.update(extra or {})
+        cases.append(rec)
+
+    torch.manual_seed(11)
+    x = torch.randn(N, 64, requires_grad=True)
+    kw = dict(aggr="softmax", t=1.0, learn_t=True, msg_norm=True, learn_msg_scale=True,
+              norm="batch", mlp_layers=2)
+    conv = sparse.GENConv(64, 64, **kw)
+    sd0 = {k: v.clone() for k, v in conv.state_dict().items()}
+    finish("genconv_softmax_msgnorm", conv, x, conv(x, ei), dict(ctor=dict(in_dim=64, emb_dim=64, **kw), state_dict_before=sd0))
+
+    torch.manual_seed(12)
+    x = torch.randn(N, 32, requires_grad=True)
+    kw = dict(aggr="power", p=2.0, learn_p=True, norm="layer", mlp_layers=1, encode_edge=True, edge_feat_dim=8)
+    conv = sparse.GENConv(32, 48, **kw)
+    ea = torch.rand(ei.size(1), 8)
+    sd0 = {k: v.clone() for k, v in conv.state_dict().items()}
+    finish("genconv_power_edge_encoder", conv, x, conv(x, ei, ea),
+           dict(ctor=dict(in_dim=32, emb_dim=48, **kw), edge_attr=ea, state_dict_before=sd0))
+
+    for convname in ["mr", "edge"]:
+        torch.manual_seed(13)
+        x = torch.randn(N, 24, requires_grad=True)
+        m = sparse.GraphConv(24, 40, convname, "relu", "batch", True)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        finish(f"graphconv_{convname}", m, x, m(x, ei),
+               dict(ctor=dict(in_channels=24, out_channels=40, conv=convname, act="relu", norm="batch", bias=True),
+                    state_dict_before=sd0))
+    torch.manual_seed(14)
+    x = torch.randn(N, 50, requires_grad=True)   # PPI width
+    m = sparse.ResGraphBlock(50, "mr", "relu", "batch", True, 8, 1)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    finish("resgraphblock_mr50", m, x, m(x, ei)[0],
+           dict(ctor=dict(channels=50, conv="mr", act="relu", norm="batch", bias=True, heads=8, res_scale=1),
+                state_dict_before=sd0))
+    return cases
+
+
+def dense_cases(dense):
+    cases = []
+    # kNN on lattice clouds (exact fp32 distance arithmetic)
+    for name, B, C, N, k, d in [("knn_xyz", 2, 3, 256, 16, 1), ("knn_xyz_d4", 2, 3, 256, 8, 4),
+                                ("knn_feat64", 2, 64, 192, 16, 3), ("knn_feat64_big", 1, 64, 512, 16, 27)]:
+        x = synth.lattice_cloud(B, C, N, seed=len(cases) + 1)
+        full = dense.dense_knn_matrix(x, k * d)
+        dil = dense.DenseDilatedKnnGraph(k, d)(x)
+        xt = x.transpose(2, 1).squeeze(-1)
+        dist = dense.pairwise_distance(xt)
+        cases.append(dict(kind="knn", name=name, x=x, k=k, dilation=d,
+                          edge_index_full=None if N > 256 else full.to(torch.int32),
+                          edge_index=dil.contiguous().to(torch.int32), dist=dist))
+    # random (non-lattice) cloud: only distance-rank consistency is checked
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 200, 1, generator=g)
+    cases.append(dict(kind="knn", name="knn_randn16", x=x, k=9, dilation=2,
+                      edge_index_full=dense.dense_knn_matrix(x, 18).to(torch.int32),
+                      edge_index=dense.DenseDilatedKnnGraph(9, 2)(x).contiguous().to(torch.int32),
+                      dist=dense.pairwise_distance(x.transpose(2, 1).squeeze(-1))))
+
+    def conv_case(name, cls, Cin, Cout, B, N, k, norm, act="relu", seed=0):
+        torch.manual_seed(seed)
+        x = torch.randn(B, Cin, N, 1, requires_grad=True)
+        ei = dense.dense_knn_matrix(x.detach(), k)
+        m = cls(Cin, Cout, act, norm, True)
+        if norm == "batch":  # mixed-sign BN weights exercise the max/min trick
+            bn = [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)][0]
+            with torch.no_grad():
+                bn.weight.copy_(torch.randn(Cout))
+                bn.bias.copy_(torch.randn(Cout) * 0.1)
+        sd0 = {kk: v.clone() for kk, v in m.state_dict().items()}
+        m.train()
+        out = m(x, ei)
+        probe = _probe(out.shape, 77)
+        ps = [p for p in m.parameters()]
+        grads = torch.autograd.grad((out * probe).sum(), [x] + ps)
+        sd1 = {kk: v.clone() for kk, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            out_eval = m(x, ei)
+        cases.append(dict(kind="conv", name=name, cls=cls.__name__, Cin=Cin, Cout=Cout, norm=norm, act=act,
+                          x=x.detach(), edge_index=ei, probe=probe, out=out.detach(), out_eval=out_eval,
+                          grad_x=grads[0], state_dict_before=sd0, state_dict_after=sd1,
+                          param_grads={n: g for (n, _), g in zip(m.named_parameters(), grads[1:])}))
+
+    conv_case("edgeconv_bn", dense.EdgeConv2d, 16, 32, 2, 128, 8, "batch", seed=1)
+    conv_case("edgeconv_nonorm", dense.EdgeConv2d, 9, 64, 2, 96, 16, None, seed=2)
+    conv_case("edgeconv_leaky_bn", dense.EdgeConv2d, 16, 16, 1, 64, 4, "batch", act="leakyrelu", seed=3)
+    conv_case("mrconv_bn", dense.MRConv2d, 16, 32, 2, 128, 8, "batch", seed=4)
+    conv_case("mrconv_nonorm", dense.MRConv2d, 12, 20, 2, 80, 6, None, seed=5)
+
+    # a residual dynamic block end to end (kNN on features + EdgeConv + residual)
+    torch.manual_seed(6)
+    x = synth.lattice_cloud(2, 16, 128, seed=21).requires_grad_(True)
+    blk = dense.ResDynBlock2d(16, 8, 2, "edge", "relu", "batch", True, False, 0.0, "matrix", 1)
+    sd0 = {kk: v.clone() for kk, v in blk.state_dict().items()}
+    blk.train()
+    out = blk(x)
+    probe = _probe(out.shape, 78)
+    grads = torch.autograd.grad((out * probe).sum(), [x] + list(blk.parameters()))
+    cases.append(dict(kind="block", name="resdynblock_edge", x=x.detach(), probe=probe, out=out.detach(),
+                      grad_x=grads[0], state_dict_before=sd0,
+                      param_grads={n: g for (n, _), g in zip(blk.named_parameters(), grads[1:])},
+                      ctor=dict(in_channels=16, kernel_size=8, dilation=2, conv="edge", act="relu",
+                                norm="batch", bias=True, stochastic=False, epsilon=0.0, knn="matrix",
+                                res_scale=1)))
+    return cases
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    dense, sparse = refshim.import_reference()
+    torch.set_num_threads(8)
+    agg = sparse_aggregate_cases(sparse)
+    torch.save(agg, os.path.join(GOLD, "sparse_aggregate.pt"))
+    mods = sparse_module_cases(sparse)
+    torch.save(mods, os.path.join(GOLD, "sparse_modules.pt"))
+    dn = dense_cases(dense)
+    torch.save(dn, os.path.join(GOLD, "dense.pt"))
+    for f in ("sparse_aggregate.pt", "sparse_modules.pt", "dense.pt"):
+        print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

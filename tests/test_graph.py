@@ -1,0 +1,78 @@
+"""CPU: host logic of the graph-structure builder (CSR/CSC, stable order, hub work lists)."""
+import torch
+
+from deep_gcns_torch_amd import synth
+from deep_gcns_torch_amd.graph import Graph, graph_of
+
+
+def _check_csr(rowptr, col, eperm, keys, vals, n):
+    E = keys.numel()
+    assert rowptr[0] == 0 and rowptr[-1] == E and rowptr.numel() == n + 1
+    perm = torch.arange(E) if eperm is None else eperm.long()
+    for r in range(n):
+        seg = perm[rowptr[r]:rowptr[r + 1]]
+        assert torch.all(keys[seg] == r)
+        assert torch.all(seg[1:] > seg[:-1]), "stable order violated"
+    assert torch.equal(col.long(), vals[perm])
+
+
+def test_csr_csc_of_tricky_graph():
+    ei = synth.tricky_graph()
+    g = Graph.from_edge_index(ei, 257)
+    _check_csr(g.rowptr, g.col, g.eperm, ei[1], ei[0], 257)
+    _check_csr(g.t_rowptr, g.t_col, g.t_eperm, ei[0], ei[1], 257)
+    assert torch.equal(g.deg, torch.bincount(ei[1], minlength=257).float())
+    assert g.deg[:16].sum() >= 0 and int(g.deg[5]) >= 2048
+
+
+def test_sorted_input_needs_no_permutation():
+    ei = synth.tricky_graph()
+    order = torch.sort(ei[1], stable=True).indices
+    g = Graph.from_edge_index(ei[:, order].contiguous(), 257)
+    assert g.eperm is None
+
+
+def test_work_list_splits_hubs_only():
+    ei = synth.tricky_graph()
+    g = Graph.from_edge_index(ei, 257, hub_chunk=256)
+    n_work, n_slots, row, beg, end, slot = g.work
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
+    covered = torch.zeros(257, dtype=torch.long)
+    for i in range(n_work):
+        r = int(row[i])
+        assert int(g.rowptr[r]) <= int(beg[i]) <= int(end[i]) <= int(g.rowptr[r + 1])
+        covered[r] += int(end[i] - beg[i])
+        if deg[r] > 512:
+            assert int(slot[i]) >= 0 and int(end[i] - beg[i]) <= 256
+        else:
+            assert int(slot[i]) == -1 and int(end[i] - beg[i]) == int(deg[r])
+    assert torch.equal(covered, deg)
+    used = slot[slot >= 0]
+    assert torch.equal(torch.sort(used).values, torch.arange(n_slots, dtype=torch.int32))
+    # items of one row are contiguous
+    assert torch.all(row[1:] >= row[:-1])
+    # a graph without hubs gets no work list
+    small = torch.randint(0, 50, (2, 300), generator=torch.Generator().manual_seed(1))
+    assert Graph.from_edge_index(small, 50).work is None
+
+
+def test_cache_is_keyed_by_tensor_object_and_version():
+    ei = torch.randint(0, 20, (2, 64), generator=torch.Generator().manual_seed(2))
+    g1 = graph_of(ei, 20)
+    assert graph_of(ei, 20) is g1
+    ei[0, 0] = (ei[0, 0] + 1) % 20          # in-place edit bumps _version -> rebuild
+    g2 = graph_of(ei, 20)
+    assert g2 is not g1
+    clone = ei.clone()
+    assert graph_of(clone, 20) is not g2     # different object -> different entry
+    assert graph_of(g2) is g2
+
+
+def test_empty_and_rectangular():
+    g = Graph(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 5, 3)
+    assert g.rowptr.tolist() == [0, 0, 0, 0] and g.t_rowptr.tolist() == [0] * 6
+    src = torch.tensor([4, 0, 4, 2])
+    dst = torch.tensor([1, 1, 0, 2])
+    g = Graph(src, dst, 5, 3)
+    assert g.rowptr.tolist() == [0, 1, 3, 4] and g.col.tolist() == [4, 4, 0, 2]
+    assert g.t_rowptr.tolist() == [0, 1, 1, 2, 2, 4] and g.t_col.tolist() == [1, 2, 1, 0]

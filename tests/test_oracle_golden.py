@@ -1,0 +1,121 @@
+"""CPU: the oracle restatement (oracle/sparse_ref.py, oracle/dense_ref.py) against
+  (a) golden vectors produced by the reference's OWN code (oracle/make_golden.py), and
+  (b) the hand-computed known answers of SURVEY.md §4.2.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dense_ref, sparse_ref
+
+AGG = load_golden("sparse_aggregate.pt")
+DENSE = load_golden("dense.pt")
+
+
+def _aggr_kwargs(c):
+    kw = dict(c["kw"])
+    y = kw.pop("y", 0.0)
+    kw.pop("learn_y", None)
+    learn_t = kw.pop("learn_t", False) and c["aggr"] in ("softmax", "softmax_sum")
+    kw.pop("learn_p", None)
+    return dict(aggr=c["aggr"], t=kw.get("t", 1.0), p=kw.get("p", 1.0), learn_t=learn_t), y
+
+
+@pytest.mark.parametrize("case", AGG["cases"], ids=lambda c: c["name"])
+def test_sparse_aggregate_restatement_matches_reference(case):
+    ei = AGG["graphs"][case["graph"]]
+    kw, y = _aggr_kwargs(case)
+    x = case["x"].clone().requires_grad_(True)
+    ea = None if case["edge_attr"] is None else case["edge_attr"].clone().requires_grad_(True)
+    t = torch.tensor([kw["t"]], requires_grad=True)
+    p = torch.tensor([kw["p"]], requires_grad=True)
+    yv = torch.tensor([float(y)], requires_grad=True)
+    out = sparse_ref.gen_propagate(x, ei, ea, aggr=kw["aggr"], t=t, p=p, y=yv, learn_t=kw["learn_t"], dim_size=case["n"])
+    torch.testing.assert_close(out, case["out"], rtol=1e-5, atol=1e-6)
+    (out * case["probe"]).sum().backward()
+    torch.testing.assert_close(x.grad, case["grad_x"], rtol=1e-4, atol=1e-6)
+    if ea is not None:
+        torch.testing.assert_close(ea.grad, case["grad_edge_attr"], rtol=1e-4, atol=1e-6)
+    if "grad_t" in case:
+        torch.testing.assert_close(t.grad, case["grad_t"], rtol=1e-4, atol=1e-5)
+    if "grad_p" in case:
+        torch.testing.assert_close(p.grad, case["grad_p"], rtol=1e-4, atol=1e-5)
+    if "grad_y" in case:
+        torch.testing.assert_close(yv.grad, case["grad_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_known_answers_single_node():
+    """Messages [1, 3] into one node, no ReLU/eps applied (raw messages)."""
+    m = torch.tensor([[1.0], [3.0]])
+    idx = torch.tensor([0, 0])
+    f = lambda **k: sparse_ref.gen_aggregate_messages(m.clone(), idx, 2, **k)
+    assert f(aggr="softmax", t=1.0)[0, 0].item() == pytest.approx(2.761594, abs=1e-6)
+    assert f(aggr="softmax", t=1e-6)[0, 0].item() == pytest.approx(2.0, abs=1e-5)
+    assert f(aggr="softmax", t=50.0)[0, 0].item() == pytest.approx(3.0, abs=1e-6)
+    assert f(aggr="power", p=1.0)[0, 0].item() == pytest.approx(2.0, abs=1e-6)
+    assert f(aggr="power", p=2.0)[0, 0].item() == pytest.approx(math.sqrt(5.0), abs=1e-6)
+    assert f(aggr="add")[0, 0].item() == 4.0
+    assert f(aggr="mean")[0, 0].item() == 2.0
+    assert f(aggr="max")[0, 0].item() == 3.0
+    # isolated node 1
+    for aggr in ("softmax", "add", "mean", "max"):
+        assert f(aggr=aggr)[1, 0].item() == 0.0
+    assert f(aggr="power", p=2.0)[1, 0].item() == pytest.approx((1e-7) ** 0.5, rel=1e-5)
+
+
+def test_message_floor_and_softmax_sg_equivalence():
+    x = torch.tensor([[-2.0, 0.5]])
+    assert torch.equal(sparse_ref.gen_message(x), torch.tensor([[1e-7, 0.5 + 1e-7]]))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(30, 8, generator=g)
+    ei = torch.randint(0, 30, (2, 200), generator=g)
+    a = sparse_ref.gen_propagate(x, ei, aggr="softmax", t=0.3)
+    b = sparse_ref.gen_propagate(x, ei, aggr="softmax_sg", t=0.3)
+    assert torch.equal(a, b)
+    # permutation invariance over edge order (up to fp32 summation order)
+    perm = torch.randperm(200, generator=g)
+    c = sparse_ref.gen_propagate(x, ei[:, perm], aggr="softmax", t=0.3)
+    torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
+    # softmax_sum with y -> -inf  == softmax
+    d = sparse_ref.gen_propagate(x, ei, aggr="softmax_sum", t=0.3, y=torch.tensor([-80.0]))
+    torch.testing.assert_close(a, d, rtol=1e-6, atol=1e-7)
+
+
+def test_scatter_max_fixup_and_mr():
+    x = torch.tensor([[1.0, -20000.0], [3.0, 5.0], [0.0, 0.0]])
+    ei = torch.tensor([[0, 1], [1, 1]])  # 0->1, 1->1
+    r = sparse_ref.mr_aggregate(x, ei)
+    assert r[0].tolist() == [0.0, 0.0] and r[2].tolist() == [0.0, 0.0]   # isolated
+    assert r[1].tolist() == [0.0, 0.0]  # max(1-3, 0)=0 ; max(-20005, 0)=0
+    out = sparse_ref.scatter_("max", torch.tensor([[-20000.0]]), torch.tensor([0]), dim_size=1)
+    assert out.item() == 0.0  # utils/pyg_util.py:30-31
+
+
+@pytest.mark.parametrize("case", [c for c in DENSE if c["kind"] == "knn"], ids=lambda c: c["name"])
+def test_dense_knn_restatement(case):
+    x, k, d = case["x"], case["k"], case["dilation"]
+    full = dense_ref.dense_knn_matrix(x, k * d)
+    dist = dense_ref.pairwise_distance(x.transpose(2, 1).squeeze(-1))
+    assert torch.equal(dist, case["dist"])
+    if case["edge_index_full"] is not None:
+        assert torch.equal(full, case["edge_index_full"].long())
+    assert torch.equal(dense_ref.dilate(full, d), case["edge_index"].long())
+
+
+@pytest.mark.parametrize("case", [c for c in DENSE if c["kind"] == "conv"], ids=lambda c: c["name"])
+def test_dense_conv_restatement(case):
+    layers = [torch.nn.Conv2d(2 * case["Cin"], case["Cout"], 1, bias=True),
+              torch.nn.ReLU() if case["act"] == "relu" else torch.nn.LeakyReLU(0.2)]
+    if case["norm"] == "batch":
+        layers.append(torch.nn.BatchNorm2d(case["Cout"]))
+    nn = torch.nn.Sequential(*layers)   # conv -> act -> norm (gcn_lib/dense/torch_nn.py:48-60)
+    nn.load_state_dict({k[len("nn."):]: v for k, v in case["state_dict_before"].items()})
+    nn.train()
+    x = case["x"].clone().requires_grad_(True)
+    fn = dense_ref.edgeconv2d if case["cls"] == "EdgeConv2d" else dense_ref.mrconv2d
+    out = fn(x, case["edge_index"], nn)
+    torch.testing.assert_close(out, case["out"], rtol=1e-5, atol=1e-6)
+    (out * case["probe"]).sum().backward()
+    torch.testing.assert_close(x.grad, case["grad_x"], rtol=1e-4, atol=1e-6)
