@@ -47,7 +47,7 @@ def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 20.
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
     s = synth.SHAPES[shape_name]
-    scale = 64 if shape_name == "products" else 1
+    scale = 128 if shape_name == "products" else 1
     n = s["n"] // scale
     nu = s["n_undirected"] // scale
     ei = synth.undirected_random_graph(n, nu, seed=s["seed"])
@@ -67,7 +67,7 @@ def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 20.
         step()
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 5:
+        if el > budget_s or reps >= 3:
             break
     return dict(value=E * reps / el, unit="edges/s", cores=ncores, kind="port",
                 sample=f"{shape_name}-shaped uniform graph scaled 1/{scale}: N={n}, E={E}, C={channels}, "

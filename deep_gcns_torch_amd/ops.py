@@ -44,7 +44,7 @@ def _rows_f32(x: torch.Tensor) -> torch.Tensor:
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, t_param, p_param, graph: Graph, mode: int, msg: int,
-                eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool):
+                eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool, track: bool):
         lib = _lib.load()
         dev = _lib.require_device(x, edge_attr)
         if dev != graph.device:
@@ -57,7 +57,7 @@ class _GenAggregate(torch.autograd.Function):
             edge_attr = edge_attr.float().contiguous()
             if edge_attr.shape != (graph.n_edges, C):
                 raise ValueError("edge_attr must be (E, C) matching x's channels")
-        need_grad = any(ctx.needs_input_grad[:4])
+        need_grad = track and any(ctx.needs_input_grad[:4])  # no_grad/inverse passes skip the saved aux
         out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         aux1 = aux2 = None
         if need_grad:
@@ -130,7 +130,7 @@ class _GenAggregate(torch.autograd.Function):
             _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
             if not ctx.needs_input_grad[0]:
                 grad_x = None
-        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 8
+        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 9
 
 
 def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
@@ -159,7 +159,7 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
         p_param = p_param.detach()
     msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
     return _GenAggregate.apply(x, edge_attr, t_param, p_param, graph, mode, msg, float(eps),
-                               t_val, p_val, learn_t, learn_p)
+                               t_val, p_val, learn_t, learn_p, torch.is_grad_enabled())
 
 
 def selftest(device="cuda:0") -> None:
