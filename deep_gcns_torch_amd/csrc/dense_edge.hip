@@ -1,0 +1,381 @@
+// Dense (B x C x N x 1) graph convolution kernels for gfx950.
+//
+//   dgcn_vertex_gemm_f32           per-VERTEX split of the EdgeConv edge MLP on fp32 MFMA
+//   dgcn_dense_edge_reduce_fwd_f32 gather + activation + neighbourhood max/min + BN statistics
+//   dgcn_dense_edge_reduce_bwd_f32 its backward
+//
+// Replaces batched_index_select (gcn_lib/dense/torch_nn.py:75-96), the 1x1 Conv2d + act of BasicConv
+// as used INSIDE EdgeConv2d/MRConv2d (torch_nn.py:48-60) and torch.max(..., -1)
+// (gcn_lib/dense/torch_vertex.py:16-20, 31-35).  Two identities make the layer cheap:
+//   * the edge MLP is linear: W [x_i ; x_j - x_i] + b = ((W1 - W2) x_i + b) + W2 x_j = P_i + Q_j,
+//     so the GEMM runs once per vertex (16x fewer flops at k = 16), on v_mfma_f32_16x16x4_f32
+//     (exact f32 fma chain) and emits point-major rows that the gather can fetch as whole lines;
+//   * BatchNorm is a per-channel affine map, so max_l BN(a_l) needs only max_l a_l and min_l a_l plus
+//     the batch statistics sum a, sum a^2: the (B,C',N,k) activation tensor is never materialised.
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "dgcn_common.h"
+
+namespace dgcn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// vertex GEMM:  out[(b*N+n)*M + m] = sum_c x[b,c,n] * W[c*M+m] + bias[m]
+// One wave: 16 points x (16*TJ) outputs, K-loop over channels in steps of 4 (one MFMA per step
+// per column tile).  A[i][k] = x[b, k0+k, n0+i]  (lanes l&15 walk consecutive points: coalesced),
+// B[k][j] = W[k0+k][j0+j], D[row=(l>>4)*4+reg][col=l&15].
+// ---------------------------------------------------------------------------------------
+struct GemmParams {
+  const float* x;
+  int64_t sb, sc, sn;
+  int B, C, N, M;
+  const float* W;
+  const float* bias;
+  float* out;
+};
+
+constexpr int kTJ = 4;
+
+__global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParams P) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int tiles_n = (P.N + 15) / 16;
+  const int tile = blockIdx.x * kWavesPerWg + wave;
+  if (tile >= P.B * tiles_n) return;  // wave-uniform
+  const int b = tile / tiles_n;
+  const int n0 = (tile % tiles_n) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+  const int n = n0 + li;
+  const bool n_ok = n < P.N;
+  const float* xa = P.x + static_cast<int64_t>(b) * P.sb + static_cast<int64_t>(min(n, P.N - 1)) * P.sn;
+  const int col_tiles = (P.M + 15) / 16;
+
+  for (int ct0 = 0; ct0 < col_tiles; ct0 += kTJ) {
+    f32x4 acc[kTJ];
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < P.C; k0 += 4) {
+      const int k = k0 + lk;
+      const bool k_ok = k < P.C;
+      const float a = (k_ok && n_ok) ? xa[static_cast<int64_t>(k) * P.sc] : 0.f;
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) {
+        const int j = (ct0 + t) * 16 + li;
+        const float bv = (k_ok && j < P.M) ? P.W[static_cast<int64_t>(k) * P.M + j] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) {
+      const int j = (ct0 + t) * 16 + li;
+      if (j < P.M) {
+        const float bj = P.bias ? P.bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = n0 + lk * 4 + r;
+          if (row < P.N) P.out[(static_cast<int64_t>(b) * P.N + row) * P.M + j] = acc[t][r] + bj;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// edge reduce
+// ---------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+
+struct EdgeParams {
+  const float* P;   // [B,N,C] or null
+  const float* Q;   // [B,N,C]
+  const int64_t* idx;
+  int64_t ib, in_, ik;  // element strides of idx (B,N,k)
+  int64_t ldp, ldq;     // row strides (floats) of P/dP and Q/dQ rows; outputs vmax.. are dense [B,N,C]
+  int B, N, C, k;
+  int act;
+  float slope;
+  // forward outputs
+  float* vmax;      // [B,N,C]
+  float* vmin;      // [B,N,C] or null
+  uint8_t* amax;    // [B,N,C] or null: neighbour slot l of the maximum (first on ties)
+  uint8_t* amin;
+  float* stats;     // [gridDim.x][2][C] partial sums of a and a^2, or null
+  // backward inputs / outputs
+  const float* gmax;  // [B,N,C]
+  const float* gmin;  // [B,N,C] or null
+  const float* gsum;  // [C] or null
+  const float* gsq;   // [C] or null
+  float* dP;          // [B,N,C] or null
+  float* dQ;          // [B,N,C], pre-zeroed, accumulated with hardware fp32 atomics
+};
+
+__device__ __forceinline__ float act_apply(float z, int act, float slope) {
+  if (act == ACT_RELU) return fmaxf(z, 0.f);
+  if (act == ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// LPR lanes x float4 cover the C channels of one point; a wave owns G = 64/LPR points at once.
+template <int LPR, bool BWD>
+__global__ __launch_bounds__(kWgThreads) void dense_edge_kernel(const EdgeParams E) {
+  constexpr int G = kWave / LPR;
+  constexpr int U = 4;
+  __shared__ float red[kWavesPerWg][2][LPR * 4];
+
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / LPR;
+  const int cl = lane % LPR;
+  const int C = E.C, k = E.k;
+  const int64_t total_pts = static_cast<int64_t>(E.B) * E.N;
+  const int64_t groups = (total_pts + G - 1) / G;
+  const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+
+  for (int cb = 0; cb < C; cb += LPR * 4) {
+    const int c0 = cb + cl * 4;
+    const bool act_lane = c0 < C;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BWD) {
+      if (act_lane && E.gsum) load_vec<4>(gs, E.gsum + c0);
+      if (act_lane && E.gsq) load_vec<4>(gq, E.gsq + c0);
+    }
+
+    for (int64_t grp = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + wave; grp < groups; grp += wave_stride) {
+      const int64_t pt = grp * G + g;
+      const bool pt_ok = pt < total_pts && act_lane;
+      const int b = static_cast<int>(min(pt, total_pts - 1) / E.N);
+      const int n = static_cast<int>(min(pt, total_pts - 1) % E.N);
+      const int64_t row = (static_cast<int64_t>(b) * E.N + n) * C + c0;
+      const int64_t prow = (static_cast<int64_t>(b) * E.N + n) * E.ldp + c0;
+      float p[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pt_ok && E.P) load_vec<4>(p, E.P + prow);
+      const int64_t* irow = E.idx + b * E.ib + n * E.in_;
+      const float* Qb = E.Q + static_cast<int64_t>(b) * E.N * E.ldq + c0;
+
+      float vmx[4], vmn[4];
+      int amx[4], amn[4];
+      float gmx[4] = {0.f, 0.f, 0.f, 0.f}, gmn[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { vmx[j] = DGCN_NEG_INF; vmn[j] = -DGCN_NEG_INF; amx[j] = 0; amn[j] = 0; }
+      if constexpr (BWD) {
+        if (pt_ok) {
+          load_vec<4>(gmx, E.gmax + row);
+          if (E.gmin) load_vec<4>(gmn, E.gmin + row);
+          uint32_t pk = *reinterpret_cast<const uint32_t*>(E.amax + row);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) amx[j] = (pk >> (8 * j)) & 0xFF;
+          if (E.amin) {
+            pk = *reinterpret_cast<const uint32_t*>(E.amin + row);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amn[j] = (pk >> (8 * j)) & 0xFF;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amn[j] = -1;
+          }
+        }
+      }
+
+      for (int l0 = 0; l0 < k; l0 += U) {
+        float q[U][4];
+        int nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int l = l0 + u;
+          nb[u] = (pt_ok && l < k) ? static_cast<int>(irow[l * E.ik]) : -1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) q[u][j] = 0.f;
+          if (nb[u] >= 0) load_vec<4>(q[u], Qb + static_cast<int64_t>(nb[u]) * E.ldq);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (nb[u] < 0) continue;
+          const int l = l0 + u;
+          float dz[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float z = p[j] + q[u][j];
+            const float a = act_apply(z, E.act, E.slope);
+            if constexpr (!BWD) {
+              if (a > vmx[j]) { vmx[j] = a; amx[j] = l; }
+              if (a < vmn[j]) { vmn[j] = a; amn[j] = l; }
+              s1[j] += a;
+              s2[j] = fmaf(a, a, s2[j]);
+            } else {
+              float da = gs[j] + 2.f * a * gq[j];
+              if (l == amx[j]) da += gmx[j];
+              if (l == amn[j]) da += gmn[j];
+              dz[j] = da * act_grad(z, E.act, E.slope);
+              dp[j] += dz[j];
+            }
+          }
+          if constexpr (BWD) {
+            float* dq = E.dQ + (static_cast<int64_t>(b) * E.N + nb[u]) * E.ldq + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dq + j, dz[j]);
+          }
+        }
+      }
+
+      if (pt_ok) {
+        if constexpr (!BWD) {
+          store_vec<4>(E.vmax + row, vmx);
+          if (E.vmin) store_vec<4>(E.vmin + row, vmn);
+          if (E.amax) {
+            *reinterpret_cast<uint32_t*>(E.amax + row) =
+                (amx[0] & 0xFF) | ((amx[1] & 0xFF) << 8) | ((amx[2] & 0xFF) << 16) | ((amx[3] & 0xFF) << 24);
+          }
+          if (E.amin) {
+            *reinterpret_cast<uint32_t*>(E.amin + row) =
+                (amn[0] & 0xFF) | ((amn[1] & 0xFF) << 8) | ((amn[2] & 0xFF) << 16) | ((amn[3] & 0xFF) << 24);
+          }
+        } else {
+          if (E.dP) store_vec<4>(E.dP + prow, dp);
+        }
+      }
+    }
+
+    if constexpr (!BWD) {
+      if (E.stats) {
+        // combine the G point groups of the wave, then the waves of the workgroup, in a fixed order
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s1[j] += __shfl_xor(s1[j], off);
+            s2[j] += __shfl_xor(s2[j], off);
+          }
+        }
+        if (g == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            red[wave][0][cl * 4 + j] = s1[j];
+            red[wave][1][cl * 4 + j] = s2[j];
+          }
+        }
+        __syncthreads();
+        if (wave == 0 && g == 0 && act_lane) {
+          float t1[4], t2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t1[j] = ((red[0][0][cl * 4 + j] + red[1][0][cl * 4 + j]) + red[2][0][cl * 4 + j]) + red[3][0][cl * 4 + j];
+            t2[j] = ((red[0][1][cl * 4 + j] + red[1][1][cl * 4 + j]) + red[2][1][cl * 4 + j]) + red[3][1][cl * 4 + j];
+          }
+          float* st = E.stats + static_cast<int64_t>(blockIdx.x) * 2 * C;
+          store_vec<4>(st + c0, t1);
+          store_vec<4>(st + C + c0, t2);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+int edge_lpr(int C) {
+  const int need = (C + 3) / 4;
+  int lpr = 4;
+  while (lpr < need && lpr < kWave) lpr <<= 1;
+  return lpr;
+}
+
+int edge_grid(int64_t total_pts, int lpr) {
+  const int G = kWave / lpr;
+  const int64_t groups = (total_pts + G - 1) / G;
+  int64_t wgs = (groups + kWavesPerWg - 1) / kWavesPerWg;
+  if (wgs > 2048) wgs = 2048;
+  if (wgs < 1) wgs = 1;
+  return static_cast<int>(wgs);
+}
+
+template <bool BWD>
+void launch_edge(const EdgeParams& E, int lpr, int grid, hipStream_t s) {
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((dense_edge_kernel<4, BWD>), dim3(grid), dim3(kWgThreads), 0, s, E); break;
+    case 8: hipLaunchKernelGGL((dense_edge_kernel<8, BWD>), dim3(grid), dim3(kWgThreads), 0, s, E); break;
+    case 16: hipLaunchKernelGGL((dense_edge_kernel<16, BWD>), dim3(grid), dim3(kWgThreads), 0, s, E); break;
+    case 32: hipLaunchKernelGGL((dense_edge_kernel<32, BWD>), dim3(grid), dim3(kWgThreads), 0, s, E); break;
+    default: hipLaunchKernelGGL((dense_edge_kernel<64, BWD>), dim3(grid), dim3(kWgThreads), 0, s, E); break;
+  }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_vertex_gemm_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
+                                    int32_t C, int32_t N, const float* W, const float* bias,
+                                    int32_t M, float* out, void* stream) {
+  if (!x || !W || !out) return DGCN_E_NULL;
+  if (B < 0 || C <= 0 || N <= 0 || M <= 0) return DGCN_E_SHAPE;
+  if (B == 0) return DGCN_OK;
+  GemmParams P{x, sb, sc, sn, B, C, N, M, W, bias, out};
+  const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
+  const int grid = static_cast<int>((tiles + kWavesPerWg - 1) / kWavesPerWg);
+  hipLaunchKernelGGL(vertex_gemm_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
+  return launch_status();
+}
+
+// Number of workgroups the forward uses = rows of the `stats` partial buffer [n][2][C].
+extern "C" int32_t dgcn_dense_edge_reduce_num_partials(int32_t B, int32_t N, int32_t C) {
+  if (B <= 0 || N <= 0 || C <= 0) return 0;
+  return edge_grid(static_cast<int64_t>(B) * N, edge_lpr(C));
+}
+
+extern "C" int dgcn_dense_edge_reduce_fwd_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                                              const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk,
+                                              int32_t B, int32_t N, int32_t C, int32_t k, int32_t act,
+                                              float slope, float* vmax, float* vmin, uint8_t* amax,
+                                              uint8_t* amin, float* stats, void* stream) {
+  if (!Q || !idx || !vmax) return DGCN_E_NULL;
+  if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 255) return DGCN_E_SHAPE;
+  if (C % 4 != 0 || ldq < C || ldq % 4 != 0 || (P && (ldp < C || ldp % 4 != 0))) return DGCN_E_SHAPE;
+  if (act < ACT_NONE || act > ACT_LEAKY) return DGCN_E_MODE;
+  if (!al16(Q) || (P && !al16(P)) || !al16(vmax) || (vmin && !al16(vmin)) || (stats && !al16(stats)))
+    return DGCN_E_ALIGN;
+  if (B == 0) return DGCN_OK;
+  EdgeParams E{};
+  E.P = P; E.Q = Q; E.ldp = ldp; E.ldq = ldq; E.idx = idx; E.ib = idx_sb; E.in_ = idx_sn; E.ik = idx_sk;
+  E.B = B; E.N = N; E.C = C; E.k = k; E.act = act; E.slope = slope;
+  E.vmax = vmax; E.vmin = vmin; E.amax = amax; E.amin = amin; E.stats = stats;
+  const int lpr = edge_lpr(C);
+  launch_edge<false>(E, lpr, edge_grid(static_cast<int64_t>(B) * N, lpr), static_cast<hipStream_t>(stream));
+  return launch_status();
+}
+
+// dL/da_e = gmax[b,n,c]*[l==amax] + gmin[b,n,c]*[l==amin] + gsum[c] + 2 a_e gsq[c];  dz = dL/da * act'(z)
+// dP[b,n,:] = sum_l dz (overwritten);  dQ[b,j,:] += dz (hardware fp32 atomics; dQ must be zeroed by the caller)
+extern "C" int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                                              const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk,
+                                              int32_t B, int32_t N, int32_t C, int32_t k, int32_t act,
+                                              float slope, const uint8_t* amax, const uint8_t* amin,
+                                              const float* gmax, const float* gmin, const float* gsum,
+                                              const float* gsq, float* dP, float* dQ, void* stream) {
+  if (!Q || !idx || !amax || !gmax || !dQ) return DGCN_E_NULL;
+  if (gmin && !amin) return DGCN_E_NULL;
+  if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 255) return DGCN_E_SHAPE;
+  if (C % 4 != 0 || ldq < C || ldq % 4 != 0 || (P && (ldp < C || ldp % 4 != 0))) return DGCN_E_SHAPE;
+  if (act < ACT_NONE || act > ACT_LEAKY) return DGCN_E_MODE;
+  if (!al16(Q) || (P && !al16(P)) || !al16(gmax) || (gmin && !al16(gmin)) || (gsum && !al16(gsum)) ||
+      (gsq && !al16(gsq)) || (dP && !al16(dP)) || !al16(dQ))
+    return DGCN_E_ALIGN;
+  if (B == 0) return DGCN_OK;
+  EdgeParams E{};
+  E.P = P; E.Q = Q; E.ldp = ldp; E.ldq = ldq; E.idx = idx; E.ib = idx_sb; E.in_ = idx_sn; E.ik = idx_sk;
+  E.B = B; E.N = N; E.C = C; E.k = k; E.act = act; E.slope = slope;
+  E.amax = const_cast<uint8_t*>(amax); E.amin = const_cast<uint8_t*>(amin);
+  E.gmax = gmax; E.gmin = gmin; E.gsum = gsum; E.gsq = gsq; E.dP = dP; E.dQ = dQ;
+  const int lpr = edge_lpr(C);
+  launch_edge<true>(E, lpr, edge_grid(static_cast<int64_t>(B) * N, lpr), static_cast<hipStream_t>(stream));
+  return launch_status();
+}

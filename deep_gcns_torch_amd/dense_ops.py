@@ -1,0 +1,200 @@
+"""Autograd-aware wrappers of the dense (B,C,N,1) kernels of libdgcn:
+
+  knn_edge_index / knn_indices  fused distance + top-K + dilation (no (B,N,N) matrix)
+  vertex_gemm                   per-vertex EdgeConv GEMM on fp32 MFMA  -> point-major (B,N,M)
+  edge_reduce                   gather + act + neighbourhood max/min + BatchNorm sums
+
+Replaces gcn_lib/dense/torch_edge.py:32-58, gcn_lib/dense/torch_nn.py:75-96 and the hot part
+of gcn_lib/dense/torch_vertex.py:16-20,31-35 of the reference.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------------------
+# kNN
+# ----------------------------------------------------------------------------------------
+def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, ctr_out):
+    """x3: (B, C, N) fp32 view (any strides)."""
+    lib = _lib.load()
+    dev = _lib.require_device(x3)
+    B, C, N = x3.shape
+    with torch.cuda.device(dev):
+        rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,
+                                    dilation, nn_out.data_ptr(), _lib.ptr(ctr_out),
+                                    _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_knn_dense_f32")
+
+
+def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1) -> torch.Tensor:
+    """x (B,C,N,1) -> edge_index (2,B,N,k) int64: [0] = every `dilation`-th of the k*dilation nearest
+    neighbours (self included, ascending distance), [1] = centre ids."""
+    with torch.no_grad():
+        x3 = x.detach()
+        if x3.dtype != torch.float32:
+            x3 = x3.float()
+        x3 = x3.squeeze(-1) if x3.dim() == 4 else x3
+        B, C, N = x3.shape
+        K = k * dilation
+        kout = (K + dilation - 1) // dilation
+        ei = torch.empty(2, B, N, kout, dtype=torch.int64, device=x.device)
+        _knn_launch(x3, K, dilation, ei[0], ei[1])
+    return ei
+
+
+def knn_indices(pts: torch.Tensor, k: int, dilation: int = 1) -> torch.Tensor:
+    """pts (B,N,C) point-major features -> (B,N,k) int64 neighbour ids (sparse-layout callers)."""
+    with torch.no_grad():
+        p = pts.detach().float()
+        B, N, C = p.shape
+        K = k * dilation
+        out = torch.empty(B, N, (K + dilation - 1) // dilation, dtype=torch.int64, device=pts.device)
+        _knn_launch(p.permute(0, 2, 1), K, dilation, out, None)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# per-vertex GEMM (fp32 MFMA forward; the backward GEMMs are plain library matmuls)
+# ----------------------------------------------------------------------------------------
+class _VertexGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        lib = _lib.load()
+        dev = _lib.require_device(x, W, bias)
+        x3 = x.squeeze(-1) if x.dim() == 4 else x
+        if x3.dtype != torch.float32:
+            x3 = x3.float()
+        B, C, N = x3.shape
+        Wc = W.float().contiguous()
+        M = Wc.size(1)
+        bc = None if bias is None else bias.float().contiguous()
+        out = torch.empty(B, N, M, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = lib.dgcn_vertex_gemm_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N,
+                                          Wc.data_ptr(), _lib.ptr(bc), M, out.data_ptr(),
+                                          _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_vertex_gemm_f32")
+        ctx.save_for_backward(x3, Wc)
+        ctx.x_shape = x.shape
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x3, Wc = ctx.saved_tensors
+        gx = gW = gb = None
+        g2 = gout.reshape(-1, gout.size(-1))                               # (B*N, M)
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(gout, Wc.t()).permute(0, 2, 1).reshape(ctx.x_shape)   # (B,C,N[,1])
+        if ctx.needs_input_grad[1]:
+            xt = x3.permute(1, 0, 2).reshape(x3.size(1), -1)               # (C, B*N)
+            gW = torch.matmul(xt, g2)                                       # (C, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gW, gb
+
+
+def vertex_gemm(x: torch.Tensor, W: torch.Tensor, bias=None) -> torch.Tensor:
+    """out[b,n,m] = sum_c x[b,c,n] * W[c,m] + bias[m];  x (B,C,N,1) or (B,C,N), W (C,M)."""
+    return _VertexGemm.apply(x, W, bias)
+
+
+# ----------------------------------------------------------------------------------------
+# neighbourhood reduction
+# ----------------------------------------------------------------------------------------
+class _EdgeReduce(torch.autograd.Function):
+    """(vmax, vmin, sum_a, sum_a2) of a_{bnl} = act(P[b,n] + Q[b, idx[b,n,l]]).
+    PQ is (B,N,2C) [P | Q] when has_p else (B,N,C) = Q.  sum_* are float64 (C,) tensors."""
+
+    @staticmethod
+    def forward(ctx, PQ, idx, has_p: bool, act: int, slope: float, need_min: bool, need_stats: bool, track: bool):
+        lib = _lib.load()
+        dev = _lib.require_device(PQ, idx)
+        PQ = PQ.float().contiguous()
+        B, N, W = PQ.shape
+        C = W // 2 if has_p else W
+        k = idx.size(-1)
+        if idx.dtype != torch.int64:
+            idx = idx.long()
+        need_bwd = track and ctx.needs_input_grad[0]
+        vmax = torch.empty(B, N, C, device=dev, dtype=torch.float32)
+        vmin = torch.empty_like(vmax) if need_min else None
+        amax = torch.empty(B, N, C, device=dev, dtype=torch.uint8) if need_bwd else None
+        amin = torch.empty(B, N, C, device=dev, dtype=torch.uint8) if (need_bwd and need_min) else None
+        stats = None
+        if need_stats:
+            nparts = lib.dgcn_dense_edge_reduce_num_partials(B, N, C)
+            stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
+        p_ptr = PQ.data_ptr() if has_p else None
+        q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
+        with torch.cuda.device(dev):
+            rc = lib.dgcn_dense_edge_reduce_fwd_f32(
+                p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
+                B, N, C, k, act, slope, vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(amax), _lib.ptr(amin),
+                _lib.ptr(stats), _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_dense_edge_reduce_fwd_f32")
+        if need_stats:
+            tot = stats.double().sum(0)
+            s1, s2 = tot[0], tot[1]
+        else:
+            s1 = s2 = torch.zeros(C, device=dev, dtype=torch.float64)
+        if vmin is None:
+            vmin = vmax.new_zeros(())
+        if need_bwd:
+            ctx.save_for_backward(PQ, idx, amax, amin)
+            ctx.cfg = (has_p, act, slope, need_min, need_stats, C, k)
+        ctx.mark_non_differentiable(*([] if need_min else [vmin]))
+        return vmax, vmin, s1, s2
+
+    @staticmethod
+    def backward(ctx, gmax, gmin, gs1, gs2):
+        lib = _lib.load()
+        PQ, idx, amax, amin = ctx.saved_tensors
+        has_p, act, slope, need_min, need_stats, C, k = ctx.cfg
+        dev = PQ.device
+        B, N, W = PQ.shape
+        gmax = gmax.float().contiguous()
+        gmin_c = gmin.float().contiguous() if (need_min and gmin is not None) else None
+        gs = gs1.float().contiguous() if (need_stats and gs1 is not None) else None
+        gq = gs2.float().contiguous() if (need_stats and gs2 is not None) else None
+        dPQ = torch.zeros_like(PQ)                      # dQ half is accumulated with atomics
+        p_ptr = PQ.data_ptr() if has_p else None
+        q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
+        dp_ptr = dPQ.data_ptr() if has_p else None
+        dq_ptr = dPQ.data_ptr() + (C * 4 if has_p else 0)
+        with torch.cuda.device(dev):
+            rc = lib.dgcn_dense_edge_reduce_bwd_f32(
+                p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
+                B, N, C, k, act, slope, amax.data_ptr(), _lib.ptr(amin if gmin_c is not None else None),
+                gmax.data_ptr(), _lib.ptr(gmin_c), _lib.ptr(gs), _lib.ptr(gq), dp_ptr, dq_ptr,
+                _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_dense_edge_reduce_bwd_f32")
+        return dPQ, None, None, None, None, None, None, None
+
+
+def edge_reduce(PQ: torch.Tensor, idx: torch.Tensor, has_p: bool, act: int = ACT_NONE, slope: float = 0.2,
+                need_min: bool = False, need_stats: bool = False):
+    """Returns (vmax, vmin|None, sum_a, sum_a2).  Channel counts that are not a multiple of 4 are
+    zero-padded for the kernel's float4 lanes and sliced back."""
+    B, N, W = PQ.shape
+    C = W // 2 if has_p else W
+    pad = (-C) % 4
+    if pad:
+        if has_p:
+            P, Q = PQ[..., :C], PQ[..., C:]
+            PQ = torch.cat([F.pad(P, (0, pad)), F.pad(Q, (0, pad))], dim=-1)
+        else:
+            PQ = F.pad(PQ, (0, pad))
+    vmax, vmin, s1, s2 = _EdgeReduce.apply(PQ, idx, has_p, act, float(slope), need_min, need_stats,
+                                           torch.is_grad_enabled())
+    if pad:
+        vmax = vmax[..., :C]
+        vmin = vmin[..., :C] if need_min else vmin
+        s1, s2 = s1[:C], s2[:C]
+    return vmax, (vmin if need_min else None), s1, s2

@@ -1,0 +1,64 @@
+"""Sparse-layout (flattened (2, N*k) edge lists) dilated kNN graphs -- public surface of the
+reference's gcn_lib/sparse/torch_edge.py (Dilated :6-29, DilatedKnnGraph :32-50, knn_matrix :66-91,
+knn_graph_matrix :94-104).  The neighbour search itself is libdgcn's fused distance+select kernel
+(the same one the dense library uses); the tree-based torch_cluster variant is not provided.
+"""
+import torch
+from torch import nn
+
+__all__ = ["Dilated", "DilatedKnnGraph", "knn_matrix", "knn_graph_matrix"]
+
+
+class Dilated(nn.Module):
+    """Keep every d-th of the k*d sorted neighbours of each point; in stochastic mode, with
+    probability epsilon (training only), keep a random k of them instead.  The CPU RNG calls
+    (`torch.rand(1)` first, then `torch.randperm`) mirror the reference's stream exactly."""
+
+    def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0):
+        super().__init__()
+        self.dilation = dilation
+        self.stochastic = stochastic
+        self.epsilon = epsilon
+        self.k = k
+
+    def forward(self, edge_index, batch=None):
+        if self.stochastic and torch.rand(1) < self.epsilon and self.training:
+            num = self.k * self.dilation
+            pick = torch.randperm(num)[:self.k]
+            return edge_index.view(2, -1, num)[:, :, pick].reshape(2, -1)
+        return edge_index[:, ::self.dilation]
+
+
+def knn_matrix(x, k=16, batch=None):
+    """(N_total, C) features of equally sized clouds -> (nn_idx, center_idx), each (1, N_total*k),
+    neighbours sorted by ascending distance, self included, ids offset per cloud."""
+    from ... import dense_ops
+    with torch.no_grad():
+        n_clouds = 1 if batch is None else int(batch[-1]) + 1
+        pts = x.detach().reshape(n_clouds, -1, x.shape[-1])
+        n_points = pts.shape[1]
+        nn_idx = dense_ops.knn_indices(pts, k)                                   # (B, N, k) int64
+        nn_idx = nn_idx + torch.arange(0, n_points * n_clouds, n_points, device=x.device).view(n_clouds, 1, 1)
+        center = torch.arange(0, n_points * n_clouds, device=x.device).repeat_interleave(k)
+    return nn_idx.reshape(1, -1), center.view(1, -1)
+
+
+def knn_graph_matrix(x, k=16, batch=None):
+    nn_idx, center_idx = knn_matrix(x, k, batch)
+    return torch.cat((nn_idx, center_idx), dim=0)
+
+
+class DilatedKnnGraph(nn.Module):
+    def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0, knn='matrix'):
+        super().__init__()
+        self.dilation = dilation
+        self.stochastic = stochastic
+        self.epsilon = epsilon
+        self.k = k
+        self._dilated = Dilated(k, dilation, stochastic, epsilon)
+        if knn != 'matrix':
+            raise NotImplementedError("only knn='matrix' is implemented (tree kNN needs torch_cluster)")
+        self.knn = knn_graph_matrix
+
+    def forward(self, x, batch):
+        return self._dilated(self.knn(x, self.k * self.dilation, batch), batch)

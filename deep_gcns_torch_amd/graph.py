@@ -89,6 +89,7 @@ class Graph:
         # --- CSC by source (stable) ---
         self.t_rowptr = self.t_col = self.t_eperm = None
         self.t_work = None
+        self.out_deg = None
         if need_transpose:
             tperm = torch.sort(src, stable=True).indices if E else torch.zeros(0, dtype=torch.long, device=dev)
             tcounts = torch.bincount(src, minlength=n_src) if E else torch.zeros(n_src, dtype=torch.long, device=dev)
@@ -97,6 +98,7 @@ class Graph:
             self.t_rowptr = t_rowptr.to(torch.int32)
             self.t_col = dst[tperm].to(torch.int32).contiguous()
             self.t_eperm = tperm.to(torch.int32).contiguous()
+            self.out_deg = tcounts.to(torch.float32)
             self.t_work = _work_list(self.t_rowptr, hub_chunk)
 
         self._c = self._make_struct()

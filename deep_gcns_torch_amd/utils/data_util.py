@@ -1,0 +1,49 @@
+"""OGB feature-table sizes and the random node partition helpers the sparse library and the
+OGB example scripts import from `utils.data_util` (reference: utils/data_util.py:14-61,246-348).
+No h5py / torch_scatter / PyG imports at module load."""
+import numpy as np
+import torch
+
+# sizes of the OGB categorical feature vocabularies (ogb/utils/features.py; reference
+# utils/data_util.py:246-282 lists the same tables, each ends with a 'misc' bucket)
+_ATOM_DIMS = [119, 4, 12, 12, 10, 6, 6, 2, 2]   # atomic num, chirality, degree, charge, numH, radical e, hybridisation, aromatic, in ring
+_BOND_DIMS = [5, 6, 2]                            # bond type, stereo, conjugated
+
+
+def get_atom_feature_dims():
+    return list(_ATOM_DIMS)
+
+
+def get_bond_feature_dims():
+    return list(_BOND_DIMS)
+
+
+def intersection(lst1, lst2):
+    return list(set(lst1) & set(lst2))
+
+
+def process_indexes(idx_list):
+    """Map each id to its position and return the ids ordered by id (utils/data_util.py:18-23)."""
+    pos = {idx: i for i, idx in enumerate(idx_list)}
+    return [pos[k] for k in sorted(pos)]
+
+
+def random_partition_graph(num_nodes, cluster_number=10):
+    """Uniform random cluster id per node (utils/data_util.py:43-45)."""
+    return np.random.randint(cluster_number, size=num_nodes)
+
+
+def generate_sub_graphs(adj, parts, cluster_number=10, batch_size=1):
+    """Induced sub-graphs of a scipy CSR adjacency for groups of `batch_size` clusters
+    (utils/data_util.py:48-61): returns (node id lists, COO edge_index tensors)."""
+    num_batches = cluster_number // batch_size
+    sg_nodes, sg_edges = [], []
+    for b in range(num_batches):
+        nodes = np.where(parts == batch_size * b)[0]
+        for k in range(1, batch_size):
+            nodes = np.concatenate((nodes, np.where(parts == batch_size * b + k)[0]), axis=0)
+        sub = adj[nodes, :][:, nodes]
+        coo = sub.tocoo()
+        sg_nodes.append(nodes)
+        sg_edges.append(torch.from_numpy(np.vstack((coo.row, coo.col))).long())
+    return sg_nodes, sg_edges

@@ -144,6 +144,58 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           float* grad_edge_attr, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dense (B x C x N x 1) point-cloud path.
+ * ------------------------------------------------------------------------------------ */
+
+/* Fused pairwise distance + exact top-K + dilation.
+ * Replaces pairwise_distance / dense_knn_matrix / DenseDilated.forward (deterministic branch)
+ * (gcn_lib/dense/torch_edge.py:32-42, 45-58, 26-28) and knn_matrix (gcn_lib/sparse/torch_edge.py:66-91).
+ *   x        (B, C, N) fp32 with element strides (sb, sc, sn)  -- channel slices / views are fine
+ *   K        = k * dilation neighbours selected per point, self included, ascending distance
+ *            D_ij = (|x_i|^2 + (-2 <x_i, x_j>)) + |x_j|^2 in fp32; equal distances ordered by index
+ *   nn_out   [B, N, ceil(K/dilation)] int64: positions 0, d, 2d, ... of the sorted list
+ *   ctr_out  same shape or NULL: the centre point id (edge_index[1])
+ * Limits: N <= 4096, K <= 512, K <= N. */
+int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
+                       int32_t N, int32_t K, int32_t dilation, int64_t* nn_out, int64_t* ctr_out,
+                       void* stream);
+
+/* Per-vertex GEMM on fp32 MFMA: out[(b*N+n)*M + m] = sum_c x[b,c,n] * W[c*M+m] + bias[m].
+ * With W = [(W1-W2)^T | W2^T] this yields P and Q of the EdgeConv split
+ * (replaces the 1x1 Conv2d over (B,2C,N,k) of BasicConv inside EdgeConv2d,
+ *  gcn_lib/dense/torch_vertex.py:34 + gcn_lib/dense/torch_nn.py:52).  bias may be NULL. */
+int dgcn_vertex_gemm_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
+                         int32_t N, const float* W, const float* bias, int32_t M, float* out,
+                         void* stream);
+
+/* Neighbourhood reduction  a_{bnl} = act(P[b,n,:] + Q[b, idx[b,n,l], :]),  l < k:
+ *   vmax/vmin [B,N,C]  max_l / min_l a   (vmin, amin optional)
+ *   amax/amin [B,N,C]  uint8 slot l attaining it (first on ties), saved for the backward
+ *   stats     [dgcn_dense_edge_reduce_num_partials(B,N,C)][2][C] per-workgroup partial sums of a and
+ *             a^2 (BatchNorm2d training statistics over B*N*k), fixed reduction order; optional
+ * Replaces batched_index_select x2 + cat + act + torch.max (gcn_lib/dense/torch_nn.py:75-96,
+ * gcn_lib/dense/torch_vertex.py:16-20,31-35).  P may be NULL (MRConv2d: Q = x point-major, act none).
+ *   P/Q rows may be strided (ldp/ldq floats between consecutive points, multiples of 4): P and Q are the two
+ *   halves of one vertex-GEMM output;  idx int64 (B,N,k) with element strides;  act: 0 none, 1 relu, 2 leaky-relu(slope);  C % 4 == 0, k <= 255. */
+int32_t dgcn_dense_edge_reduce_num_partials(int32_t B, int32_t N, int32_t C);
+
+int dgcn_dense_edge_reduce_fwd_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                                   const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk, int32_t B, int32_t N, int32_t C,
+                                   int32_t k, int32_t act, float slope, float* vmax, float* vmin,
+                                   uint8_t* amax, uint8_t* amin, float* stats, void* stream);
+
+/* Backward of the above for L(vmax, vmin, sum a, sum a^2):
+ *   dL/da_e = gmax*[l==amax] + gmin*[l==amin] + gsum[c] + 2 a_e gsq[c];  dz = dL/da * act'(z)
+ *   dP[b,n,:] = sum_l dz (overwritten, optional);  dQ[b,j,:] += dz with hardware fp32 atomics
+ *   (dQ must be zero-filled by the caller; summation order, hence the last bits, may vary run to run). */
+int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                                   const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk, int32_t B, int32_t N, int32_t C,
+                                   int32_t k, int32_t act, float slope, const uint8_t* amax,
+                                   const uint8_t* amin, const float* gmax, const float* gmin,
+                                   const float* gsum, const float* gsq, float* dP, float* dQ,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
