@@ -144,7 +144,7 @@ class EdgConv(nn.Module):
             qmin = -ops.gen_aggregate(-Q, g, aggr='max', relu_eps=False)
             pre = scale * (P + torch.where(scale >= 0, qmax, qmin)) + shift
         out = pre
-        for m in self.nn[1:]:
+        for m in list(self.nn.children())[1:]:
             if not isinstance(m, nn.BatchNorm1d):
                 out = m(out)                                # activation (+ dropout)
         return torch.where((g.deg > 0).unsqueeze(1), out, torch.zeros_like(out))
