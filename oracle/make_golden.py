@@ -209,9 +209,31 @@ def dense_cases(dense):
     return cases
 
 
+def model_key_tables():
+    """state_dict key -> shape of the reference's example architectures built on the REFERENCE gcn_lib."""
+    import io
+    import tempfile
+    from contextlib import redirect_stdout
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_models
+    out = {}
+    with redirect_stdout(io.StringIO()), tempfile.TemporaryDirectory() as tmp:
+        models = dict(sem_seg_dense_resgcn28=ref_models.dense_deepgcn(28),
+                      ogbn_arxiv_deepergcn28=ref_models.arxiv_deepergcn(28),
+                      ogbn_proteins_style_learn=ref_models.arxiv_deepergcn(3, gcn_aggr="softmax", learn_t=True,
+                                                                       msg_norm=True, learn_msg_scale=True, mlp_layers=2, norm="layer"),
+                      ppi_deepgcn_mr=ref_models.ppi_deepgcn("mr"), ppi_deepgcn_edge=ref_models.ppi_deepgcn("edge"),
+                      proteins_revgcn=ref_models.proteins_revgcn(tmp))
+    for name, m in models.items():
+        out[name] = dict(keys={k: tuple(v.shape) for k, v in m.state_dict().items()},
+                         n_params=sum(p.numel() for p in m.parameters()))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     dense, sparse = refshim.import_reference()
+    torch.save(model_key_tables(), os.path.join(GOLD, "model_keys.pt"))
     torch.set_num_threads(8)
     agg = sparse_aggregate_cases(sparse)
     torch.save(agg, os.path.join(GOLD, "sparse_aggregate.pt"))

@@ -1,0 +1,98 @@
+"""CPU drop-in checks: the reference's OWN example architectures (loaded by path from /root/reference,
+build container only) are instantiated on top of this package's gcn_lib/utils and must expose exactly
+the reference's state_dict keys, shapes and parameter counts (checkpoint compatibility).
+Forward passes are exercised on the GPU (tests/test_models_gpu.py); here nothing is computed."""
+import io
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+import torch
+
+import ref_models
+from conftest import load_golden
+
+KEYS = load_golden("model_keys.pt")
+
+needs_ref = pytest.mark.skipif(not ref_models.have_reference(), reason="/root/reference not present")
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    import deep_gcns_torch_amd
+    for name in [n for n in sys.modules if n == "gcn_lib" or n.startswith("gcn_lib.") or n == "utils" or n.startswith("utils.")]:
+        del sys.modules[name]
+    lib = deep_gcns_torch_amd.install(reference_root=ref_models.REF if ref_models.have_reference() else None)
+    assert "deep_gcns_torch_amd" in sys.modules["gcn_lib"].__name__
+    yield lib
+
+
+def _check(model, name):
+    want = KEYS[name]
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert list(got.keys()) == list(want["keys"].keys())
+    assert got == want["keys"]
+    assert sum(p.numel() for p in model.parameters()) == want["n_params"]
+
+
+@needs_ref
+def test_sem_seg_dense_resgcn28(dropin):
+    with redirect_stdout(io.StringIO()):
+        m = ref_models.dense_deepgcn(28)
+    _check(m, "sem_seg_dense_resgcn28")
+    assert type(m.head.gconv).__module__.startswith("deep_gcns_torch_amd")
+    assert m.backbone[26].body.k == 16 and m.backbone[26].body.d == 27       # attributes callers read
+
+
+@needs_ref
+def test_ogbn_arxiv_deepergcn(dropin):
+    with redirect_stdout(io.StringIO()):
+        m = ref_models.arxiv_deepergcn(28)
+        m2 = ref_models.arxiv_deepergcn(3, gcn_aggr="softmax", learn_t=True, msg_norm=True, learn_msg_scale=True,
+                                        mlp_layers=2, norm="layer")
+    _check(m, "ogbn_arxiv_deepergcn28")
+    _check(m2, "ogbn_proteins_style_learn")
+    g = m2.gcns[0]
+    assert isinstance(g.t, torch.nn.Parameter) and g.t.shape == (1,) and g.learn_t is True
+    assert m.gcns[0].t == 0.1 and m.gcns[0].learn_t is False
+    assert g.msg_norm.msg_scale.shape == (1,)
+    with redirect_stdout(io.StringIO()):
+        m2.print_params(final=True)          # reads gcn.t / gcn.msg_norm.msg_scale (model.py:142-178)
+
+
+@needs_ref
+@pytest.mark.parametrize("conv", ["mr", "edge"])
+def test_ppi_deepgcn(dropin, conv):
+    _check(ref_models.ppi_deepgcn(conv), f"ppi_deepgcn_{conv}")
+
+
+@needs_ref
+def test_proteins_revgcn(dropin, tmp_path):
+    with redirect_stdout(io.StringIO()):
+        m = ref_models.proteins_revgcn(str(tmp_path))
+    _check(m, "proteins_revgcn")
+
+
+def test_install_registers_every_reference_module_path(dropin):
+    from gcn_lib.dense import (BasicConv, DenseDilatedKnnGraph, DenseDynBlock2d, GraphConv2d, PlainDynBlock2d,  # noqa: F401
+                               ResDynBlock2d)
+    from gcn_lib.sparse import DenseGraphBlock, GraphConv, MLP, MultiSeq, ResGraphBlock  # noqa: F401
+    from gcn_lib.sparse.torch_nn import norm_layer  # noqa: F401
+    from gcn_lib.sparse.torch_vertex import GENConv  # noqa: F401
+    from gcn_lib.sparse.torch_message import GenMessagePassing, MsgNorm  # noqa: F401
+    from utils.pyg_util import scatter_  # noqa: F401
+    from utils.data_util import get_atom_feature_dims, get_bond_feature_dims
+    assert get_atom_feature_dims() == [119, 4, 12, 12, 10, 6, 6, 2, 2] and get_bond_feature_dims() == [5, 6, 2]
+
+
+def test_unsupported_options_fail_loudly(dropin):
+    from gcn_lib.dense import DynConv2d, EdgeConv2d
+    from gcn_lib.sparse import GraphConv
+    with pytest.raises(NotImplementedError):
+        EdgeConv2d(8, 8, "relu", "instance")
+    with pytest.raises(NotImplementedError):
+        DynConv2d(8, 8, knn="tree")
+    with pytest.raises(NotImplementedError):
+        GraphConv(8, 8, "gat")
+    with pytest.raises(NotImplementedError):
+        GraphConv(8, 8, "bogus")
