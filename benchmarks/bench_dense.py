@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Dense point-cloud hot path micro-benchmark (BASELINE.md config 2 shapes: B=8, N=4096, k=16, C=64).
+
+Prints one JSON line per measurement: kNN graph build at dilation 1/14/27, EdgeConv2d (relu, batch-norm)
+forward and forward+backward, a full ResDynBlock2d step, and (optionally) the CPU oracle beside them.
+    python benchmarks/bench_dense.py [--cpu-baseline] [--iters 20]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--cpu-baseline", action="store_true")
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--C", type=int, default=64)
+    ap.add_argument("--k", type=int, default=16)
+    a = ap.parse_args()
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from gcn_lib.dense import DenseDilatedKnnGraph, EdgeConv2d, ResDynBlock2d
+    dev = torch.device("cuda:0")
+    B, N, C, k = a.B, a.N, a.C, a.k
+    torch.manual_seed(0)
+    x = torch.randn(B, C, N, 1, device=dev)
+    edges = B * N * k
+    out = []
+
+    for d in (1, 14, 27):
+        g = DenseDilatedKnnGraph(k, d)
+        avg, mn = timed(lambda: g(x), a.iters)
+        flops = 2.0 * B * N * N * C
+        out.append(dict(op="knn_dense", dilation=d, K=k * d, ms_avg=avg, ms_min=mn,
+                        distance_tflops=flops / (avg * 1e-3) / 1e12, rows_per_s=B * N / (avg * 1e-3)))
+    ei = DenseDilatedKnnGraph(k, 1)(x)
+    conv = EdgeConv2d(C, C, "relu", "batch", True).to(dev).train()
+    xg = x.clone().requires_grad_(True)
+    go = torch.randn(B, C, N, 1, device=dev)
+    with torch.no_grad():
+        avg, mn = timed(lambda: conv(x, ei), a.iters)
+    out.append(dict(op="edgeconv2d_fwd", ms_avg=avg, ms_min=mn, edges_per_s=edges / (avg * 1e-3)))
+
+    def fb():
+        y = conv(xg, ei)
+        torch.autograd.grad(y, [xg] + list(conv.parameters()), go)
+    avg, mn = timed(fb, a.iters)
+    out.append(dict(op="edgeconv2d_fwd_bwd", ms_avg=avg, ms_min=mn, edges_per_s=edges / (avg * 1e-3)))
+
+    blk = ResDynBlock2d(C, k, 14, "edge", "relu", "batch", True).to(dev).train()
+
+    def blk_fb():
+        y = blk(xg)
+        torch.autograd.grad(y, [xg] + list(blk.parameters()), go)
+    avg, mn = timed(blk_fb, a.iters)
+    out.append(dict(op="resdynblock2d_d14_fwd_bwd (knn + edgeconv + residual)", ms_avg=avg, ms_min=mn,
+                    edges_per_s=edges / (avg * 1e-3)))
+
+    if a.cpu_baseline:
+        from oracle import dense_ref
+        torch.set_num_threads(os.cpu_count())
+        xc = x.cpu()
+        t0 = time.perf_counter(); dense_ref.dense_knn_matrix(xc, k * 14); t_knn = time.perf_counter() - t0
+        nn = torch.nn.Sequential(torch.nn.Conv2d(2 * C, C, 1), torch.nn.ReLU(), torch.nn.BatchNorm2d(C)).train()
+        eic = ei.cpu()
+        xr = xc.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        y = dense_ref.edgeconv2d(xr, eic, nn)
+        t_f = time.perf_counter() - t0
+        y.backward(go.cpu())
+        t_fb = time.perf_counter() - t0
+        out.append(dict(op="cpu_oracle", cores=os.cpu_count(), knn_K224_ms=t_knn * 1e3, edgeconv_fwd_ms=t_f * 1e3,
+                        edgeconv_fwd_bwd_ms=t_fb * 1e3, edgeconv_fwd_bwd_edges_per_s=edges / t_fb))
+    for r in out:
+        r.update(B=B, N=N, C=C, k=k)
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -60,7 +60,7 @@ def test_sparse_module_matches_reference(case):
     for pname, g in case["param_grads"].items():
         if g is None:
             continue
-        _close(named[pname].grad, g, rtol=5e-4, atol_scale=1e-5, what=f"grad {pname}")
+        _close(named[pname].grad, g, rtol=5e-4, atol_scale=4e-5, what=f"grad {pname}")
     after = m.state_dict()
     for k, v in case["state_dict"].items():            # running stats after one training step
         if "running" in k or "num_batches" in k:
