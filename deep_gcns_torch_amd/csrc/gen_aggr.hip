@@ -70,6 +70,9 @@ struct BwdParams {
   const float* gcoef;
   const void* aux1;
   const float* out;
+  const float* gshift;    // [n_dst, C] g_i * exp(kshift_c - L_i)  (single-gather softmax backward) or null
+  const float* kshift;    // [C] per-channel shift
+  const int32_t* shift_ok;  // device flag: 1 = the shifted form is numerically safe for this call
   float* grad_x;
   float* grad_ea;
   float* ws;  // partial slots: [slot][C]
@@ -453,8 +456,10 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
 // backward: walk the CSC (rows = sources).  For CSC position e with destination i and
 // original edge id oe:   dz_e = R(z_e) * K(m_e, i)      
 // ---------------------------------------------------------------------------------------
+constexpr int kModeSoftmaxShifted = 100;  // internal: softmax backward with ONE gathered row per edge
+
 template <int MODE, int VEC, int LPR, bool HAS_EA>
-__global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
+__device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   constexpr int G = kWave / LPR;
   constexpr int U = (VEC == 4) ? 4 : 8;
   constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
@@ -477,10 +482,13 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
     for (int cb = 0; cb < C; cb += LPR * VEC) {
       const int c0 = cb + cl * VEC;
       const bool act = c0 < C;
-      float xs[VEC], acc[VEC];
+      float xs[VEC], acc[VEC], ksh[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; }
+      for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; ksh[j] = 0.f; }
       if (act) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
+      if constexpr (MODE == kModeSoftmaxShifted) {
+        if (act) load_vec<VEC>(ksh, P.kshift + c0);
+      }
 
       for (int blk = w.beg; blk < w.end; blk += kWave) {
         const int nb = min(kWave, w.end - blk);
@@ -507,7 +515,11 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
             }
             if (ok[u] && act) {
               const int64_t ro = static_cast<int64_t>(dst) * C + c0;
-              load_vec<VEC>(gc[u], P.gcoef + ro);
+              if constexpr (MODE == kModeSoftmaxShifted) {
+                load_vec<VEC>(gc[u], P.gshift + ro);
+              } else {
+                load_vec<VEC>(gc[u], P.gcoef + ro);
+              }
               if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
                 load_vec<VEC>(a1[u], static_cast<const float*>(P.aux1) + ro);
                 if (learn_t) load_vec<VEC>(oo[u], P.out + ro);
@@ -534,6 +546,9 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
                 float wgt = fast_exp(t * m - a1[u][j]);
                 if (learn_t) wgt *= 1.f + t * (m - oo[u][j]);
                 k = gc[u][j] * wgt;
+              } else if constexpr (MODE == kModeSoftmaxShifted) {
+                // g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] * exp(t m - K_c): the bracket was gathered
+                k = gc[u][j] * fast_exp(t * m - ksh[j]);
               } else if constexpr (MODE == DGCN_AGGR_POWER) {
                 const bool in = (m >= kPowLo) && (m <= kPowHi);
                 const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
@@ -567,6 +582,39 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
         }
       }
     }
+  }
+}
+
+template <int MODE, int VEC, int LPR, bool HAS_EA>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    // single-gather form when the caller prepared it and the device-side range check passed
+    if (P.gshift != nullptr && !P.learn_t && *P.shift_ok != 0) {
+      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, HAS_EA>(P);
+      return;
+    }
+  }
+  gen_aggr_bwd_body<MODE, VEC, LPR, HAS_EA>(P);
+}
+
+// out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])   (node-wise prologue of the single-gather backward)
+__global__ __launch_bounds__(kWgThreads) void softmax_bwd_prep_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ L,
+                                                                      const float* __restrict__ kshift,
+                                                                      float* __restrict__ out, int64_t n_vec4,
+                                                                      int c_vec4) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec4; i += stride) {
+    const int cv = static_cast<int>(i % c_vec4);
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4 lv = reinterpret_cast<const float4*>(L)[i];
+    const float4 kv = reinterpret_cast<const float4*>(kshift)[cv];
+    float4 o;
+    o.x = gv.x * fast_exp(kv.x - lv.x);
+    o.y = gv.y * fast_exp(kv.y - lv.y);
+    o.z = gv.z * fast_exp(kv.z - lv.z);
+    o.w = gv.w * fast_exp(kv.w - lv.w);
+    reinterpret_cast<float4*>(out)[i] = o;
   }
 }
 
@@ -678,6 +726,20 @@ extern "C" size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t
   return static_cast<size_t>(g->n_slots) * 4u * static_cast<size_t>(channels) * sizeof(float);
 }
 
+extern "C" int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshift, float* out,
+                                         int64_t n_rows, int32_t channels, void* stream) {
+  if (!g || !L || !kshift || !out) return DGCN_E_NULL;
+  if (n_rows < 0 || channels <= 0 || channels % 4 != 0) return DGCN_E_SHAPE;
+  if (!aligned16(g) || !aligned16(L) || !aligned16(kshift) || !aligned16(out)) return DGCN_E_ALIGN;
+  if (n_rows == 0) return DGCN_OK;
+  const int64_t n4 = n_rows * (channels / 4);
+  int64_t blocks = (n4 + kWgThreads - 1) / kWgThreads;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_bwd_prep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWgThreads), 0,
+                     static_cast<hipStream_t>(stream), g, L, kshift, out, n4, channels / 4);
+  return launch_status();
+}
+
 extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
   if (!g || g->t_n_work == 0) return 0;
   return static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float);
@@ -730,7 +792,8 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
                                      const float* edge_attr, int32_t channels, int32_t mode,
                                      int32_t msg, int32_t flags, float t, float p, float eps,
                                      const float* t_dev, const float* p_dev, const float* gcoef,
-                                     const void* aux1, const float* out, float* grad_x,
+                                     const void* aux1, const float* out, const float* gshift,
+                                     const float* kshift, const int32_t* shift_ok, float* grad_x,
                                      float* grad_edge_attr, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
@@ -761,6 +824,10 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
+  P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr;
+  if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
+    P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
+  }
   P.ws = static_cast<float*>(workspace);
 
   const int n_items = g->t_n_work ? g->t_n_work : g->n_src;

@@ -21,6 +21,8 @@ _MODES = {
     "power": _lib.AGGR_POWER, "power_sum": _lib.AGGR_POWER,
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
+SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
+SHIFT_MAX_RANGE = 60.0             # max_i L - min_i L per channel below which exp(K-L), exp(tm-K) stay in fp32 range
 
 
 def _scalar_arg(v):
@@ -121,11 +123,25 @@ class _GenAggregate(torch.autograd.Function):
                 grad_ea = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+            gshift = kshift = shift_ok = None
+            if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
+                # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  The
+                # range check stays on the device (no host sync); the kernel falls back to two gathers.
+                lmin, lmax = torch.aminmax(aux1, dim=0)
+                kshift = ((lmin + lmax) * 0.5).contiguous()
+                shift_ok = ((lmax - lmin).amax() < SHIFT_MAX_RANGE).to(torch.int32)
+                gshift = torch.empty_like(gcoef)
+                with torch.cuda.device(dev):
+                    rc = lib.dgcn_softmax_bwd_prep_f32(gcoef.data_ptr(), aux1.data_ptr(), kshift.data_ptr(),
+                                                       gshift.data_ptr(), gcoef.size(0), C,
+                                                       _lib.current_stream_handle(dev))
+                _lib.check(rc, "dgcn_softmax_bwd_prep_f32")
             with torch.cuda.device(dev):
                 rc = lib.dgcn_gen_aggr_bwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
                     ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
-                    gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), grad_x.data_ptr(),
+                    gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
+                    _lib.ptr(shift_ok), grad_x.data_ptr(),
                     _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
             _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
             if not ctx.needs_input_grad[0]:

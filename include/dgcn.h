@@ -131,6 +131,7 @@ int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
  *             SOFTMAX: g_i    POWER: g_i * r_i^(1/p-1) / max(deg_i,1) * 1[lo<=q_i<=hi]
  *   aux1    as written by the forward (SOFTMAX: L_i, MAX: arg-max edge ids)
  *   out     forward output (only read for SOFTMAX with DGCN_FLAG_LEARN_T)
+ *   gshift, kshift, shift_ok   optional single-gather form for SOFTMAX (see dgcn_softmax_bwd_prep_f32), or NULL
  *   grad_x  [n_src, C] contiguous, fully overwritten
  *   grad_edge_attr [E, C] in original edge order or NULL
  */
@@ -140,9 +141,19 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           const float* edge_attr, int32_t channels, int32_t mode,
                           int32_t msg, int32_t flags, float t, float p, float eps,
                           const float* t_dev, const float* p_dev, const float* gcoef,
-                          const void* aux1, const float* out, float* grad_x,
+                          const void* aux1, const float* out, const float* gshift,
+                          const float* kshift, const int32_t* shift_ok, float* grad_x,
                           float* grad_edge_attr, void* workspace, size_t workspace_bytes,
                           void* stream);
+
+/* Node-wise prologue of the single-gather softmax backward:
+ *   out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])          (channels % 4 == 0)
+ * With it, dL/dm_e = g_i exp(t m_e - L_i) = out_i * exp(t m_e - kshift_c): the edge walk gathers ONE row
+ * per edge instead of two.  The caller passes (gshift=out, kshift, shift_ok) to dgcn_gen_aggr_bwd_f32;
+ * shift_ok is a DEVICE flag (1 when max_i L - min_i L is small enough for fp32, decided without a host
+ * sync); when it is 0, or the three pointers are NULL, the kernel uses the two-gather form. */
+int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshift, float* out,
+                              int64_t n_rows, int32_t channels, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense (B x C x N x 1) point-cloud path.

@@ -160,3 +160,45 @@ def test_arxiv_shape_properties():
     torch.testing.assert_close(xg.grad, odeg * (x > 0).float() * torch.ones(1, C, device=dev), rtol=1e-5, atol=1e-5)
     # run-to-run bit reproducibility
     assert torch.equal(ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.1), sm)
+
+
+@pytest.mark.parametrize("t,expect_shifted", [(0.1, True), (1.0, True), (40.0, False)])
+def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_shifted):
+    """The softmax backward gathers ONE pre-scaled row per edge when max L - min L < 60 per channel,
+    otherwise (decided on the device, no host sync) two rows.  Both must match the float64 oracle."""
+    from deep_gcns_torch_amd import ops
+    from oracle import sparse_ref
+    dev = _dev()
+    ei = AGG["graphs"]["tricky"]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(257, 64, generator=g) * 2.0
+    probe = torch.randn(257, 64, generator=g)
+    xr = x.double().requires_grad_(True)
+    ref = sparse_ref.gen_propagate(xr, ei, aggr="softmax_sg", t=t)
+    (ref * probe.double()).sum().backward()
+    grads = {}
+    for flag in (True, False):
+        ops.SINGLE_GATHER_SOFTMAX_BWD = flag
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            out = ops.gen_aggregate(xd, ei.to(dev), aggr="softmax_sg", t=t)
+            (out * probe.to(dev)).sum().backward()
+        finally:
+            ops.SINGLE_GATHER_SOFTMAX_BWD = True
+        grads[flag] = xd.grad.cpu()
+        gs = xr.grad.abs().max().item()
+        torch.testing.assert_close(grads[flag].double(), xr.grad, rtol=RTOL, atol=2e-6 * max(gs, 1.0))
+    # range check itself
+    xd = x.to(dev)
+    from deep_gcns_torch_amd.graph import Graph
+    m = torch.relu(x) + 1e-7
+    lse = torch.zeros(257, 64, dtype=torch.float64)
+    s = (t * m.double())[ei[0]]
+    mx = torch.zeros(257, 64, dtype=torch.float64).scatter_reduce_(0, ei[1].view(-1, 1).expand(-1, 64), s, "amax", include_self=False)
+    den = torch.zeros(257, 64, dtype=torch.float64).index_add_(0, ei[1], torch.exp(s - mx[ei[1]]))
+    has = torch.bincount(ei[1], minlength=257) > 0
+    lse[has] = (mx + torch.log(den.clamp_min(1e-300)))[has]
+    rng = float((lse.amax(0) - lse.amin(0)).max())
+    assert (rng < 60.0) == expect_shifted
+    if not expect_shifted:
+        assert torch.equal(grads[True], grads[False])     # same two-gather code path, bit-identical
