@@ -230,10 +230,64 @@ def model_key_tables():
     return out
 
 
+def full_model_cases():
+    """Small instances of the reference's example models, REAL architecture files on the REFERENCE gcn_lib."""
+    import argparse
+    import io
+    from contextlib import redirect_stdout
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_models
+    cases = []
+
+    def record(name, model, inputs, ctor):
+        model.train()
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        out = model(*inputs)
+        probe = _probe(out.shape, 5)
+        wrt = [t for t in inputs if t.is_floating_point() and t.requires_grad]
+        (out * probe).sum().backward()          # (.backward, not autograd.grad: re-entrant checkpointing)
+        grads = [t.grad.clone() for t in wrt]
+        cases.append(dict(name=name, ctor=ctor, inputs=[t.detach() for t in inputs], probe=probe, out=out.detach(),
+                          grads=[g for g in grads], state_dict_before=sd0))
+
+    with redirect_stdout(io.StringIO()):
+        torch.manual_seed(31)
+        m = ref_models.dense_deepgcn(4, n_filters=32, k=8, stochastic=False, epsilon=0.0, dropout=0.0)
+        pos = synth.lattice_cloud(2, 3, 256, seed=9)
+        x = torch.cat([pos, torch.rand(2, 6, 256, 1)], dim=1).requires_grad_(True)
+        record("sem_seg_dense_resgcn4", m, [x], dict(n_blocks=4, channels=32, k=8))
+
+        torch.manual_seed(32)
+        m = ref_models.arxiv_deepergcn(8, in_channels=32, hidden_channels=64, num_tasks=10, dropout=0.0)
+        ei = synth.tricky_graph()
+        x = torch.randn(257, 32, requires_grad=True)
+        record("ogbn_arxiv_deepergcn8_ckpt", m, [x, ei], dict(num_layers=8, in_channels=32, hidden=64, num_tasks=10))
+
+        for conv in ("mr", "edge"):
+            torch.manual_seed(33)
+            m = ref_models.ppi_deepgcn(conv, dropout=0.0)
+            x = torch.randn(257, 50, requires_grad=True)
+            data = argparse.Namespace(x=x, edge_index=ei, batch=None)
+
+            class _Wrap(torch.nn.Module):
+                def __init__(self, inner):
+                    super().__init__()
+                    self.inner = inner
+
+                def forward(self, x, edge_index):
+                    return self.inner(argparse.Namespace(x=x, edge_index=edge_index, batch=None))
+
+                def state_dict(self, *a, **k):
+                    return self.inner.state_dict(*a, **k)
+            record(f"ppi_deepgcn_{conv}", _Wrap(m), [x, ei], dict(conv=conv))
+    return cases
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     dense, sparse = refshim.import_reference()
     torch.save(model_key_tables(), os.path.join(GOLD, "model_keys.pt"))
+    torch.save(full_model_cases(), os.path.join(GOLD, "models.pt"))
     torch.set_num_threads(8)
     agg = sparse_aggregate_cases(sparse)
     torch.save(agg, os.path.join(GOLD, "sparse_aggregate.pt"))
