@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--t", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="profiling aid: skip the backward")
+    ap.add_argument("--force-partitioned", action="store_true",
+                    help="run the RCCL destination-partitioned path even with one rank (sanity check)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,10 +108,12 @@ def main():
     _lib.load()
 
     dist = None
-    if world > 1:
+    partitioned = world > 1 or args.force_partitioned
+    if partitioned:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     s = synth.SHAPES[args.shape]
     C = args.channels or s["channels"]
@@ -122,7 +126,7 @@ def main():
     x_full = torch.randn(n, C, device=dev, generator=gx)
     g_full = torch.randn(n, C, device=dev, generator=gx)
 
-    if world == 1:
+    if not partitioned:
         graph = Graph.from_edge_index(ei, n)
         del ei
         x = x_full.requires_grad_(True)
@@ -187,15 +191,14 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        E_local = E if world == 1 else None
-        if world == 1:
+        if not partitioned:
             algo = fwd_bytes(E, n, C)
         else:
             algo = fwd_bytes(part.n_local_edges, part.hi - part.lo, C)
         achieved = algo / (fwd_ms_avg * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile) and world == 1:
+        if os.path.exists(tfile) and not partitioned:
             try:
                 tj = json.load(open(tfile))
                 if tj.get("shape") == args.shape and tj.get("graph") == args.graph and tj.get("channels") == C:
@@ -219,7 +222,7 @@ def main():
                 "workload": f"GENConv {args.aggr} aggregation (t={args.t}) fwd+bwd, ogbn-{args.shape}-shaped "
                             f"{args.graph} random graph N={n} E={E} C={C}"
                             + (" [fwd only]" if args.fwd_only else ""),
-                "parallelism": "single GPU" if world == 1 else f"destination-partitioned x{world}, RCCL all-gather of features",
+                "parallelism": "single GPU" if not partitioned else f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd",
             },
             "roofline": {
                 "kernel": "gen_aggr_fwd_kernel<SOFTMAX> (dgcn_gen_aggr_fwd_f32)",
@@ -234,9 +237,9 @@ def main():
                 "launch_ms_min": fwd_ms[0],
                 "frac_of_measured_copy_6290GBs": achieved / 6290.0,
             },
-            "fwd_edges_per_s": (E if world == 1 else part.n_local_edges) / (fwd_ms_avg * 1e-3),
+            "fwd_edges_per_s": (E if not partitioned else part.n_local_edges) / (fwd_ms_avg * 1e-3),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not partitioned and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t)
         print(json.dumps(res), flush=True)
 

@@ -66,7 +66,8 @@ _SIGNATURES = {
     "dgcn_dense_edge_reduce_bwd_f32": (C.c_int, [
         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "dgcn_dense_edge_reduce_bwd_nsplit": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
 }
 
 _lib = None

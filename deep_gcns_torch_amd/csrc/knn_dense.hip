@@ -135,21 +135,21 @@ __device__ __noinline__ void select_row(const KnnParams& P, float* drow, uint32_
     key[s] = (s < slots && j < N) ? key_of(drow[j]) : 0xFFFFFFFFu;
   }
 
-  // phase 2: largest tau with count(key < tau) < K  ==> tau is the K-th smallest key
+  // phase 2: largest tau with count(key < tau) < K  ==> tau is the K-th smallest key.
+  // The wave-wide count is a sum of scalar popcounts of compare masks (v_cmp -> s_bcnt1): no
+  // cross-lane reduction on the 32-step dependent chain.
   uint32_t tau = 0;
 #pragma unroll 1
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t cand = tau | (1u << bit);
     int cnt = 0;
 #pragma unroll
-    for (int s = 0; s < kMaxPerLane; ++s) cnt += (key[s] < cand) ? 1 : 0;
-    cnt = wave_sum(cnt);
+    for (int s = 0; s < kMaxPerLane; ++s) cnt += __popcll(__ballot(key[s] < cand));
     if (cnt < K) tau = cand;
   }
   int cnt_lt = 0;
 #pragma unroll
-  for (int s = 0; s < kMaxPerLane; ++s) cnt_lt += (key[s] < tau) ? 1 : 0;
-  cnt_lt = wave_sum(cnt_lt);
+  for (int s = 0; s < kMaxPerLane; ++s) cnt_lt += __popcll(__ballot(key[s] < tau));
   const int need_eq = K - cnt_lt;  // >= 1 ties to take at the threshold, lowest index first
 
   // phase 3: ordered compaction
@@ -186,7 +186,7 @@ __device__ __noinline__ void select_row(const KnnParams& P, float* drow, uint32_
 
 // LDS layout (dynamic): q[C][TM] | sq[TM] | dist[TM][Npad] | selkey[TM][Kpad]
 // (the winners' indices are compacted IN PLACE at the front of each dist row: position <= index)
-template <int TM>
+template <int TM, bool VEC4>
 __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams P, int Npad, int Kpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int C = P.C, N = P.N, K = P.K;
@@ -219,41 +219,108 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 
   // ---- phase 1: distance strip ----
   constexpr int JJ = 4;
-  for (int j0 = 0; j0 < N; j0 += kKnnThreads * JJ) {
-    float acc[JJ][TM], sj[JJ];
-    int col[JJ];
-#pragma unroll
-    for (int jj = 0; jj < JJ; ++jj) {
-      col[jj] = j0 + jj * kKnnThreads + tid;
-      sj[jj] = 0.f;
-#pragma unroll
-      for (int r = 0; r < TM; ++r) acc[jj][r] = 0.f;
-    }
-#pragma unroll 2
-    for (int c = 0; c < C; ++c) {
-      float xv[JJ];
-#pragma unroll
-      for (int jj = 0; jj < JJ; ++jj) {
-        const int j = min(col[jj], N - 1);
-        xv[jj] = xb[c * P.sc + j * P.sn];
-      }
-      float qv[TM];
-#pragma unroll
-      for (int r = 0; r < TM; ++r) qv[r] = q[c * TM + r];
+#ifdef KNN_SKIP_DIST
+  const int n_phase1 = KNN_SKIP_DIST ? 0 : N;
+#else
+  const int n_phase1 = N;
+#endif
+  if (VEC4) {
+    // contiguous, 16B-aligned points: each thread owns 4 CONSECUTIVE columns -> one dwordx4 load per
+    // channel (1 KiB per wave instruction) and one ds_write_b128 per row.
+    for (int j0 = 0; j0 < n_phase1; j0 += kKnnThreads * JJ) {
+      const int cbase = j0 + tid * JJ;          // N % 4 == 0 in this mode: a block is all-in or all-out
+      const bool in = cbase < N;
+      const float* xc = xb + (in ? cbase : 0);
+      float acc[JJ][TM], sj[JJ];
 #pragma unroll
       for (int jj = 0; jj < JJ; ++jj) {
-        sj[jj] = fmaf(xv[jj], xv[jj], sj[jj]);
+        sj[jj] = 0.f;
 #pragma unroll
-        for (int r = 0; r < TM; ++r) acc[jj][r] = fmaf(qv[r], xv[jj], acc[jj][r]);
+        for (int r = 0; r < TM; ++r) acc[jj][r] = 0.f;
       }
-    }
+      // software pipeline: the next CH channels are in flight while the current CH are consumed
+      // (only 2 waves per SIMD are resident, so latency must be hidden by ILP, not by occupancy)
+      constexpr int CH = 8;
+      float4 nxt[CH];
 #pragma unroll
-    for (int jj = 0; jj < JJ; ++jj) {
-      if (col[jj] < N) {
+      for (int u = 0; u < CH; ++u) {
+        nxt[u] = (u < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(u) * P.sc)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int c0 = 0; c0 < C; c0 += CH) {
+        float4 cur[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int c = c0 + CH + u;
+          nxt[u] = (c < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(c) * P.sc)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int c = min(c0 + u, C - 1);      // channels past C carry zeros: no contribution
+          const float xv[JJ] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+          float qv[TM];
+#pragma unroll
+          for (int r = 0; r < TM; ++r) qv[r] = q[c * TM + r];
+#pragma unroll
+          for (int jj = 0; jj < JJ; ++jj) {
+            sj[jj] = fmaf(xv[jj], xv[jj], sj[jj]);
+#pragma unroll
+            for (int r = 0; r < TM; ++r) acc[jj][r] = fmaf(qv[r], xv[jj], acc[jj][r]);
+          }
+        }
+      }
+      if (in) {
 #pragma unroll
         for (int r = 0; r < TM; ++r) {
-          // reference association: (x_square + x_inner) + x_square^T, x_inner = -2 * <x_i, x_j>
-          dist[r * Npad + col[jj]] = (sq[r] + (-2.f * acc[jj][r])) + sj[jj];
+          float4 o;
+          o.x = (sq[r] + (-2.f * acc[0][r])) + sj[0];
+          o.y = (sq[r] + (-2.f * acc[1][r])) + sj[1];
+          o.z = (sq[r] + (-2.f * acc[2][r])) + sj[2];
+          o.w = (sq[r] + (-2.f * acc[3][r])) + sj[3];
+          *reinterpret_cast<float4*>(dist + r * Npad + cbase) = o;
+        }
+      }
+    }
+  } else {
+    for (int j0 = 0; j0 < n_phase1; j0 += kKnnThreads * JJ) {
+      float acc[JJ][TM], sj[JJ];
+      int col[JJ];
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) {
+        col[jj] = j0 + jj * kKnnThreads + tid;
+        sj[jj] = 0.f;
+#pragma unroll
+        for (int r = 0; r < TM; ++r) acc[jj][r] = 0.f;
+      }
+#pragma unroll 2
+      for (int c = 0; c < C; ++c) {
+        float xv[JJ];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+          const int j = min(col[jj], N - 1);
+          xv[jj] = xb[c * P.sc + j * P.sn];
+        }
+        float qv[TM];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) qv[r] = q[c * TM + r];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+          sj[jj] = fmaf(xv[jj], xv[jj], sj[jj]);
+#pragma unroll
+          for (int r = 0; r < TM; ++r) acc[jj][r] = fmaf(qv[r], xv[jj], acc[jj][r]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) {
+        if (col[jj] < N) {
+#pragma unroll
+          for (int r = 0; r < TM; ++r) {
+            // reference association: (x_square + x_inner) + x_square^T, x_inner = -2 * <x_i, x_j>
+            dist[r * Npad + col[jj]] = (sq[r] + (-2.f * acc[jj][r])) + sj[jj];
+          }
         }
       }
     }
@@ -261,6 +328,9 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   __syncthreads();
 
   // ---- phases 2-5: one wave per query row ----
+#ifdef KNN_SKIP_SELECT
+  if (KNN_SKIP_SELECT) return;
+#endif
   for (int r = wave; r < TM; r += kKnnWaves) {
     const int i = i0 + r;
     if (i >= N) continue;  // wave-uniform
@@ -306,31 +376,21 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   const dim3 grid(static_cast<unsigned>(B) * tiles), block(kKnnThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipSuccess;
+  const bool vec4 = (sn == 1) && (N % 4 == 0) && (sc % 4 == 0) && (sb % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+#define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \
+  do {                                                                                                      \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<TMV, V4>),                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
+    if (e != hipSuccess) return static_cast<int>(e);                                                        \
+    hipLaunchKernelGGL((knn_dense_kernel<TMV, V4>), grid, block, lds, s, P, Npad, Kpad);                    \
+  } while (0)
   switch (TM) {
-    case 8:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(knn_dense_kernel<8>, grid, block, lds, s, P, Npad, Kpad);
-      break;
-    case 4:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(knn_dense_kernel<4>, grid, block, lds, s, P, Npad, Kpad);
-      break;
-    case 2:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(knn_dense_kernel<2>, grid, block, lds, s, P, Npad, Kpad);
-      break;
-    default:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(knn_dense_kernel<1>, grid, block, lds, s, P, Npad, Kpad);
-      break;
+    case 8: if (vec4) DGCN_KNN_LAUNCH(8, true); else DGCN_KNN_LAUNCH(8, false); break;
+    case 4: if (vec4) DGCN_KNN_LAUNCH(4, true); else DGCN_KNN_LAUNCH(4, false); break;
+    case 2: if (vec4) DGCN_KNN_LAUNCH(2, true); else DGCN_KNN_LAUNCH(2, false); break;
+    default: if (vec4) DGCN_KNN_LAUNCH(1, true); else DGCN_KNN_LAUNCH(1, false); break;
   }
+#undef DGCN_KNN_LAUNCH
   return launch_status();
 }

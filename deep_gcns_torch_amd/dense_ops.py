@@ -163,7 +163,13 @@ class _EdgeReduce(torch.autograd.Function):
         gmin_c = gmin.float().contiguous() if (need_min and gmin is not None) else None
         gs = gs1.float().contiguous() if (need_stats and gs1 is not None) else None
         gq = gs2.float().contiguous() if (need_stats and gs2 is not None) else None
-        dPQ = torch.zeros_like(PQ)                      # dQ half is accumulated with atomics
+        nsplit = lib.dgcn_dense_edge_reduce_bwd_nsplit(B, N, C)
+        parts = None
+        if nsplit > 0:                                  # LDS-accumulated dQ partials, no global atomics
+            parts = torch.empty(nsplit, B, N, C, device=dev, dtype=torch.float32)
+            dPQ = torch.empty_like(PQ)
+        else:
+            dPQ = torch.zeros_like(PQ)                  # dQ half is accumulated with global atomics
         p_ptr = PQ.data_ptr() if has_p else None
         q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
         dp_ptr = dPQ.data_ptr() if has_p else None
@@ -173,8 +179,14 @@ class _EdgeReduce(torch.autograd.Function):
                 p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
                 B, N, C, k, act, slope, amax.data_ptr(), _lib.ptr(amin if gmin_c is not None else None),
                 gmax.data_ptr(), _lib.ptr(gmin_c), _lib.ptr(gs), _lib.ptr(gq), dp_ptr, dq_ptr,
-                _lib.current_stream_handle(dev))
+                _lib.ptr(parts), nsplit, _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_dense_edge_reduce_bwd_f32")
+        if parts is not None:
+            dq = parts[0] if nsplit == 1 else parts.sum(0)
+            if has_p:
+                dPQ[..., C:] = dq
+            else:
+                dPQ = dq
         return dPQ, None, None, None, None, None, None, None
 
 

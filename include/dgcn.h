@@ -198,14 +198,21 @@ int dgcn_dense_edge_reduce_fwd_f32(const float* P, int64_t ldp, const float* Q, 
 
 /* Backward of the above for L(vmax, vmin, sum a, sum a^2):
  *   dL/da_e = gmax*[l==amax] + gmin*[l==amin] + gsum[c] + 2 a_e gsq[c];  dz = dL/da * act'(z)
- *   dP[b,n,:] = sum_l dz (overwritten, optional);  dQ[b,j,:] += dz with hardware fp32 atomics
- *   (dQ must be zero-filled by the caller; summation order, hence the last bits, may vary run to run). */
+ *   dP[b,n,:] = sum_l dz (overwritten, optional).  dQ, two forms:
+ *   (a) dq_parts != NULL, nsplit = dgcn_dense_edge_reduce_bwd_nsplit(B,N,C) > 0: each workgroup accumulates an
+ *       8-channel slice of dQ[b] in LDS (ds_add_f32) and writes dq_parts[s][b][j][c] (dense, fully overwritten);
+ *       the caller sums over s in a fixed order -> deterministic, no global atomics;  dQ is ignored;
+ *   (b) dq_parts == NULL: dQ[b,j,:] += dz with hardware fp32 global atomics (dQ zero-filled by the caller;
+ *       the last bits may vary run to run). */
 int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
                                    const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk, int32_t B, int32_t N, int32_t C,
                                    int32_t k, int32_t act, float slope, const uint8_t* amax,
                                    const uint8_t* amin, const float* gmax, const float* gmin,
                                    const float* gsum, const float* gsq, float* dP, float* dQ,
-                                   void* stream);
+                                   float* dq_parts, int32_t nsplit, void* stream);
+
+/* Leading dimension of `dq_parts` for the atomic-free backward, or 0 when N*32 bytes exceed the LDS. */
+int32_t dgcn_dense_edge_reduce_bwd_nsplit(int32_t B, int32_t N, int32_t C);
 
 #ifdef __cplusplus
 }
