@@ -376,8 +376,9 @@ __global__ __launch_bounds__(kBwdLdsThreads) void dense_edge_bwd_lds_kernel(cons
 
 int bwd_nsplit(int B, int N, int C) {
   if (static_cast<size_t>(N) * kBwdSlice * 4 > 158u * 1024u) return 0;  // slice does not fit LDS: atomic path
+  // one 128 KB workgroup per CU: aim for exactly one round of <= 256 workgroups
   const int base = B * ((C + kBwdSlice - 1) / kBwdSlice);
-  int ns = (320 + base - 1) / base;
+  int ns = kNumCU / base;
   if (ns < 1) ns = 1;
   if (ns > 16) ns = 16;
   while (ns > 1 && (N + ns - 1) / ns < 64) --ns;

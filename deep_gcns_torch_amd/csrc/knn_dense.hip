@@ -41,11 +41,17 @@ __device__ __forceinline__ uint32_t key_of(float d) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // monotone: float order == unsigned order
 }
 
-// wave-wide sum of a per-lane int (all lanes get the result)
+// wave-wide sum of a per-lane int, returned wave-uniform.  DPP row shifts + row broadcasts (VALU data
+// path, ~8 cycles per step) instead of ds_bpermute shuffles (~100+ cycles each on a dependent chain):
+// the 32-step bisection below calls this once per step.
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8  -> inclusive scan per 16-lane row
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
@@ -120,8 +126,8 @@ __device__ __forceinline__ void sort_and_emit(const KnnParams& P, const uint32_t
   }
 }
 
-// Phases 2-5 for one query row, executed by one wave.  Not inlined: shared by every TM variant.
-__device__ __noinline__ void select_row(const KnnParams& P, float* drow, uint32_t* skey, int b, int i) {
+// Phases 2-5 for one query row, executed by one wave (inlined: a call would spill the 64 live keys).
+__device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint32_t* skey, int b, int i) {
   const int lane = lane_id();
   const int N = P.N, K = P.K;
   uint32_t* sidx = reinterpret_cast<uint32_t*>(drow);  // in-place compaction target (position <= index)
@@ -136,20 +142,20 @@ __device__ __noinline__ void select_row(const KnnParams& P, float* drow, uint32_
   }
 
   // phase 2: largest tau with count(key < tau) < K  ==> tau is the K-th smallest key.
-  // The wave-wide count is a sum of scalar popcounts of compare masks (v_cmp -> s_bcnt1): no
-  // cross-lane reduction on the 32-step dependent chain.
+  // Per step: 64 compare+add-carry on registers, then ONE DPP wave reduction.
   uint32_t tau = 0;
 #pragma unroll 1
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t cand = tau | (1u << bit);
-    int cnt = 0;
+    int c4[4] = {0, 0, 0, 0};   // independent chains: a single add-carry chain serialises on its own latency
 #pragma unroll
-    for (int s = 0; s < kMaxPerLane; ++s) cnt += __popcll(__ballot(key[s] < cand));
-    if (cnt < K) tau = cand;
+    for (int s = 0; s < kMaxPerLane; ++s) c4[s & 3] += (key[s] < cand) ? 1 : 0;
+    if (wave_sum((c4[0] + c4[1]) + (c4[2] + c4[3])) < K) tau = cand;
   }
   int cnt_lt = 0;
 #pragma unroll
-  for (int s = 0; s < kMaxPerLane; ++s) cnt_lt += __popcll(__ballot(key[s] < tau));
+  for (int s = 0; s < kMaxPerLane; ++s) cnt_lt += (key[s] < tau) ? 1 : 0;
+  cnt_lt = wave_sum(cnt_lt);
   const int need_eq = K - cnt_lt;  // >= 1 ties to take at the threshold, lowest index first
 
   // phase 3: ordered compaction
