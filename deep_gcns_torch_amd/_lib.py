@@ -66,8 +66,23 @@ _SIGNATURES = {
     "dgcn_dense_edge_reduce_bwd_f32": (C.c_int, [
         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dgcn_dense_edge_reduce_bwd_nsplit": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "dgcn_edgeconv_pq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dgcn_bn_finalize_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                       C.c_void_p, C.c_void_p]),
+    "dgcn_bn_apply_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
+    "dgcn_bn_bwd_num_partials": (C.c_int32, [C.c_int32, C.c_int32]),
+    "dgcn_bn_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p]),
+    "dgcn_bn_bwd_finalize_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                        C.c_void_p]),
 }
 
 _lib = None

@@ -35,6 +35,8 @@ struct GemmParams {
   const float* W;
   const float* bias;
   float* out;
+  int conv_split;  // 0: W is [C][M].  1: W is the Conv2d weight [M/2][2C] of EdgeConv2d and the kernel forms
+                   //    [(W1-W2)^T | W2^T] on the fly; bias [M/2] applies to the first half only
 };
 
 constexpr int kTJ = 4;
@@ -64,7 +66,16 @@ __global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParam
 #pragma unroll
       for (int t = 0; t < kTJ; ++t) {
         const int j = (ct0 + t) * 16 + li;
-        const float bv = (k_ok && j < P.M) ? P.W[static_cast<int64_t>(k) * P.M + j] : 0.f;
+        float bv = 0.f;
+        if (k_ok && j < P.M) {
+          if (P.conv_split) {
+            const int half = P.M / 2;
+            const float* wr = P.W + static_cast<int64_t>(j < half ? j : j - half) * (2 * P.C);
+            bv = (j < half) ? wr[k] - wr[P.C + k] : wr[P.C + k];
+          } else {
+            bv = P.W[static_cast<int64_t>(k) * P.M + j];
+          }
+        }
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
       }
     }
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParam
     for (int t = 0; t < kTJ; ++t) {
       const int j = (ct0 + t) * 16 + li;
       if (j < P.M) {
-        const float bj = P.bias ? P.bias[j] : 0.f;
+        const float bj = (P.bias && (!P.conv_split || j < P.M / 2)) ? P.bias[j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = n0 + lk * 4 + r;
@@ -108,6 +119,8 @@ struct EdgeParams {
   const float* gmin;  // [B,N,C] or null
   const float* gsum;  // [C] or null
   const float* gsq;   // [C] or null
+  const float* selscale;  // [C] or null: BatchNorm scale; gmax is routed to the arg-max slot where scale >= 0
+                          // and to the arg-min slot where scale < 0 (gmin is then ignored)
   float* dP;          // [B,N,C] or null
   float* dQ;          // [B,N,C], pre-zeroed, accumulated with hardware fp32 atomics
 };
@@ -180,6 +193,16 @@ __global__ __launch_bounds__(kWgThreads) void dense_edge_kernel(const EdgeParams
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) amn[j] = -1;
+          }
+          if (E.selscale) {
+            float sc[4];
+            load_vec<4>(sc, E.selscale + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (sc[j] < 0.f) amx[j] = amn[j];
+              amn[j] = -1;
+              gmn[j] = 0.f;
+            }
           }
         }
       }
@@ -330,6 +353,19 @@ __global__ __launch_bounds__(kBwdLdsThreads) void dense_edge_bwd_lds_kernel(cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) amn[j] = (pk >> (8 * j)) & 0xFF;
       }
+      if (E.selscale) {
+        float sc[4];
+        load_vec<4>(sc, E.selscale + c0);
+        if (E.amin) {
+          pk = *reinterpret_cast<const uint32_t*>(E.amin + row);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (sc[j] < 0.f) amx[j] = (pk >> (8 * j)) & 0xFF;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { amn[j] = -1; gmn[j] = 0.f; }
+      }
       const int64_t* irow = E.idx + b * E.ib + n * E.in_;
       for (int l0 = 0; l0 < k; l0 += U) {
         float q[U][4];
@@ -425,7 +461,22 @@ extern "C" int dgcn_vertex_gemm_f32(const float* x, int64_t sb, int64_t sc, int6
   if (!x || !W || !out) return DGCN_E_NULL;
   if (B < 0 || C <= 0 || N <= 0 || M <= 0) return DGCN_E_SHAPE;
   if (B == 0) return DGCN_OK;
-  GemmParams P{x, sb, sc, sn, B, C, N, M, W, bias, out};
+  GemmParams P{x, sb, sc, sn, B, C, N, M, W, bias, out, 0};
+  const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
+  const int grid = static_cast<int>((tiles + kWavesPerWg - 1) / kWavesPerWg);
+  hipLaunchKernelGGL(vertex_gemm_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
+  return launch_status();
+}
+
+// P/Q producer of EdgeConv2d straight from the Conv2d parameters: conv_w [Cout][2C] (the (Cout,2C,1,1)
+// weight), bias [Cout] or NULL;  out [B,N,2*Cout] = [ (W1-W2) x + b | W2 x ].
+extern "C" int dgcn_edgeconv_pq_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
+                                    int32_t N, const float* conv_w, const float* bias, int32_t Cout,
+                                    float* out, void* stream) {
+  if (!x || !conv_w || !out) return DGCN_E_NULL;
+  if (B < 0 || C <= 0 || N <= 0 || Cout <= 0) return DGCN_E_SHAPE;
+  if (B == 0) return DGCN_OK;
+  GemmParams P{x, sb, sc, sn, B, C, N, 2 * Cout, conv_w, bias, out, 1};
   const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
   const int grid = static_cast<int>((tiles + kWavesPerWg - 1) / kWavesPerWg);
   hipLaunchKernelGGL(vertex_gemm_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
@@ -473,10 +524,11 @@ extern "C" int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const
                                               int32_t B, int32_t N, int32_t C, int32_t k, int32_t act,
                                               float slope, const uint8_t* amax, const uint8_t* amin,
                                               const float* gmax, const float* gmin, const float* gsum,
-                                              const float* gsq, float* dP, float* dQ, float* dq_parts,
-                                              int32_t nsplit, void* stream) {
+                                              const float* gsq, const float* sel_scale, float* dP, float* dQ,
+                                              float* dq_parts, int32_t nsplit, void* stream) {
   if (!Q || !idx || !amax || !gmax || (!dQ && !dq_parts)) return DGCN_E_NULL;
   if (gmin && !amin) return DGCN_E_NULL;
+  if (sel_scale && !al16(sel_scale)) return DGCN_E_ALIGN;
   if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 255) return DGCN_E_SHAPE;
   if (C % 4 != 0 || ldq < C || ldq % 4 != 0 || (P && (ldp < C || ldp % 4 != 0))) return DGCN_E_SHAPE;
   if (act < ACT_NONE || act > ACT_LEAKY) return DGCN_E_MODE;
@@ -488,7 +540,7 @@ extern "C" int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const
   E.P = P; E.Q = Q; E.ldp = ldp; E.ldq = ldq; E.idx = idx; E.ib = idx_sb; E.in_ = idx_sn; E.ik = idx_sk;
   E.B = B; E.N = N; E.C = C; E.k = k; E.act = act; E.slope = slope;
   E.amax = const_cast<uint8_t*>(amax); E.amin = const_cast<uint8_t*>(amin);
-  E.gmax = gmax; E.gmin = gmin; E.gsum = gsum; E.gsq = gsq; E.dP = dP; E.dQ = dQ;
+  E.gmax = gmax; E.gmin = gmin; E.gsum = gsum; E.gsq = gsq; E.selscale = sel_scale; E.dP = dP; E.dQ = dQ;
   if (dq_parts) {
     if (nsplit < 1 || nsplit != bwd_nsplit(B, N, C)) return DGCN_E_WORKSPACE;
     const size_t lds = static_cast<size_t>(N) * kBwdSlice * sizeof(float);

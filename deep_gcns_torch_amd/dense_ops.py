@@ -178,7 +178,7 @@ class _EdgeReduce(torch.autograd.Function):
             rc = lib.dgcn_dense_edge_reduce_bwd_f32(
                 p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
                 B, N, C, k, act, slope, amax.data_ptr(), _lib.ptr(amin if gmin_c is not None else None),
-                gmax.data_ptr(), _lib.ptr(gmin_c), _lib.ptr(gs), _lib.ptr(gq), dp_ptr, dq_ptr,
+                gmax.data_ptr(), _lib.ptr(gmin_c), _lib.ptr(gs), _lib.ptr(gq), None, dp_ptr, dq_ptr,
                 _lib.ptr(parts), nsplit, _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_dense_edge_reduce_bwd_f32")
         if parts is not None:
@@ -210,3 +210,160 @@ def edge_reduce(PQ: torch.Tensor, idx: torch.Tensor, has_p: bool, act: int = ACT
         vmin = vmin[..., :C] if need_min else vmin
         s1, s2 = s1[:C], s2[:C]
     return vmax, (vmin if need_min else None), s1, s2
+
+
+# ----------------------------------------------------------------------------------------
+# fused dense EdgeConv2d (conv -> act -> [BatchNorm2d] -> max over neighbours) in a handful of launches
+# ----------------------------------------------------------------------------------------
+BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
+
+
+def _splitk_xt_g(g2: torch.Tensor, xr: torch.Tensor) -> torch.Tensor:
+    """g2^T @ xr for tall-skinny operands ((R, M)^T (R, C), R = B*N >> M, C): batched split-K + fixed-order
+    sum instead of one GEMM with a 32768-long reduction (which the library runs on a handful of CUs)."""
+    R = g2.size(0)
+    S = 1
+    while S < 64 and R % (S * 2) == 0 and R // (S * 2) >= 256:
+        S *= 2
+    if S == 1:
+        return g2.t() @ xr
+    part = torch.bmm(g2.view(S, R // S, -1).transpose(1, 2), xr.view(S, R // S, -1))
+    return part.sum(0)
+
+
+class _EdgeConv2dFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, idx, act, slope, bn_mode, running_mean, running_var,
+                num_batches, momentum, eps, track):
+        lib = _lib.load()
+        dev = _lib.require_device(x, weight, idx)
+        stream = _lib.current_stream_handle(dev)
+        x3 = x.squeeze(-1) if x.dim() == 4 else x
+        if x3.dtype != torch.float32:
+            x3 = x3.float()
+        B, C, N = x3.shape
+        Cout = weight.size(0)
+        W2 = weight.reshape(Cout, 2 * C).float().contiguous()
+        bc = None if bias is None else bias.float().contiguous()
+        if idx.dtype != torch.int64:
+            idx = idx.long()
+        k = idx.size(-1)
+        need_bwd = track and any(ctx.needs_input_grad[:5])
+        has_bn = bn_mode != BN_NONE
+        pq = torch.empty(B, N, 2 * Cout, device=dev, dtype=torch.float32)
+        vmax = torch.empty(B, N, Cout, device=dev, dtype=torch.float32)
+        vmin = torch.empty_like(vmax) if has_bn else None
+        amax = torch.empty(B, N, Cout, device=dev, dtype=torch.uint8) if need_bwd else None
+        amin = torch.empty(B, N, Cout, device=dev, dtype=torch.uint8) if (need_bwd and has_bn) else None
+        stats = None
+        nparts = 0
+        if bn_mode == BN_TRAIN:
+            nparts = lib.dgcn_dense_edge_reduce_num_partials(B, N, Cout)
+            stats = torch.empty(nparts, 2, Cout, device=dev, dtype=torch.float32)
+        out = torch.empty(B, Cout, N, 1, device=dev, dtype=torch.float32)
+        bnbuf = torch.empty(4, Cout, device=dev, dtype=torch.float32) if has_bn else None
+        count = float(B) * N * k
+        with torch.cuda.device(dev):
+            _lib.check(lib.dgcn_edgeconv_pq_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N,
+                                                W2.data_ptr(), _lib.ptr(bc), Cout, pq.data_ptr(), stream),
+                       "dgcn_edgeconv_pq_f32")
+            _lib.check(lib.dgcn_dense_edge_reduce_fwd_f32(
+                pq.data_ptr(), 2 * Cout, pq.data_ptr() + 4 * Cout, 2 * Cout, idx.data_ptr(), idx.stride(0),
+                idx.stride(1), idx.stride(2), B, N, Cout, k, act, slope, vmax.data_ptr(), _lib.ptr(vmin),
+                _lib.ptr(amax), _lib.ptr(amin), _lib.ptr(stats), stream), "dgcn_dense_edge_reduce_fwd_f32")
+            if has_bn:
+                _lib.check(lib.dgcn_bn_finalize_f32(
+                    _lib.ptr(stats), nparts, Cout, count, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                    _lib.ptr(running_var), _lib.ptr(num_batches), 1 if bn_mode == BN_TRAIN else 0,
+                    float(momentum), float(eps), bnbuf.data_ptr(), stream), "dgcn_bn_finalize_f32")
+            _lib.check(lib.dgcn_bn_apply_f32(vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(bnbuf), out.data_ptr(),
+                                             B, N, Cout, stream), "dgcn_bn_apply_f32")
+        if need_bwd:
+            ctx.save_for_backward(x3, W2, pq, idx, amax, amin, vmax, vmin, bnbuf, gamma)
+            ctx.cfg = (act, slope, bn_mode, count, tuple(x.shape), tuple(weight.shape), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x3, W2, pq, idx, amax, amin, vmax, vmin, bnbuf, gamma = ctx.saved_tensors
+        act, slope, bn_mode, count, x_shape, w_shape, has_bias = ctx.cfg
+        dev = x3.device
+        stream = _lib.current_stream_handle(dev)
+        B, C, N = x3.shape
+        Cout = W2.size(0)
+        k = idx.size(-1)
+        has_bn = bn_mode != BN_NONE
+        g3 = g.squeeze(-1) if g.dim() == 4 else g
+        if g3.dtype != torch.float32:
+            g3 = g3.float()
+        gsel = torch.empty(B, N, Cout, device=dev, dtype=torch.float32)
+        nparts = lib.dgcn_bn_bwd_num_partials(B, N)
+        partial = torch.empty(nparts, 2, Cout, device=dev, dtype=torch.float32) if has_bn else None
+        coef = torch.empty(4, Cout, device=dev, dtype=torch.float32) if has_bn else None
+        dPQ = torch.empty(B, N, 2 * Cout, device=dev, dtype=torch.float32)
+        nsplit = lib.dgcn_dense_edge_reduce_bwd_nsplit(B, N, Cout)
+        parts = torch.empty(nsplit, B, N, Cout, device=dev, dtype=torch.float32) if nsplit > 0 else None
+        if parts is None:
+            dPQ[..., Cout:].zero_()
+        train_stats = bn_mode == BN_TRAIN
+        with torch.cuda.device(dev):
+            _lib.check(lib.dgcn_bn_bwd_prep_f32(g3.data_ptr(), g3.stride(0), g3.stride(1), g3.stride(2), vmax.data_ptr(),
+                                                _lib.ptr(vmin), _lib.ptr(bnbuf), gsel.data_ptr(), _lib.ptr(partial),
+                                                B, N, Cout, stream), "dgcn_bn_bwd_prep_f32")
+            if has_bn:
+                _lib.check(lib.dgcn_bn_bwd_finalize_f32(partial.data_ptr(), nparts, Cout, count, _lib.ptr(gamma),
+                                                        bnbuf.data_ptr(), 1 if train_stats else 0, coef.data_ptr(),
+                                                        stream), "dgcn_bn_bwd_finalize_f32")
+            gs_ptr = coef[2].data_ptr() if train_stats else None
+            gq_ptr = coef[3].data_ptr() if train_stats else None
+            _lib.check(lib.dgcn_dense_edge_reduce_bwd_f32(
+                pq.data_ptr(), 2 * Cout, pq.data_ptr() + 4 * Cout, 2 * Cout, idx.data_ptr(), idx.stride(0),
+                idx.stride(1), idx.stride(2), B, N, Cout, k, act, slope, amax.data_ptr(), _lib.ptr(amin),
+                gsel.data_ptr(), None, gs_ptr, gq_ptr, bnbuf.data_ptr() if has_bn else None,
+                dPQ.data_ptr(), dPQ.data_ptr() + 4 * Cout, _lib.ptr(parts), nsplit, stream),
+                "dgcn_dense_edge_reduce_bwd_f32")
+            if parts is not None:
+                _lib.check(lib.dgcn_reduce_parts_f32(parts.data_ptr(), nsplit, B * N, Cout,
+                                                     dPQ.data_ptr() + 4 * Cout, 2 * Cout, stream),
+                           "dgcn_reduce_parts_f32")
+        gx = gW = gb = ggamma = gbeta = None
+        w1, w2h = W2[:, :C], W2[:, C:]
+        if ctx.needs_input_grad[0]:
+            wc = torch.cat([w1 - w2h, w2h], dim=0)                          # (2Cout, C)
+            gx = torch.matmul(dPQ, wc).permute(0, 2, 1).reshape(x_shape)    # (B,C,N[,1])
+        if ctx.needs_input_grad[1]:
+            xr = x3.permute(0, 2, 1).reshape(B * N, C)
+            dwc = _splitk_xt_g(dPQ.view(B * N, 2 * Cout), xr)               # (2Cout, C)
+            gW = torch.cat([dwc[:Cout], dwc[Cout:] - dwc[:Cout]], dim=1).reshape(w_shape)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = dPQ[..., :Cout].sum((0, 1))
+        if has_bn and gamma is not None:
+            if ctx.needs_input_grad[3]:
+                ggamma = coef[0]
+            if ctx.needs_input_grad[4]:
+                gbeta = coef[1]
+        return (gx, gW, gb, ggamma, gbeta) + (None,) * 10
+
+
+def edgeconv2d_fused(x, weight, bias, idx, act, slope, bn=None):
+    """max_l BN(act(W [x_i ; x_j - x_i] + b)) for x (B,C,N,1), idx (B,N,k) -> (B,Cout,N,1).
+    ``bn``: a BatchNorm2d module (training or eval semantics, running statistics updated in place) or None."""
+    if bn is None:
+        return _EdgeConv2dFused.apply(x, weight, bias, None, None, idx, act, float(slope), BN_NONE, None, None,
+                                      None, 0.0, 0.0, torch.is_grad_enabled())
+    use_batch = bn.training or not bn.track_running_stats
+    momentum = bn.momentum
+    nbt = bn.num_batches_tracked if (use_batch and bn.track_running_stats and bn.training) else None
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if use_batch and not bn.training:
+        rm = rv = None                                   # batch statistics without touching the buffers
+    if nbt is not None and momentum is None:             # cumulative moving average: needs the count (host sync,
+        bn.num_batches_tracked += 1                      # exactly like torch.nn.BatchNorm2d itself)
+        momentum = 1.0 / float(bn.num_batches_tracked)
+        nbt = None
+    return _EdgeConv2dFused.apply(x, weight, bias, bn.weight, bn.bias, idx, act, float(slope),
+                                  BN_TRAIN if use_batch else BN_EVAL, rm, rv, nbt,
+                                  0.0 if momentum is None else float(momentum), float(bn.eps),
+                                  torch.is_grad_enabled())

@@ -62,6 +62,15 @@ class EdgeConv2d(nn.Module):
 
     def forward(self, x, edge_index):
         conv = self.nn[0]
+        act, slope = _act_code(self.nn)
+        bn = next((m for m in self.nn if isinstance(m, nn.BatchNorm2d)), None)
+        if conv.out_channels % 4 == 0:
+            # fused path: P/Q GEMM straight from the conv weight, edge kernel, BN finalize, transposing apply
+            return dense_ops.edgeconv2d_fused(x, conv.weight, conv.bias, edge_index[0], act, slope, bn)
+        return self._forward_composed(x, edge_index, conv, act, slope, bn)
+
+    def _forward_composed(self, x, edge_index, conv, act, slope, bn):
+        """Same math from separately differentiable pieces (channel counts that are not a multiple of 4)."""
         cin = conv.in_channels // 2
         cout = conv.out_channels
         W = conv.weight.view(cout, 2 * cin)
@@ -71,8 +80,6 @@ class EdgeConv2d(nn.Module):
         if conv.bias is not None:
             bcat = torch.cat([conv.bias, torch.zeros_like(conv.bias)])
         pq = dense_ops.vertex_gemm(x, wcat, bcat)                               # (B,N,2C') = [P | Q]
-        act, slope = _act_code(self.nn)
-        bn = next((m for m in self.nn if isinstance(m, nn.BatchNorm2d)), None)
         if bn is None:
             vmax, _, _, _ = dense_ops.edge_reduce(pq, edge_index[0], True, act, slope)
             return _to_bcn1(vmax)

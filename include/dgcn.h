@@ -180,6 +180,12 @@ int dgcn_vertex_gemm_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int
                          int32_t N, const float* W, const float* bias, int32_t M, float* out,
                          void* stream);
 
+/* EdgeConv2d P/Q producer straight from the Conv2d parameters (no host-side weight re-packing):
+ * conv_w [Cout][2C] = the (Cout,2C,1,1) weight, bias [Cout] or NULL;
+ * out [B,N,2*Cout] = [ (W1-W2) x + b | W2 x ]  with W = [W1 | W2]. */
+int dgcn_edgeconv_pq_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C, int32_t N,
+                         const float* conv_w, const float* bias, int32_t Cout, float* out, void* stream);
+
 /* Neighbourhood reduction  a_{bnl} = act(P[b,n,:] + Q[b, idx[b,n,l], :]),  l < k:
  *   vmax/vmin [B,N,C]  max_l / min_l a   (vmin, amin optional)
  *   amax/amin [B,N,C]  uint8 slot l attaining it (first on ties), saved for the backward
@@ -198,6 +204,8 @@ int dgcn_dense_edge_reduce_fwd_f32(const float* P, int64_t ldp, const float* Q, 
 
 /* Backward of the above for L(vmax, vmin, sum a, sum a^2):
  *   dL/da_e = gmax*[l==amax] + gmin*[l==amin] + gsum[c] + 2 a_e gsq[c];  dz = dL/da * act'(z)
+ *   sel_scale [C] (optional): BatchNorm scale; gmax is then routed to the arg-max slot where scale >= 0 and to
+ *   the arg-min slot where scale < 0, and gmin is ignored (needs amin).
  *   dP[b,n,:] = sum_l dz (overwritten, optional).  dQ, two forms:
  *   (a) dq_parts != NULL, nsplit = dgcn_dense_edge_reduce_bwd_nsplit(B,N,C) > 0: each workgroup accumulates an
  *       8-channel slice of dQ[b] in LDS (ds_add_f32) and writes dq_parts[s][b][j][c] (dense, fully overwritten);
@@ -208,11 +216,49 @@ int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const float* Q, 
                                    const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk, int32_t B, int32_t N, int32_t C,
                                    int32_t k, int32_t act, float slope, const uint8_t* amax,
                                    const uint8_t* amin, const float* gmax, const float* gmin,
-                                   const float* gsum, const float* gsq, float* dP, float* dQ,
-                                   float* dq_parts, int32_t nsplit, void* stream);
+                                   const float* gsum, const float* gsq, const float* sel_scale, float* dP,
+                                   float* dQ, float* dq_parts, int32_t nsplit, void* stream);
 
 /* Leading dimension of `dq_parts` for the atomic-free backward, or 0 when N*32 bytes exceed the LDS. */
 int32_t dgcn_dense_edge_reduce_bwd_nsplit(int32_t B, int32_t N, int32_t C);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm2d around the neighbourhood max (EdgeConv2d with norm='batch',
+ * gcn_lib/dense/torch_nn.py:54-56 + gcn_lib/dense/torch_vertex.py:34).  BN is a per-channel affine map
+ * y = scale*a + shift, so max_l y = scale*(scale >= 0 ? max_l a : min_l a) + shift: node-sized work.
+ *   bnbuf [4][C] = scale, shift, mean, invstd (written by dgcn_bn_finalize_f32)
+ * ------------------------------------------------------------------------------------ */
+
+/* stats [nparts][2][C] (from dgcn_dense_edge_reduce_fwd_f32) -> bnbuf; training=1 uses the batch statistics
+ * over `count` = B*N*k activations (biased variance) and updates running_mean/var (momentum, unbiased
+ * variance) and *num_batches += 1 when given; training=0 uses the running statistics.  One workgroup, fixed
+ * summation order, fp64 accumulation.  gamma/beta NULL = 1/0. */
+int dgcn_bn_finalize_f32(const float* stats, int32_t nparts, int32_t C, double count, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                         int32_t training, float momentum, float eps, float* bnbuf, void* stream);
+
+/* out[b,c,n] = scale_c * (scale_c >= 0 ? vmax : vmin)[b,n,c] + shift_c : (B,N,C) point-major extremes ->
+ * (B,C,N,1) channel-major layer output (LDS tile transpose).  bnbuf NULL = identity (norm=None). */
+int dgcn_bn_apply_f32(const float* vmax, const float* vmin, const float* bnbuf, float* out, int32_t B,
+                      int32_t N, int32_t C, void* stream);
+
+/* Backward prologue: g (B,C,N) with element strides -> gsel[b,n,c] = g*scale (point-major) and per-workgroup
+ * partial sums of g and g*sel, partial [dgcn_bn_bwd_num_partials(B,N)][2][C] (NULL to skip). */
+int32_t dgcn_bn_bwd_num_partials(int32_t B, int32_t N);
+int dgcn_bn_bwd_prep_f32(const float* g, int64_t gb, int64_t gc, int64_t gn, const float* vmax,
+                         const float* vmin, const float* bnbuf, float* gsel, float* partial, int32_t B,
+                         int32_t N, int32_t C, void* stream);
+
+/* partial -> coef [4][C] = dgamma, dbeta, gsum, gsq where (gsum, gsq) are the per-channel coefficients that
+ * make dgcn_dense_edge_reduce_bwd_f32 reproduce the exact BatchNorm backward (0 when training=0). */
+int dgcn_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, double count,
+                             const float* gamma, const float* bnbuf, int32_t training, float* coef,
+                             void* stream);
+
+/* dst[row*ld + c] = sum_s parts[s][row][c]  (fixed order; C % 4 == 0): combines the dq_parts of the
+ * atomic-free edge backward into the Q half of the vertex-GEMM gradient. */
+int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int32_t C, float* dst, int64_t ld,
+                          void* stream);
 
 #ifdef __cplusplus
 }
