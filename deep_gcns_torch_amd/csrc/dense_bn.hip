@@ -21,6 +21,8 @@ namespace dgcn {
 namespace {
 
 constexpr int kTile = 64;
+constexpr int kFinThreads = 1024;            // finalize kernels: 16 row groups x 64 channels
+constexpr int kFinRows = kFinThreads / kTile;
 
 // ---- bn_finalize -----------------------------------------------------------------------
 // bnbuf layout: [0]=scale [1]=shift [2]=mean [3]=invstd, each [C]
@@ -40,15 +42,16 @@ struct BnFinalizeParams {
   float* bnbuf;        // [4][C]
 };
 
-__global__ __launch_bounds__(kWgThreads) void bn_finalize_kernel(const BnFinalizeParams P) {
-  __shared__ double red[4][2][kTile];
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const BnFinalizeParams P) {
+  __shared__ double red[kFinRows][2][kTile];
   const int cc = threadIdx.x % kTile;
-  const int r = threadIdx.x / kTile;  // 0..3: interleaved share of the partial rows
+  const int r = threadIdx.x / kTile;  // interleaved share of the partial rows
   for (int c0 = 0; c0 < P.C; c0 += kTile) {
     const int c = c0 + cc;
     double s1 = 0.0, s2 = 0.0;
     if (P.training && c < P.C) {
-      for (int p = r; p < P.nparts; p += 4) {
+#pragma unroll 4
+      for (int p = r; p < P.nparts; p += kFinRows) {
         s1 += static_cast<double>(P.stats[(static_cast<int64_t>(p) * 2) * P.C + c]);
         s2 += static_cast<double>(P.stats[(static_cast<int64_t>(p) * 2 + 1) * P.C + c]);
       }
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(kWgThreads) void bn_finalize_kernel(const BnFinaliz
     if (r == 0 && c < P.C) {
       double mean, var;
       if (P.training) {
-        const double t1 = ((red[0][0][cc] + red[1][0][cc]) + red[2][0][cc]) + red[3][0][cc];
-        const double t2 = ((red[0][1][cc] + red[1][1][cc]) + red[2][1][cc]) + red[3][1][cc];
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < kFinRows; ++q) { t1 += red[q][0][cc]; t2 += red[q][1][cc]; }   // fixed order
         mean = t1 / P.count;
         var = t2 / P.count - mean * mean;  // biased batch variance
         if (var < 0.0) var = 0.0;
@@ -207,15 +210,16 @@ struct BnBwdFinalizeParams {
   float* coef;
 };
 
-__global__ __launch_bounds__(kWgThreads) void bn_bwd_finalize_kernel(const BnBwdFinalizeParams P) {
-  __shared__ double red[4][2][kTile];
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const BnBwdFinalizeParams P) {
+  __shared__ double red[kFinRows][2][kTile];
   const int cc = threadIdx.x % kTile;
   const int r = threadIdx.x / kTile;
   for (int c0 = 0; c0 < P.C; c0 += kTile) {
     const int c = c0 + cc;
     double s1 = 0.0, s2 = 0.0;
     if (c < P.C) {
-      for (int p = r; p < P.nparts; p += 4) {
+#pragma unroll 4
+      for (int p = r; p < P.nparts; p += kFinRows) {
         s1 += static_cast<double>(P.partial[(static_cast<int64_t>(p) * 2) * P.C + c]);
         s2 += static_cast<double>(P.partial[(static_cast<int64_t>(p) * 2 + 1) * P.C + c]);
       }
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(kWgThreads) void bn_bwd_finalize_kernel(const BnBwd
     red[r][1][cc] = s2;
     __syncthreads();
     if (r == 0 && c < P.C) {
-      const double db = ((red[0][0][cc] + red[1][0][cc]) + red[2][0][cc]) + red[3][0][cc];
-      const double ds = ((red[0][1][cc] + red[1][1][cc]) + red[2][1][cc]) + red[3][1][cc];
+      double db = 0.0, ds = 0.0;
+      for (int q = 0; q < kFinRows; ++q) { db += red[q][0][cc]; ds += red[q][1][cc]; }   // fixed order
       const double gamma = P.gamma ? P.gamma[c] : 1.0;
       const double mean = P.bnbuf[2 * P.C + c];
       const double rstd = P.bnbuf[3 * P.C + c];
@@ -281,7 +285,7 @@ extern "C" int dgcn_bn_finalize_f32(const float* stats, int32_t nparts, int32_t 
   if (running_mean && !running_var) return DGCN_E_NULL;
   BnFinalizeParams P{stats, nparts, C, count, gamma, beta, running_mean, running_var, num_batches,
                      training, momentum, eps, bnbuf};
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream), P);
   return launch_status();
 }
 
@@ -320,7 +324,7 @@ extern "C" int dgcn_bn_bwd_finalize_f32(const float* partial, int32_t nparts, in
   if (!partial || !bnbuf || !coef) return DGCN_E_NULL;
   if (C <= 0 || nparts <= 0 || count <= 0.0) return DGCN_E_SHAPE;
   BnBwdFinalizeParams P{partial, nparts, C, count, gamma, bnbuf, training, coef};
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream), P);
   return launch_status();
 }
 

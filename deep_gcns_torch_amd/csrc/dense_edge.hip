@@ -39,14 +39,28 @@ struct GemmParams {
                    //    [(W1-W2)^T | W2^T] on the fly; bias [M/2] applies to the first half only
 };
 
-constexpr int kTJ = 4;
+constexpr int kTJ = 4;    // 16-column MFMA tiles per wave pass -> 64 output columns
+constexpr int kGemmKC = 64;  // channels staged in LDS per step
+
+// effective B operand: W[c][m] (plain) or the EdgeConv split [(W1-W2)^T | W2^T] formed on the fly
+__device__ __forceinline__ float gemm_b(const GemmParams& P, int k, int j) {
+  if (k >= P.C || j >= P.M) return 0.f;
+  if (P.conv_split) {
+    const int half = P.M / 2;
+    const float* wr = P.W + static_cast<int64_t>(j < half ? j : j - half) * (2 * P.C);
+    return (j < half) ? wr[k] - wr[P.C + k] : wr[P.C + k];
+  }
+  return P.W[static_cast<int64_t>(k) * P.M + j];
+}
 
 __global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParams P) {
+  __shared__ float wt[kGemmKC][kTJ * 16];  // 16 KB: the weight tile shared by the 4 waves (= 4 point tiles)
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int tiles_n = (P.N + 15) / 16;
-  const int tile = blockIdx.x * kWavesPerWg + wave;
-  if (tile >= P.B * tiles_n) return;  // wave-uniform
+  const int total_tiles = P.B * tiles_n;
+  const int tile = min(blockIdx.x * kWavesPerWg + wave, total_tiles - 1);  // clamp: all waves hit the barriers
+  const bool tile_ok = blockIdx.x * kWavesPerWg + wave < total_tiles;
   const int b = tile / tiles_n;
   const int n0 = (tile % tiles_n) * 16;
   const int li = lane & 15, lk = lane >> 4;
@@ -59,35 +73,35 @@ __global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParam
     f32x4 acc[kTJ];
 #pragma unroll
     for (int t = 0; t < kTJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < P.C; k0 += 4) {
-      const int k = k0 + lk;
-      const bool k_ok = k < P.C;
-      const float a = (k_ok && n_ok) ? xa[static_cast<int64_t>(k) * P.sc] : 0.f;
+    for (int kc = 0; kc < P.C; kc += kGemmKC) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < kGemmKC * kTJ * 16; e += kWgThreads) {
+        const int kk = e / (kTJ * 16), jj = e % (kTJ * 16);
+        wt[kk][jj] = gemm_b(P, kc + kk, ct0 * 16 + jj);
+      }
+      __syncthreads();
+      const int kend = min(kGemmKC, P.C - kc);
+      for (int k0 = 0; k0 < kend; k0 += 4) {
+        const int k = kc + k0 + lk;
+        const float a = (k < P.C && n_ok) ? xa[static_cast<int64_t>(k) * P.sc] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kTJ; ++t) {
+          const float bv = wt[k0 + lk][t * 16 + li];   // rows past C hold zeros
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (tile_ok) {
 #pragma unroll
       for (int t = 0; t < kTJ; ++t) {
         const int j = (ct0 + t) * 16 + li;
-        float bv = 0.f;
-        if (k_ok && j < P.M) {
-          if (P.conv_split) {
-            const int half = P.M / 2;
-            const float* wr = P.W + static_cast<int64_t>(j < half ? j : j - half) * (2 * P.C);
-            bv = (j < half) ? wr[k] - wr[P.C + k] : wr[P.C + k];
-          } else {
-            bv = P.W[static_cast<int64_t>(k) * P.M + j];
+        if (j < P.M) {
+          const float bj = (P.bias && (!P.conv_split || j < P.M / 2)) ? P.bias[j] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = n0 + lk * 4 + r;
+            if (row < P.N) P.out[(static_cast<int64_t>(b) * P.N + row) * P.M + j] = acc[t][r] + bj;
           }
-        }
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < kTJ; ++t) {
-      const int j = (ct0 + t) * 16 + li;
-      if (j < P.M) {
-        const float bj = (P.bias && (!P.conv_split || j < P.M / 2)) ? P.bias[j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = n0 + lk * 4 + r;
-          if (row < P.N) P.out[(static_cast<int64_t>(b) * P.N + row) * P.M + j] = acc[t][r] + bj;
         }
       }
     }
