@@ -32,6 +32,7 @@ struct KnnParams {
   const float* x;
   int64_t sb, sc, sn;  // strides in floats of (B, C, N)
   int B, C, N, K, dilation, Kout;
+  int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
   int64_t* ctr_out;    // [B, N, Kout] centre ids (may be null)
 };
@@ -126,6 +127,76 @@ __device__ __forceinline__ void sort_and_emit(const KnnParams& P, const uint32_t
   }
 }
 
+// Exact K-th smallest (0-based K-1) of the R*64 keys held as k[r] per lane: largest tau with
+// count(key < tau) < K.  32 steps of R compare+add and one DPP wave reduction.
+template <int R>
+__device__ __forceinline__ uint32_t kth_smallest(const uint32_t (&k)[R], int K) {
+  uint32_t tau = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = tau | (1u << bit);
+    int c4[4] = {0, 0, 0, 0};  // independent chains: a single add-carry chain serialises on its latency
+#pragma unroll
+    for (int s = 0; s < R; ++s) c4[s & 3] += (k[s] < cand) ? 1 : 0;
+    if (wave_sum((c4[0] + c4[1]) + (c4[2] + c4[3])) < K) tau = cand;
+  }
+  return tau;
+}
+
+template <int R>
+__device__ __forceinline__ int count_below(const uint32_t (&k)[R], uint32_t tau, bool inclusive) {
+  int c = 0;
+#pragma unroll
+  for (int s = 0; s < R; ++s) c += (inclusive ? (k[s] <= tau) : (k[s] < tau)) ? 1 : 0;
+  return wave_sum(c);
+}
+
+// Ordered compaction of the winners {key < tau} + the first need_eq of {key == tau} out of R*64 keys
+// (element e = r*64 + lane, increasing e = increasing point index) into skey/sidx.
+template <int R>
+__device__ __forceinline__ void compact_winners(const uint32_t (&k)[R], const uint32_t (&id)[R], int slots,
+                                                uint32_t tau, int need_eq, uint32_t* skey, uint32_t* sidx,
+                                                int lane) {
+  int n_sel = 0, n_eq = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int s = 0; s < R; ++s) {
+    if (s < slots) {  // uniform
+      const bool lt = k[s] < tau;
+      const bool eq = k[s] == tau;
+      const unsigned long long m_eq = __ballot(eq);
+      const int eq_rank = n_eq + __popcll(m_eq & below);
+      const bool take = lt || (eq && eq_rank < need_eq);
+      const unsigned long long m_take = __ballot(take);
+      if (take) {
+        const int pos = n_sel + __popcll(m_take & below);
+        skey[pos] = k[s];
+        sidx[pos] = id[s];
+      }
+      n_sel += __popcll(m_take);
+      n_eq += __popcll(m_eq);
+    }
+  }
+}
+
+// Candidate stage of the pre-filtered select: R candidates per lane from LDS -> exact threshold -> winners.
+template <int R>
+__device__ __forceinline__ void select_from_candidates(const uint32_t* ckey, const uint32_t* cidx, int cnt, int K,
+                                                       uint32_t* skey, uint32_t* sidx, int lane) {
+  uint32_t ck[R], ci[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * kWave + lane;
+    ck[r] = (e < cnt) ? ckey[e] : 0xFFFFFFFFu;
+    ci[r] = (e < cnt) ? cidx[e] : 0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();   // candidates are in registers before sidx (aliasing cidx) is rewritten
+  const uint32_t tau = kth_smallest<R>(ck, K);
+  const int need_eq = K - count_below<R>(ck, tau, false);
+  compact_winners<R>(ck, ci, (cnt + kWave - 1) / kWave, tau, need_eq, skey, sidx, lane);
+}
+
 // Phases 2-5 for one query row, executed by one wave (inlined: a call would spill the 64 live keys).
 __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint32_t* skey, int b, int i) {
   const int lane = lane_id();
@@ -141,43 +212,60 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
     key[s] = (s < slots && j < N) ? key_of(drow[j]) : 0xFFFFFFFFu;
   }
 
-  // phase 2: largest tau with count(key < tau) < K  ==> tau is the K-th smallest key.
-  // Per step: 64 compare+add-carry on registers, then ONE DPP wave reduction.
-  uint32_t tau = 0;
-#pragma unroll 1
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t cand = tau | (1u << bit);
-    int c4[4] = {0, 0, 0, 0};   // independent chains: a single add-carry chain serialises on its own latency
+  // phases 2-3.  Fast path: threshold a 256-key SAMPLE (4 keys per lane) at a rank chosen so that, with
+  // overwhelming probability, at least K and at most ~2K+100 of the row's keys lie below it; compact those
+  // candidates (index order) and run the exact 32-step bisection on <= 16 keys per lane instead of 64.
+  // Any miss (fewer than K candidates, or too many) falls through to the exact full-row path: the
+  // result never depends on the sample.
+  bool done = false;
+  if (P.sample_rank > 0 && slots >= 4) {
+    const int st = slots / 4;
+    uint32_t ks[4];
 #pragma unroll
-    for (int s = 0; s < kMaxPerLane; ++s) c4[s & 3] += (key[s] < cand) ? 1 : 0;
-    if (wave_sum((c4[0] + c4[1]) + (c4[2] + c4[3])) < K) tau = cand;
-  }
-  int cnt_lt = 0;
+    for (int i = 0; i < 4; ++i) {
+      uint32_t v = 0xFFFFFFFFu;
 #pragma unroll
-  for (int s = 0; s < kMaxPerLane; ++s) cnt_lt += (key[s] < tau) ? 1 : 0;
-  cnt_lt = wave_sum(cnt_lt);
-  const int need_eq = K - cnt_lt;  // >= 1 ties to take at the threshold, lowest index first
-
-  // phase 3: ordered compaction
-  int n_sel = 0, n_eq = 0;
-#pragma unroll
-  for (int s = 0; s < kMaxPerLane; ++s) {
-    if (s < slots) {  // uniform
-      const bool lt = key[s] < tau;
-      const bool eq = key[s] == tau;
-      const unsigned long long m_eq = __ballot(eq);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      const int eq_rank = n_eq + __popcll(m_eq & below);
-      const bool take = lt || (eq && eq_rank < need_eq);
-      const unsigned long long m_take = __ballot(take);
-      if (take) {
-        const int pos = n_sel + __popcll(m_take & below);
-        skey[pos] = key[s];
-        sidx[pos] = static_cast<uint32_t>(s * kWave + lane);
-      }
-      n_sel += __popcll(m_take);
-      n_eq += __popcll(m_eq);
+      for (int s = 0; s < kMaxPerLane; ++s) v = (s == i * st) ? key[s] : v;   // key[] stays in registers
+      ks[i] = v;
     }
+    const uint32_t ts = kth_smallest<4>(ks, P.sample_rank);
+    const int cnt = count_below<kMaxPerLane>(key, ts, true);
+    const int cap = min(16 * kWave, (N / 2) & ~3);
+    if (cnt >= K && cnt <= cap) {
+      uint32_t* cidx = reinterpret_cast<uint32_t*>(drow);          // the row is dead: its keys are in registers
+      uint32_t* ckey = cidx + cap;
+      int n_c = 0;
+      const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int s = 0; s < kMaxPerLane; ++s) {
+        if (s < slots) {
+          const bool in = key[s] <= ts;
+          const unsigned long long m = __ballot(in);
+          if (in) {
+            const int pos = n_c + __popcll(m & below);
+            ckey[pos] = key[s];
+            cidx[pos] = static_cast<uint32_t>(s * kWave + lane);
+          }
+          n_c += __popcll(m);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (cnt <= 2 * kWave) select_from_candidates<2>(ckey, cidx, cnt, K, skey, sidx, lane);
+      else if (cnt <= 4 * kWave) select_from_candidates<4>(ckey, cidx, cnt, K, skey, sidx, lane);
+      else if (cnt <= 8 * kWave) select_from_candidates<8>(ckey, cidx, cnt, K, skey, sidx, lane);
+      else select_from_candidates<16>(ckey, cidx, cnt, K, skey, sidx, lane);
+      done = true;
+    }
+  }
+  if (!done) {
+    // exact full-row path
+    const uint32_t tau = kth_smallest<kMaxPerLane>(key, K);
+    const int need_eq = K - count_below<kMaxPerLane>(key, tau, false);  // >= 1 ties at the threshold
+    uint32_t id[kMaxPerLane];
+#pragma unroll
+    for (int s = 0; s < kMaxPerLane; ++s) id[s] = static_cast<uint32_t>(s * kWave + lane);
+    compact_winners<kMaxPerLane>(key, id, slots, tau, need_eq, skey, sidx, lane);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -378,6 +466,12 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.B = B; P.C = C; P.N = N; P.K = K; P.dilation = dilation;
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
+  P.sample_rank = 0;
+  if (N >= 1024) {
+    const double ns = 4.0 * kWave, f = static_cast<double>(K) / N;
+    const int r = static_cast<int>(ceil(ns * f + 3.0 * sqrt(ns * f * (1.0 - f)) + 2.0));
+    if (r <= 160) P.sample_rank = r;   // beyond that the candidate set is no smaller than the row
+  }
   const int tiles = (N + TM - 1) / TM;
   const dim3 grid(static_cast<unsigned>(B) * tiles), block(kKnnThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -203,3 +203,39 @@ def test_vertex_gemm_is_an_exact_fma_chain():
     out = dense_ops.vertex_gemm(x.to(dev), W.to(dev)).cpu()
     ref = torch.einsum("bcn,cm->bnm", x.squeeze(-1).double(), W.double())
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,C,K,kind", [(4096, 3, 16, "lattice"), (4096, 64, 432, "lattice"), (2048, 16, 64, "sorted"),
+                                        (1024, 3, 100, "duplicates"), (4096, 8, 512, "lattice"), (1536, 5, 1, "lattice")])
+def test_dense_knn_large_n_sampled_select_vs_oracle(N, C, K, kind):
+    """N >= 1024 takes the sample-pre-filtered select; its result must equal the exact top-K whatever the
+    point order (sorted clouds defeat the sample -> exact fallback) and with heavy ties (duplicates)."""
+    from deep_gcns_torch_amd import dense_ops, synth
+    from oracle import dense_ref
+    dev = _dev()
+    x = synth.lattice_cloud(2, C, N, seed=N + K)
+    if kind == "sorted":
+        order = torch.argsort(x[:, 0, :, 0], dim=1)                       # points sorted along the first axis
+        x = torch.gather(x, 2, order.view(2, 1, N, 1).expand(2, C, N, 1)).contiguous()
+    elif kind == "duplicates":
+        x = x[:, :, torch.randint(0, 64, (N,), generator=torch.Generator().manual_seed(1))]   # 64 distinct points
+    ei = dense_ops.knn_edge_index(x.to(dev), K, 1)
+    mine = ei[0].cpu()
+    dist = dense_ref.pairwise_distance(x.transpose(2, 1).squeeze(-1))
+    ref_sorted = torch.sort(dist, dim=2).values[:, :, :K]
+    assert torch.equal(torch.gather(dist, 2, mine), ref_sorted)
+    assert bool((torch.sort(mine, dim=2).values.diff(dim=2) != 0).all()) if K > 1 else True
+    # ties are ordered by index: within equal distances the ids ascend, and the boundary takes the lowest ids
+    d_m = torch.gather(dist, 2, mine)
+    same = d_m.diff(dim=2) == 0
+    assert bool((mine.diff(dim=2)[same] > 0).all())
+    kth = ref_sorted[:, :, -1:]
+    n_le = (dist <= kth).sum(2)
+    if kind == "duplicates":
+        # among the points tied with the K-th distance the chosen ones are the lowest-indexed
+        for b in range(2):
+            for i in (0, N // 2, N - 1):
+                tied = torch.nonzero(dist[b, i] == kth[b, i, 0]).flatten()
+                chosen = mine[b, i][d_m[b, i] == kth[b, i, 0]]
+                assert torch.equal(chosen, tied[:chosen.numel()])
+    assert bool((n_le >= K).all())
