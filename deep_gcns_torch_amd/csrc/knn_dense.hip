@@ -32,6 +32,7 @@ struct KnnParams {
   const float* x;
   int64_t sb, sc, sn;  // strides in floats of (B, C, N)
   int B, C, N, K, dilation, Kout;
+  int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
   int64_t* ctr_out;    // [B, N, Kout] centre ids (may be null)
@@ -209,7 +210,7 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
 #pragma unroll
   for (int s = 0; s < kMaxPerLane; ++s) {
     const int j = s * kWave + lane;
-    key[s] = (s < slots && j < N) ? key_of(drow[j]) : 0xFFFFFFFFu;
+    key[s] = (s < slots && j < N && !(P.exclude_self && j == i)) ? key_of(drow[j]) : 0xFFFFFFFFu;
   }
 
   // phases 2-3.  Fast path: threshold a 256-key SAMPLE (4 keys per lane) at a rank chosen so that, with
@@ -445,11 +446,11 @@ using namespace dgcn;
 // point (self included, ascending distance); positions 0, d, 2d, ... are written, Kout = ceil(K/d).
 // nn_out / ctr_out: [B, N, Kout] int64 contiguous (ctr_out may be NULL).
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
-                                  int32_t C, int32_t N, int32_t K, int32_t dilation, int64_t* nn_out,
-                                  int64_t* ctr_out, void* stream) {
+                                  int32_t C, int32_t N, int32_t K, int32_t dilation, int32_t exclude_self,
+                                  int64_t* nn_out, int64_t* ctr_out, void* stream) {
   if (!x || !nn_out) return DGCN_E_NULL;
   if (B < 0 || C <= 0 || N <= 0 || K <= 0 || dilation <= 0) return DGCN_E_SHAPE;
-  if (K > N || K > 512) return DGCN_E_SHAPE;             // sorted winners: 8 u64 per lane
+  if (K > N - (exclude_self ? 1 : 0) || K > 512) return DGCN_E_SHAPE;             // sorted winners: 8 u64 per lane
   if (N > kMaxPerLane * kWave) return DGCN_E_SHAPE;      // 64 keys per lane in the select phase: N <= 4096
   if (B == 0) return DGCN_OK;
 
@@ -466,6 +467,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.B = B; P.C = C; P.N = N; P.K = K; P.dilation = dilation;
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
+  P.exclude_self = exclude_self ? 1 : 0;
   P.sample_rank = 0;
   if (N >= 1024) {
     const double ns = 4.0 * kWave, f = static_cast<double>(K) / N;

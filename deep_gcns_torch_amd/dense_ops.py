@@ -20,21 +20,21 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # ----------------------------------------------------------------------------------------
 # kNN
 # ----------------------------------------------------------------------------------------
-def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, ctr_out):
+def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, ctr_out, exclude_self: bool = False):
     """x3: (B, C, N) fp32 view (any strides)."""
     lib = _lib.load()
     dev = _lib.require_device(x3)
     B, C, N = x3.shape
     with torch.cuda.device(dev):
         rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,
-                                    dilation, nn_out.data_ptr(), _lib.ptr(ctr_out),
+                                    dilation, 1 if exclude_self else 0, nn_out.data_ptr(), _lib.ptr(ctr_out),
                                     _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_knn_dense_f32")
 
 
-def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1) -> torch.Tensor:
+def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1, exclude_self: bool = False) -> torch.Tensor:
     """x (B,C,N,1) -> edge_index (2,B,N,k) int64: [0] = every `dilation`-th of the k*dilation nearest
-    neighbours (self included, ascending distance), [1] = centre ids."""
+    neighbours (ascending distance; self included unless ``exclude_self``), [1] = centre ids."""
     with torch.no_grad():
         x3 = x.detach()
         if x3.dtype != torch.float32:
@@ -44,18 +44,18 @@ def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1) -> torch.Tensor:
         K = k * dilation
         kout = (K + dilation - 1) // dilation
         ei = torch.empty(2, B, N, kout, dtype=torch.int64, device=x.device)
-        _knn_launch(x3, K, dilation, ei[0], ei[1])
+        _knn_launch(x3, K, dilation, ei[0], ei[1], exclude_self)
     return ei
 
 
-def knn_indices(pts: torch.Tensor, k: int, dilation: int = 1) -> torch.Tensor:
+def knn_indices(pts: torch.Tensor, k: int, dilation: int = 1, exclude_self: bool = False) -> torch.Tensor:
     """pts (B,N,C) point-major features -> (B,N,k) int64 neighbour ids (sparse-layout callers)."""
     with torch.no_grad():
         p = pts.detach().float()
         B, N, C = p.shape
         K = k * dilation
         out = torch.empty(B, N, (K + dilation - 1) // dilation, dtype=torch.int64, device=pts.device)
-        _knn_launch(p.permute(0, 2, 1), K, dilation, out, None)
+        _knn_launch(p.permute(0, 2, 1), K, dilation, out, None, exclude_self)
     return out
 
 

@@ -71,9 +71,20 @@ class DenseDilatedKnnGraph(nn.Module):
 
 
 class DilatedKnnGraph(nn.Module):
-    """Tree-based (torch_cluster) per-sample variant of the reference (:79-101): self-excluding kNN.
-    Not part of the hot path named by the benchmark configs; not implemented."""
+    """The reference's torch_cluster variant (:79-101): per sample, the k*d nearest neighbours of every point
+    EXCLUDING the point itself (knn_graph(..., loop=False)), grouped by centre, then dilated.  Served by the
+    same brute-force HIP kernel with the query point masked out (exact, not a tree)."""
 
     def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0):
         super().__init__()
-        raise NotImplementedError("DilatedKnnGraph (knn='tree', torch_cluster) is not implemented; use knn='matrix'")
+        self.dilation = dilation
+        self.stochastic = stochastic
+        self.epsilon = epsilon
+        self.k = k
+        self._dilated = DenseDilated(k, dilation, stochastic, epsilon)
+        self.knn = dense_ops.knn_edge_index
+
+    def forward(self, x):
+        if self._dilated._random_branch():
+            return _take_random_k(self.knn(x, self.k * self.dilation, 1, exclude_self=True), self.k, self.dilation)
+        return self.knn(x, self.k, self.dilation, exclude_self=True)

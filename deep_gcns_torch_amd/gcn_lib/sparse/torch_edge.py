@@ -6,7 +6,7 @@ knn_graph_matrix :94-104).  The neighbour search itself is libdgcn's fused dista
 import torch
 from torch import nn
 
-__all__ = ["Dilated", "DilatedKnnGraph", "knn_matrix", "knn_graph_matrix"]
+__all__ = ["Dilated", "DilatedKnnGraph", "knn_matrix", "knn_graph_matrix", "knn_graph"]
 
 
 class Dilated(nn.Module):
@@ -29,18 +29,31 @@ class Dilated(nn.Module):
         return edge_index[:, ::self.dilation]
 
 
-def knn_matrix(x, k=16, batch=None):
-    """(N_total, C) features of equally sized clouds -> (nn_idx, center_idx), each (1, N_total*k),
-    neighbours sorted by ascending distance, self included, ids offset per cloud."""
+def _knn_flat(x, k, batch, exclude_self):
     from ... import dense_ops
     with torch.no_grad():
         n_clouds = 1 if batch is None else int(batch[-1]) + 1
+        if x.shape[0] % n_clouds != 0:
+            raise NotImplementedError("kNN kernel needs equally sized clouds (N_total divisible by batch size)")
         pts = x.detach().reshape(n_clouds, -1, x.shape[-1])
         n_points = pts.shape[1]
-        nn_idx = dense_ops.knn_indices(pts, k)                                   # (B, N, k) int64
+        nn_idx = dense_ops.knn_indices(pts, k, 1, exclude_self)                  # (B, N, k) int64
         nn_idx = nn_idx + torch.arange(0, n_points * n_clouds, n_points, device=x.device).view(n_clouds, 1, 1)
         center = torch.arange(0, n_points * n_clouds, device=x.device).repeat_interleave(k)
     return nn_idx.reshape(1, -1), center.view(1, -1)
+
+
+def knn_matrix(x, k=16, batch=None):
+    """(N_total, C) features of equally sized clouds -> (nn_idx, center_idx), each (1, N_total*k),
+    neighbours sorted by ascending distance, self included, ids offset per cloud."""
+    return _knn_flat(x, k, batch, False)
+
+
+def knn_graph(x, k, batch=None, loop=False, flow="source_to_target"):
+    """Stand-in for torch_cluster.knn_graph on equally sized clouds: (2, N_total*k), row 0 = neighbour,
+    row 1 = centre, grouped by centre, self excluded unless ``loop`` (exact brute force on the GPU)."""
+    nn_idx, center_idx = _knn_flat(x, k, batch, not loop)
+    return torch.cat((nn_idx, center_idx), dim=0)
 
 
 def knn_graph_matrix(x, k=16, batch=None):
@@ -56,9 +69,7 @@ class DilatedKnnGraph(nn.Module):
         self.epsilon = epsilon
         self.k = k
         self._dilated = Dilated(k, dilation, stochastic, epsilon)
-        if knn != 'matrix':
-            raise NotImplementedError("only knn='matrix' is implemented (tree kNN needs torch_cluster)")
-        self.knn = knn_graph_matrix
+        self.knn = knn_graph_matrix if knn == 'matrix' else knn_graph
 
     def forward(self, x, batch):
         return self._dilated(self.knn(x, self.k * self.dilation, batch), batch)

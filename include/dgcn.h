@@ -167,10 +167,12 @@ int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshif
  *            D_ij = (|x_i|^2 + (-2 <x_i, x_j>)) + |x_j|^2 in fp32; equal distances ordered by index
  *   nn_out   [B, N, ceil(K/dilation)] int64: positions 0, d, 2d, ... of the sorted list
  *   ctr_out  same shape or NULL: the centre point id (edge_index[1])
+ *   exclude_self != 0: the query point itself is never returned (torch_cluster.knn_graph(loop=False),
+ *            gcn_lib/dense/torch_edge.py:97, gcn_lib/sparse/torch_edge.py:46); then K <= N-1
  * Limits: N <= 4096, K <= 512, K <= N. */
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
-                       int32_t N, int32_t K, int32_t dilation, int64_t* nn_out, int64_t* ctr_out,
-                       void* stream);
+                       int32_t N, int32_t K, int32_t dilation, int32_t exclude_self, int64_t* nn_out,
+                       int64_t* ctr_out, void* stream);
 
 /* Per-vertex GEMM on fp32 MFMA: out[(b*N+n)*M + m] = sum_c x[b,c,n] * W[c*M+m] + bias[m].
  * With W = [(W1-W2)^T | W2^T] this yields P and Q of the EdgeConv split

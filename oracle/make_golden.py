@@ -160,6 +160,18 @@ def dense_cases(dense):
                       edge_index=dense.DenseDilatedKnnGraph(9, 2)(x).contiguous().to(torch.int32),
                       dist=dense.pairwise_distance(x.transpose(2, 1).squeeze(-1))))
 
+    # sparse-layout kNN (gcn_lib/sparse/torch_edge.py) and the self-excluding torch_cluster variants, on lattice clouds
+    import importlib
+    sp_edge = importlib.import_module("gcn_lib.sparse.torch_edge")
+    x = synth.lattice_cloud(3, 6, 160, seed=77)
+    flat = x.squeeze(-1).transpose(1, 2).reshape(3 * 160, 6).contiguous()
+    batch = torch.arange(3).repeat_interleave(160)
+    cases.append(dict(kind="knn_sparse", name="sparse_knn_matrix", x=x, flat=flat, batch=batch, k=6, dilation=2,
+                      edge_index=sp_edge.DilatedKnnGraph(6, 2, knn="matrix")(flat, batch).to(torch.int32),
+                      edge_index_tree=sp_edge.DilatedKnnGraph(6, 2, knn="tree")(flat, batch).to(torch.int32),
+                      dense_tree=dense.DilatedKnnGraph(6, 2)(x).contiguous().to(torch.int32),
+                      dist=dense.pairwise_distance(x.transpose(2, 1).squeeze(-1))))
+
     def conv_case(name, cls, Cin, Cout, B, N, k, norm, act="relu", seed=0):
         torch.manual_seed(seed)
         x = torch.randn(B, Cin, N, 1, requires_grad=True)

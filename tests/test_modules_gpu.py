@@ -239,3 +239,40 @@ def test_dense_knn_large_n_sampled_select_vs_oracle(N, C, K, kind):
                 chosen = mine[b, i][d_m[b, i] == kth[b, i, 0]]
                 assert torch.equal(chosen, tied[:chosen.numel()])
     assert bool((n_le >= K).all())
+
+
+def test_sparse_layout_and_self_excluding_knn_match_reference():
+    """gcn_lib.sparse.torch_edge.DilatedKnnGraph (knn='matrix' and the torch_cluster-style 'tree' variant)
+    and gcn_lib.dense.DilatedKnnGraph against the reference's own modules (golden), compared through the
+    exact lattice distances (equal distances may be ordered differently)."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from gcn_lib.sparse.torch_edge import DilatedKnnGraph as SparseKnn
+    from gcn_lib.dense.torch_edge import DilatedKnnGraph as DenseTreeKnn
+    dev = _dev()
+    case = next(c for c in DENSE if c["kind"] == "knn_sparse")
+    k, d, B, N = case["k"], case["dilation"], 3, 160
+    dist = case["dist"]                                                   # (B,N,N)
+    flat, batch = case["flat"].to(dev), case["batch"].to(dev)
+
+    def dists_of(edge_index):                                             # (2, B*N*k) flattened, global ids
+        nb = edge_index[0].cpu().long().view(B, N, k)
+        ct = edge_index[1].cpu().long().view(B, N, k)
+        off = (torch.arange(B) * N).view(B, 1, 1)
+        assert torch.equal(ct - off, torch.arange(N).view(1, N, 1).expand(B, N, k))
+        assert bool(((nb - off) >= 0).all()) and bool(((nb - off) < N).all())
+        return torch.gather(dist, 2, nb - off), nb - off
+
+    for knn, key in (("matrix", "edge_index"), ("tree", "edge_index_tree")):
+        mine = SparseKnn(k, d, knn=knn)(flat, batch)
+        assert mine.shape == (2, B * N * k) and mine.dtype == torch.int64
+        dm, nbm = dists_of(mine)
+        dr, _ = dists_of(case[key])
+        assert torch.equal(dm, dr), knn
+        if knn == "tree":
+            assert bool((nbm != torch.arange(N).view(1, N, 1)).all())     # self excluded
+    dt = DenseTreeKnn(k, d)(case["x"].to(dev))
+    assert dt.shape == (2, B, N, k)
+    ref = case["dense_tree"].long()
+    assert torch.equal(torch.gather(dist, 2, dt[0].cpu()), torch.gather(dist, 2, ref[0]))
+    assert bool((dt[0].cpu() != torch.arange(N).view(1, N, 1)).all())
