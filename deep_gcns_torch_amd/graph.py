@@ -141,11 +141,21 @@ class Graph:
 # epoch in the reference's training loops).  Keyed by the tensor OBJECT through a weak
 # reference, never by data_ptr: a recycled allocation must not resurrect a stale structure.
 # ----------------------------------------------------------------------------------------
-_cache: dict = {}   # id(tensor) -> (weakref to tensor, key, Graph)
+_cache: dict = {}      # id(tensor) -> (weakref to tensor, key, Graph)
+_by_storage: dict = {}  # (data_ptr, shape, stride, dtype, num_nodes) -> id of the LIVE tensor that owns the entry
+
+
+def _alias_key(t, num_nodes):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, int(num_nodes))
 
 
 def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
-    """Return the cached Graph for ``edge_index`` (a (2,E) tensor) or pass a Graph through."""
+    """Return the cached Graph for ``edge_index`` (a (2,E) tensor) or pass a Graph through.
+
+    Hits: the same tensor object at the same version, or an ALIAS of a cached tensor that is still alive
+    (same storage pointer, shape, strides and shared version counter) -- e.g. the ``edge_index.detach()`` that
+    re-entrant ``torch.utils.checkpoint`` hands to the recomputed layer.  While the cached tensor is alive its
+    storage cannot have been recycled, so an alias necessarily holds the same edges."""
     if isinstance(edge_index, Graph):
         return edge_index
     if num_nodes is None:
@@ -155,11 +165,27 @@ def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
     hit = _cache.get(ident)
     if hit is not None and hit[0]() is edge_index and hit[1] == key:
         return hit[2]
+    akey = _alias_key(edge_index, num_nodes)
+    owner = _by_storage.get(akey)
+    if owner is not None:
+        ohit = _cache.get(owner)
+        if ohit is not None:
+            live = ohit[0]()
+            if live is not None and live._version == edge_index._version and ohit[1][0] == live._version \
+                    and live.data_ptr() == edge_index.data_ptr():
+                return ohit[2]
     g = Graph.from_edge_index(edge_index, int(num_nodes))
-    ref = weakref.ref(edge_index, lambda _r, ident=ident: _cache.pop(ident, None))
-    _cache[ident] = (ref, key, g)
+
+    def _evict(_r, ident=ident, akey=akey):
+        _cache.pop(ident, None)
+        if _by_storage.get(akey) == ident:
+            _by_storage.pop(akey, None)
+
+    _cache[ident] = (weakref.ref(edge_index, _evict), key, g)
+    _by_storage[akey] = ident
     return g
 
 
 def clear_cache() -> None:
     _cache.clear()
+    _by_storage.clear()

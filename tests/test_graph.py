@@ -64,8 +64,19 @@ def test_cache_is_keyed_by_tensor_object_and_version():
     g2 = graph_of(ei, 20)
     assert g2 is not g1
     clone = ei.clone()
-    assert graph_of(clone, 20) is not g2     # different object -> different entry
+    assert graph_of(clone, 20) is not g2     # different object, different storage -> different entry
     assert graph_of(g2) is g2
+    # an alias of a LIVE cached tensor (what re-entrant checkpointing passes: edge_index.detach()) hits
+    assert graph_of(ei.detach(), 20) is g2
+    assert graph_of(ei.view(2, -1), 20) is g2
+    assert graph_of(ei[:, :32], 20) is not g2            # different shape: not an alias of the whole list
+    # once the owner dies a recycled allocation must not resurrect the entry
+    import gc
+    from deep_gcns_torch_amd import graph as G
+    n_before = len(G._cache)
+    del clone
+    gc.collect()
+    assert len(G._cache) == n_before - 1
 
 
 def test_empty_and_rectangular():
