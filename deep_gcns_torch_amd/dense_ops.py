@@ -218,17 +218,7 @@ def edge_reduce(PQ: torch.Tensor, idx: torch.Tensor, has_p: bool, act: int = ACT
 BN_NONE, BN_TRAIN, BN_EVAL = 0, 1, 2
 
 
-def _splitk_xt_g(g2: torch.Tensor, xr: torch.Tensor) -> torch.Tensor:
-    """g2^T @ xr for tall-skinny operands ((R, M)^T (R, C), R = B*N >> M, C): batched split-K + fixed-order
-    sum instead of one GEMM with a 32768-long reduction (which the library runs on a handful of CUs)."""
-    R = g2.size(0)
-    S = 1
-    while S < 64 and R % (S * 2) == 0 and R // (S * 2) >= 256:
-        S *= 2
-    if S == 1:
-        return g2.t() @ xr
-    part = torch.bmm(g2.view(S, R // S, -1).transpose(1, 2), xr.view(S, R // S, -1))
-    return part.sum(0)
+from .nn_util import splitk_xt_g as _splitk_xt_g  # noqa: E402  (tall-skinny g^T x as batched split-K)
 
 
 class _EdgeConv2dFused(torch.autograd.Function):

@@ -7,6 +7,7 @@ norm, act, [dropout] per hidden layer; nothing after the last Linear when ``last
 """
 from torch import nn
 
+from ...nn_util import TallLinear
 from ...utils.data_util import get_atom_feature_dims, get_bond_feature_dims
 
 __all__ = ["act_layer", "norm_layer", "MultiSeq", "MLP", "AtomEncoder", "BondEncoder"]
@@ -58,7 +59,7 @@ class MLP(nn.Sequential):
         stages = []
         last = len(channels) - 1
         for i in range(1, len(channels)):
-            stages.append(nn.Linear(channels[i - 1], channels[i], bias))
+            stages.append(TallLinear(channels[i - 1], channels[i], bias))   # an nn.Linear; split-K weight grad
             if last_lin and i == last:
                 continue
             if _enabled(norm):

@@ -13,6 +13,7 @@ from ... import ops
 from ...graph import graph_of
 from .torch_edge import DilatedKnnGraph
 from .torch_message import GenMessagePassing, MsgNorm
+from ...nn_util import TallLinear
 from .torch_nn import MLP, BondEncoder, act_layer, norm_layer  # noqa: F401
 
 __all__ = ["GENConv", "MRConv", "EdgConv", "GATConv", "SAGEConv", "RSAGEConv", "SemiGCNConv", "GinConv",
@@ -36,7 +37,7 @@ class GENConv(GenMessagePassing):
         self.bond_encoder = bond_encoder
         self.msg_norm = MsgNorm(learn_msg_scale=learn_msg_scale) if msg_norm else None
         if encode_edge:
-            self.edge_encoder = BondEncoder(emb_dim=in_dim) if bond_encoder else nn.Linear(edge_feat_dim, in_dim)
+            self.edge_encoder = BondEncoder(emb_dim=in_dim) if bond_encoder else TallLinear(edge_feat_dim, in_dim)
 
     def forward(self, x, edge_index, edge_attr=None):
         edge_emb = self.edge_encoder(edge_attr) if (self.encode_edge and edge_attr is not None) else edge_attr
