@@ -57,7 +57,6 @@ struct FwdParams {
 
 struct BwdParams {
   WalkGraph g;      // transposed walk: rows = sources, col = destinations
-  const int32_t* d_rowptr;  // unused (reserved)
   const float* x;
   int64_t x_stride;
   const float* ea;
@@ -819,7 +818,6 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   BwdParams P;
   P.g = WalkGraph{g->n_src, g->t_n_work, g->t_rowptr, g->t_col, g->t_eperm,
                   g->t_work_row, g->t_work_beg, g->t_work_end, g->t_work_slot};
-  P.d_rowptr = g->rowptr;
   P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
   P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;

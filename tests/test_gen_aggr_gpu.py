@@ -202,3 +202,56 @@ def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_s
     assert (rng < 60.0) == expect_shifted
     if not expect_shifted:
         assert torch.equal(grads[True], grads[False])     # same two-gather code path, bit-identical
+
+
+def test_degenerate_graphs():
+    """Empty edge list, a single node, all edges into one node, C not a multiple of 4, one channel."""
+    from deep_gcns_torch_amd import ops
+    from oracle import sparse_ref
+    dev = _dev()
+    x = torch.randn(5, 8, device=dev, requires_grad=True)
+    empty = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    for aggr in ("add", "mean", "max", "softmax", "power"):
+        out = ops.gen_aggregate(x, empty, aggr=aggr, dim_size=5)
+        ref = sparse_ref.gen_propagate(x.detach().cpu(), empty.cpu(), aggr=aggr, dim_size=5)
+        torch.testing.assert_close(out.detach().cpu(), ref, rtol=1e-5, atol=1e-9)
+        out.sum().backward()
+        assert torch.count_nonzero(x.grad) == 0
+        x.grad = None
+    one = torch.randn(1, 3, device=dev)                       # single node with a self loop, C = 3
+    loop = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    torch.testing.assert_close(ops.gen_aggregate(one, loop, aggr="softmax").cpu(),
+                               sparse_ref.gen_propagate(one.cpu(), loop.cpu(), aggr="softmax"), rtol=1e-5, atol=1e-7)
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(300, 1, generator=g)                     # one channel, star graph into node 0
+    star = torch.stack([torch.arange(300), torch.zeros(300, dtype=torch.long)])
+    for aggr, kw in (("softmax", dict(t=3.0)), ("max", {}), ("power", dict(p=3.0))):
+        xr = xs.clone().requires_grad_(True)
+        ref = sparse_ref.gen_propagate(xr, star, aggr=aggr, **kw)
+        ref.sum().backward()
+        xd = xs.to(dev).requires_grad_(True)
+        out = ops.gen_aggregate(xd, star.to(dev), aggr=aggr, **kw)
+        out.sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_strided_inputs_and_non_default_stream():
+    """x given as a column slice (row stride > C) and launches on a side stream (library follows torch's
+    current stream; the caller synchronises streams as usual)."""
+    from deep_gcns_torch_amd import ops
+    dev = _dev()
+    ei = AGG["graphs"]["tricky"].to(dev)
+    big = torch.randn(257, 192, device=dev)
+    x = big[:, 64:128]                                         # stride (192, 1): rows are 16-B aligned
+    ref = ops.gen_aggregate(x.contiguous(), ei, aggr="softmax_sg", t=0.5)
+    assert torch.equal(ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.5), ref)
+    xu = big[:, 1:65]                                          # misaligned rows -> scalar-lane kernel, same result
+    torch.testing.assert_close(ops.gen_aggregate(xu, ei, aggr="softmax_sg", t=0.5),
+                               ops.gen_aggregate(xu.contiguous(), ei, aggr="softmax_sg", t=0.5), rtol=1e-6, atol=1e-7)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.5)
+    s.synchronize()
+    assert torch.equal(out, ref)

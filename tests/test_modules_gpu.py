@@ -276,3 +276,28 @@ def test_sparse_layout_and_self_excluding_knn_match_reference():
     ref = case["dense_tree"].long()
     assert torch.equal(torch.gather(dist, 2, dt[0].cpu()), torch.gather(dist, 2, ref[0]))
     assert bool((dt[0].cpu() != torch.arange(N).view(1, N, 1)).all())
+
+
+@pytest.mark.parametrize("B,C,N,k,d", [(1, 3, 101, 5, 1), (3, 7, 130, 1, 1), (2, 4, 64, 64, 1), (1, 2, 4096, 3, 7)])
+def test_dense_knn_odd_shapes(B, C, N, k, d):
+    """N not a multiple of 4 (scalar distance phase), k = 1, K = N, tiny C."""
+    from deep_gcns_torch_amd import dense_ops, synth
+    from oracle import dense_ref
+    dev = _dev()
+    x = synth.lattice_cloud(B, C, N, seed=B * 100 + N)
+    ei = dense_ops.knn_edge_index(x.to(dev), k, d)
+    assert ei.shape == (2, B, N, k)
+    dist = dense_ref.pairwise_distance(x.transpose(2, 1).squeeze(-1))
+    ref = torch.sort(dist, dim=2).values[:, :, :k * d][:, :, ::d]
+    assert torch.equal(torch.gather(dist, 2, ei[0].cpu()), ref)
+    assert torch.equal(ei[1].cpu(), torch.arange(N).view(1, N, 1).expand(B, N, k))
+
+
+def test_dense_limits_are_reported_not_silently_wrong():
+    from deep_gcns_torch_amd import dense_ops
+    dev = _dev()
+    x = torch.randn(1, 3, 5000, 1, device=dev)
+    with pytest.raises(RuntimeError, match="shape"):
+        dense_ops.knn_edge_index(x, 4, 1)                      # N > 4096
+    with pytest.raises(RuntimeError, match="shape"):
+        dense_ops.knn_edge_index(x[:, :, :1024], 600, 1)       # K > 512
