@@ -248,7 +248,7 @@ def test_strided_inputs_and_non_default_stream():
     assert torch.equal(ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.5), ref)
     xu = big[:, 1:65]                                          # misaligned rows -> scalar-lane kernel, same result
     torch.testing.assert_close(ops.gen_aggregate(xu, ei, aggr="softmax_sg", t=0.5),
-                               ops.gen_aggregate(xu.contiguous(), ei, aggr="softmax_sg", t=0.5), rtol=1e-6, atol=1e-7)
+                               ops.gen_aggregate(xu.contiguous(), ei, aggr="softmax_sg", t=0.5), rtol=1e-5, atol=1e-6)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
