@@ -81,6 +81,21 @@ def main():
     out.append(dict(op="resdynblock2d_d14_fwd_bwd (knn + edgeconv + residual)", ms_avg=avg, ms_min=mn,
                     edges_per_s=edges / (avg * 1e-3)))
 
+    # the same block step captured in a HIP graph (no host launch overhead): what the kernels alone cost
+    params = [xg] + list(blk.parameters())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            torch.autograd.grad(blk(xg), params, go)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static = torch.autograd.grad(blk(xg), params, go)  # noqa: F841
+    avg, mn = timed(graph.replay, a.iters)
+    out.append(dict(op="resdynblock2d_d14_fwd_bwd, HIP-graph replay", ms_avg=avg, ms_min=mn,
+                    edges_per_s=edges / (avg * 1e-3)))
+
     if a.cpu_baseline:
         from oracle import dense_ref
         torch.set_num_threads(os.cpu_count())

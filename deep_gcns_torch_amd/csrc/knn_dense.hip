@@ -284,14 +284,13 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
 template <int TM, bool VEC4>
 __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams P, int Npad, int Kpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int C = P.C, N = P.N, K = P.K;
+  const int C = P.C, N = P.N;
   float* q = reinterpret_cast<float*>(smem);                 // [C][TM]
   float* sq = q + static_cast<size_t>(C) * TM;               // [TM] (padded to 16 floats)
   float* dist = sq + 16;                                     // [TM][Npad]
   uint32_t* selkey = reinterpret_cast<uint32_t*>(dist + static_cast<size_t>(TM) * Npad);  // [TM][Kpad]
 
   const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
   const int tiles_per_b = (N + TM - 1) / TM;
   const int b = blockIdx.x / tiles_per_b;
