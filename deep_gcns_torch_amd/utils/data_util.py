@@ -47,3 +47,30 @@ def generate_sub_graphs(adj, parts, cluster_number=10, batch_size=1):
         sg_nodes.append(nodes)
         sg_edges.append(torch.from_numpy(np.vstack((coo.row, coo.col))).long())
     return sg_nodes, sg_edges
+
+
+# ---- dataset-preparation helpers the OGB graph-property examples import (data prep on CPU tensors, not
+# ---- part of the message-passing hot path; reference utils/data_util.py:26-40) --------------------------
+def add_zeros(data):
+    data.x = torch.zeros(data.num_nodes, dtype=torch.long)
+    return data
+
+
+def extract_node_feature(data, reduce='add'):
+    """Node features = reduction of the incident edge features by source node."""
+    if reduce not in ['mean', 'max', 'add']:
+        raise Exception('Unknown Aggregation Type')
+    idx = data.edge_index[0]
+    out = torch.zeros((data.num_nodes,) + tuple(data.edge_attr.shape[1:]), dtype=data.edge_attr.dtype,
+                      device=data.edge_attr.device)
+    index = idx.view(-1, *([1] * (data.edge_attr.dim() - 1))).expand_as(data.edge_attr)
+    kind = {'add': 'sum', 'mean': 'mean', 'max': 'amax'}[reduce]
+    data.x = out.scatter_reduce(0, index, data.edge_attr, kind, include_self=False)
+    return data
+
+
+def __getattr__(name):
+    if name == "PartNet":
+        raise ImportError("utils.data_util.PartNet is a torch_geometric InMemoryDataset (dataset code, out of the "
+                          "hot-path scope); import it from the reference's utils with torch_geometric installed")
+    raise AttributeError(name)
