@@ -11,7 +11,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  (must be imported first: libdgcn binds to the HIP runtime torch loaded)
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdgcn.so"
+_LIB_PATH = Path(os.environ.get("DGCN_LIB_PATH") or (Path(__file__).resolve().parent / "csrc" / "libdgcn.so"))
 
 # aggregation modes / flags (include/dgcn.h)
 AGGR_ADD, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4

@@ -257,7 +257,11 @@ __device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][V
 template <int MODE, int VEC, int LPR, bool HAS_EA>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParams P) {
   constexpr int G = kWave / LPR;            // edges walked in parallel by one wave
+#ifdef DGCN_FWD_U
+  constexpr int U = DGCN_FWD_U;
+#else
   constexpr int U = (VEC == 4) ? 4 : 8;     // load batches in flight per lane
+#endif
   constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
 
   const int lane = lane_id();
@@ -775,7 +779,11 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
 
   const int n_items = g->n_work ? g->n_work : g->n_dst;
+#ifdef DGCN_FWD_WAVES_PER_CU
+  const int grid = round_up8(grid_for_waves(n_items, DGCN_FWD_WAVES_PER_CU));
+#else
   const int grid = round_up8(grid_for_waves(n_items));
+#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (mode) {
     case DGCN_AGGR_ADD: launch_fwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;
