@@ -1,0 +1,78 @@
+"""Device-side graph preprocessing.
+
+The reference prepares graphs on the CPU every epoch: PyG ``to_undirected`` / ``add_self_loops``
+(examples/ogb/ogbn_arxiv/main.py:72-75), a random node partition and scipy CSR slicing per cluster
+(utils/data_util.py:43-61, examples/ogb/ogbn_products/main.py:120-126), then an H2D copy per cluster.  Once the
+aggregation runs at HBM speed that host work is the epoch bottleneck.  These helpers do the same integer work
+with device-side sort / scan / compaction (rocPRIM through torch) on whatever device ``edge_index`` lives on, and
+return COO ``edge_index`` tensors with the reference's conventions so they can be fed to the modules (and cached
+as CSR/CSC by ``graph.graph_of``) without touching the host.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def coalesce(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Sort by (row, col) and drop duplicate edges (torch_sparse.coalesce on indices only)."""
+    key = edge_index[0] * num_nodes + edge_index[1]
+    key = torch.unique(key, sorted=True)
+    return torch.stack([key // num_nodes, key % num_nodes])
+
+
+def to_undirected(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Both directions of every edge, coalesced (sorted by source, duplicates removed): PyG ``to_undirected``."""
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    return coalesce(both, num_nodes)
+
+
+def add_self_loops(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Append one (i, i) edge per node at the END of the list (PyG ``add_self_loops`` keeps existing loops)."""
+    loop = torch.arange(num_nodes, device=edge_index.device, dtype=edge_index.dtype)
+    return torch.cat([edge_index, loop.unsqueeze(0).repeat(2, 1)], dim=1)
+
+
+def remove_self_loops(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor] = None):
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
+
+
+def random_partition(num_nodes: int, cluster_number: int, generator: Optional[torch.Generator] = None,
+                     device="cpu") -> torch.Tensor:
+    """Uniform random cluster id per node (utils/data_util.py:43-45), generated on ``device``."""
+    return torch.randint(0, cluster_number, (num_nodes,), generator=generator, device=device)
+
+
+def induced_subgraph(edge_index: torch.Tensor, parts: torch.Tensor, cluster: int, num_nodes: int,
+                     edge_attr: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
+    """Sub-graph induced by the nodes with ``parts == cluster`` (what ``adj[nodes, :][:, nodes]`` does on the
+    host, utils/data_util.py:55-60): returns (node ids ascending, relabelled edge_index in the original edge
+    order, the matching rows of ``edge_attr``, ids of the kept edges)."""
+    mask = parts == cluster
+    nodes = torch.nonzero(mask).flatten()
+    new_id = torch.full((num_nodes,), -1, dtype=edge_index.dtype, device=edge_index.device)
+    new_id[nodes] = torch.arange(nodes.numel(), device=edge_index.device, dtype=edge_index.dtype)
+    keep = mask[edge_index[0]] & mask[edge_index[1]]
+    eids = torch.nonzero(keep).flatten()
+    sub = new_id[edge_index[:, eids]]
+    return nodes, sub, (None if edge_attr is None else edge_attr[eids]), eids
+
+
+def generate_sub_graphs(edge_index: torch.Tensor, parts: torch.Tensor, num_nodes: int, cluster_number: int = 10,
+                        batch_size: int = 1) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """Device-side equivalent of utils/data_util.generate_sub_graphs: one induced sub-graph per group of
+    ``batch_size`` clusters.  Edge lists are sorted by (row, col) like the scipy CSR -> COO conversion."""
+    sg_nodes, sg_edges = [], []
+    for b in range(cluster_number // batch_size):
+        group = (parts >= b * batch_size) & (parts < (b + 1) * batch_size)
+        nodes = torch.nonzero(group).flatten()
+        new_id = torch.full((num_nodes,), -1, dtype=edge_index.dtype, device=edge_index.device)
+        new_id[nodes] = torch.arange(nodes.numel(), device=edge_index.device, dtype=edge_index.dtype)
+        keep = group[edge_index[0]] & group[edge_index[1]]
+        sub = new_id[edge_index[:, keep]]
+        sg_nodes.append(nodes)
+        sg_edges.append(coalesce(sub, max(int(nodes.numel()), 1)) if sub.numel() else sub)
+    return sg_nodes, sg_edges
