@@ -33,6 +33,7 @@ class DgcnGraph(C.Structure):
         ("work_row", C.c_void_p), ("work_beg", C.c_void_p), ("work_end", C.c_void_p), ("work_slot", C.c_void_p),
         ("t_n_work", C.c_int32), ("t_n_slots", C.c_int32),
         ("t_work_row", C.c_void_p), ("t_work_beg", C.c_void_p), ("t_work_end", C.c_void_p), ("t_work_slot", C.c_void_p),
+        ("n_split", C.c_int32), ("t_n_split", C.c_int32), ("split_item", C.c_void_p), ("t_split_item", C.c_void_p),
     ]
 
 

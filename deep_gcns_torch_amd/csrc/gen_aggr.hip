@@ -37,6 +37,8 @@ struct WalkGraph {
   const int32_t* work_beg;
   const int32_t* work_end;
   const int32_t* work_slot;
+  int n_split;
+  const int32_t* split_item;
 };
 
 struct FwdParams {
@@ -382,75 +384,66 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
   }
 }
 
-// Merge the partial slots of split (hub) rows.  One wave scans 64 work items; each item that
-// opens a split row is merged by the whole wave, one channel per lane at a time.
+// Merge the partial slots of split (hub) rows: one wave per split row (its first work item is listed in
+// split_item), lanes over channels, slots folded in work-list order -> deterministic.
 template <int MODE>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const FwdParams P) {
   const int lane = lane_id();
   const int C = P.C;
   const int n_work = P.g.n_work;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  const int base = wave * kWave;
-  if (base >= n_work) return;
+  if (wave >= P.g.n_split) return;
   const float p = P.p_dev ? *P.p_dev : P.p;
-  const int it = base + lane;
-  bool first = false;
-  if (it < n_work && P.g.work_slot[it] >= 0) {
-    first = (it == 0) || (P.g.work_row[it - 1] != P.g.work_row[it]);
-  }
-  unsigned long long mask = __ballot(first);
-  while (mask) {
-    const int l = __ffsll(static_cast<long long>(mask)) - 1;
-    mask &= mask - 1;
-    const int i0 = base + l;
-    const int row = uni(P.g.work_row[i0]);
-    const float deg = static_cast<float>(P.g.rowptr[row + 1] - P.g.rowptr[row]);
-    for (int c = lane; c < C; c += kWave) {
-      State<1> st;
-      state_init<MODE, 1>(st);
-      for (int i = i0; i < n_work && P.g.work_row[i] == row; ++i) {
-        const float* ws = P.ws + (static_cast<int64_t>(P.g.work_slot[i]) * 4) * C + c;
-        State<1> o;
-        state_init<MODE, 1>(o);
-        if constexpr (MODE == DGCN_AGGR_MAX) {
-          o.a[0] = ws[0];
-          o.idx[0] = __float_as_int(ws[C]);
-        } else {
-          o.a[0] = ws[0];
-          o.b[0] = ws[C];
-          o.c[0] = ws[2 * C];
-          o.d[0] = ws[3 * C];
-        }
-        state_merge<MODE, 1>(st, o);
-      }
-      const int64_t o = static_cast<int64_t>(row) * C + c;
-      float res, x1 = 0.f, x2 = 0.f;
-      if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
-        const bool any = st.b[0] > 0.f;
-        const float inv = any ? 1.f / st.b[0] : 0.f;
-        res = st.c[0] * inv;
-        x1 = any ? st.a[0] + fast_log(st.b[0]) : 0.f;
-        x2 = st.d[0] * inv;
-      } else if constexpr (MODE == DGCN_AGGR_POWER) {
-        const float q = st.b[0] / fmaxf(deg, 1.f);
-        const float r = fminf(fmaxf(q, kPowLo), kPowHi);
-        res = fast_pow(r, 1.f / p);
-        x1 = q;
-        x2 = st.d[0];
-      } else if constexpr (MODE == DGCN_AGGR_MAX) {
-        res = st.idx[0] >= 0 ? st.a[0] : 0.f;
-      } else if constexpr (MODE == DGCN_AGGR_MEAN) {
-        res = st.b[0] / fmaxf(deg, 1.f);
-      } else {
-        res = st.b[0];
-      }
-      P.out[o] = res;
+  const int i0 = uni(P.g.split_item[wave]);
+  const int row = uni(P.g.work_row[i0]);
+  const float deg = static_cast<float>(P.g.rowptr[row + 1] - P.g.rowptr[row]);
+  int i1 = i0;
+  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
+  for (int c = lane; c < C; c += kWave) {
+    State<1> st;
+    state_init<MODE, 1>(st);
+    for (int i = i0; i < i1; ++i) {
+      const float* ws = P.ws + (static_cast<int64_t>(P.g.work_slot[i]) * 4) * C + c;
+      State<1> o;
+      state_init<MODE, 1>(o);
       if constexpr (MODE == DGCN_AGGR_MAX) {
-        if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = st.idx[0];
-      } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
-        if (P.aux1) static_cast<float*>(P.aux1)[o] = x1;
-        if (P.aux2) P.aux2[o] = x2;
+        o.a[0] = ws[0];
+        o.idx[0] = __float_as_int(ws[C]);
+      } else {
+        o.a[0] = ws[0];
+        o.b[0] = ws[C];
+        o.c[0] = ws[2 * C];
+        o.d[0] = ws[3 * C];
       }
+      state_merge<MODE, 1>(st, o);
+    }
+    const int64_t o = static_cast<int64_t>(row) * C + c;
+    float res, x1 = 0.f, x2 = 0.f;
+    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+      const bool any = st.b[0] > 0.f;
+      const float inv = any ? 1.f / st.b[0] : 0.f;
+      res = st.c[0] * inv;
+      x1 = any ? st.a[0] + fast_log(st.b[0]) : 0.f;
+      x2 = st.d[0] * inv;
+    } else if constexpr (MODE == DGCN_AGGR_POWER) {
+      const float q = st.b[0] / fmaxf(deg, 1.f);
+      const float r = fminf(fmaxf(q, kPowLo), kPowHi);
+      res = fast_pow(r, 1.f / p);
+      x1 = q;
+      x2 = st.d[0];
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+      res = st.idx[0] >= 0 ? st.a[0] : 0.f;
+    } else if constexpr (MODE == DGCN_AGGR_MEAN) {
+      res = st.b[0] / fmaxf(deg, 1.f);
+    } else {
+      res = st.b[0];
+    }
+    P.out[o] = res;
+    if constexpr (MODE == DGCN_AGGR_MAX) {
+      if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = st.idx[0];
+    } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
+      if (P.aux1) static_cast<float*>(P.aux1)[o] = x1;
+      if (P.aux2) P.aux2[o] = x2;
     }
   }
 }
@@ -626,26 +619,15 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
   const int C = P.C;
   const int n_work = P.g.n_work;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  const int base = wave * kWave;
-  if (base >= n_work) return;
-  const int it = base + lane;
-  bool first = false;
-  if (it < n_work && P.g.work_slot[it] >= 0) {
-    first = (it == 0) || (P.g.work_row[it - 1] != P.g.work_row[it]);
-  }
-  unsigned long long mask = __ballot(first);
-  while (mask) {
-    const int l = __ffsll(static_cast<long long>(mask)) - 1;
-    mask &= mask - 1;
-    const int i0 = base + l;
-    const int row = uni(P.g.work_row[i0]);
-    for (int c = lane; c < C; c += kWave) {
-      float acc = 0.f;
-      for (int i = i0; i < n_work && P.g.work_row[i] == row; ++i) {
-        acc += P.ws[static_cast<int64_t>(P.g.work_slot[i]) * C + c];
-      }
-      P.grad_x[static_cast<int64_t>(row) * C + c] = acc;
-    }
+  if (wave >= P.g.n_split) return;
+  const int i0 = uni(P.g.split_item[wave]);
+  const int row = uni(P.g.work_row[i0]);
+  int i1 = i0;
+  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
+  for (int c = lane; c < C; c += kWave) {
+    float acc = 0.f;
+    for (int i = i0; i < i1; ++i) acc += P.ws[static_cast<int64_t>(P.g.work_slot[i]) * C + c];
+    P.grad_x[static_cast<int64_t>(row) * C + c] = acc;
   }
 }
 
@@ -682,9 +664,8 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
   } else {
     launch_fwd_ea<MODE, 1, 64>(P, grid, s);
   }
-  if (P.g.n_work) {
-    const int waves = (P.g.n_work + kWave - 1) / kWave;
-    const int mg = (waves + kWavesPerWg - 1) / kWavesPerWg;
+  if (P.g.n_work && P.g.n_split > 0) {
+    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL((gen_aggr_fwd_merge_kernel<MODE>), dim3(mg), dim3(kWgThreads), 0, s, P);
   }
 }
@@ -710,9 +691,8 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
   } else {
     launch_bwd_ea<MODE, 1, 64>(P, grid, s);
   }
-  if (P.g.n_work) {
-    const int waves = (P.g.n_work + kWave - 1) / kWave;
-    const int mg = (waves + kWavesPerWg - 1) / kWavesPerWg;
+  if (P.g.n_work && P.g.n_split > 0) {
+    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL(gen_aggr_bwd_merge_kernel, dim3(mg), dim3(kWgThreads), 0, s, P);
   }
 }
@@ -762,6 +742,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   if (g->n_dst == 0) return DGCN_OK;
   if (!g->rowptr || (g->n_edges > 0 && !g->col)) return DGCN_E_NULL;
   if (g->n_work && (!g->work_row || !g->work_beg || !g->work_end || !g->work_slot)) return DGCN_E_NULL;
+  if (g->n_work && g->n_split > 0 && !g->split_item) return DGCN_E_NULL;
   if (workspace_bytes < dgcn_gen_aggr_fwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
   if (g->n_work && g->n_slots > 0 && !workspace) return DGCN_E_NULL;
 
@@ -773,7 +754,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
 
   FwdParams P;
   P.g = WalkGraph{g->n_dst, g->n_work, g->rowptr, g->col, g->eperm,
-                  g->work_row, g->work_beg, g->work_end, g->work_slot};
+                  g->work_row, g->work_beg, g->work_end, g->work_slot, g->n_split, g->split_item};
   P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
@@ -812,6 +793,7 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   if (g->n_src == 0) return DGCN_OK;
   if (!g->t_rowptr || (g->n_edges > 0 && (!g->t_col || !g->t_eperm))) return DGCN_E_NULL;
   if (g->t_n_work && (!g->t_work_row || !g->t_work_beg || !g->t_work_end || !g->t_work_slot)) return DGCN_E_NULL;
+  if (g->t_n_work && g->t_n_split > 0 && !g->t_split_item) return DGCN_E_NULL;
   if (workspace_bytes < dgcn_gen_aggr_bwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
   if (g->t_n_work && g->t_n_slots > 0 && !workspace) return DGCN_E_NULL;
 
@@ -825,7 +807,7 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
 
   BwdParams P;
   P.g = WalkGraph{g->n_src, g->t_n_work, g->t_rowptr, g->t_col, g->t_eperm,
-                  g->t_work_row, g->t_work_beg, g->t_work_end, g->t_work_slot};
+                  g->t_work_row, g->t_work_beg, g->t_work_end, g->t_work_slot, g->t_n_split, g->t_split_item};
   P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
   P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;

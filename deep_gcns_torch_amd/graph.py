@@ -29,7 +29,7 @@ HUB_CHUNK = 256
 
 
 def _work_list(rowptr: torch.Tensor, chunk: int):
-    """Split rows with more than 2*chunk edges.  Returns (n_work, n_slots, row, beg, end, slot)
+    """Split rows with more than 2*chunk edges.  Returns (n_work, n_slots, row, beg, end, slot, split_first)
     as int32 device tensors, or None when no row needs splitting."""
     deg = rowptr[1:] - rowptr[:-1]
     if deg.numel() == 0 or int(deg.max()) <= 2 * chunk:
@@ -46,8 +46,9 @@ def _work_list(rowptr: torch.Tensor, chunk: int):
                       rowptr[work_row + 1].long())
     slot = torch.where(split, torch.cumsum(split.long(), 0) - 1, torch.full_like(k, -1))
     n_slots = int(split.sum())
+    split_first = torch.nonzero(split & (k == 0)).flatten()      # first work item of every split row
     i32 = lambda t: t.to(torch.int32).contiguous()
-    return work_row.numel(), n_slots, i32(work_row), i32(beg), i32(end), i32(slot)
+    return work_row.numel(), n_slots, i32(work_row), i32(beg), i32(end), i32(slot), i32(split_first)
 
 
 class Graph:
@@ -118,10 +119,12 @@ class Graph:
         g.t_rowptr, g.t_col, g.t_eperm = p(self.t_rowptr), p(self.t_col), p(self.t_eperm)
         if self.work is not None:
             g.n_work, g.n_slots = self.work[0], self.work[1]
-            g.work_row, g.work_beg, g.work_end, g.work_slot = (p(t) for t in self.work[2:])
+            g.work_row, g.work_beg, g.work_end, g.work_slot = (p(t) for t in self.work[2:6])
+            g.n_split, g.split_item = self.work[6].numel(), p(self.work[6])
         if self.t_work is not None:
             g.t_n_work, g.t_n_slots = self.t_work[0], self.t_work[1]
-            g.t_work_row, g.t_work_beg, g.t_work_end, g.t_work_slot = (p(t) for t in self.t_work[2:])
+            g.t_work_row, g.t_work_beg, g.t_work_end, g.t_work_slot = (p(t) for t in self.t_work[2:6])
+            g.t_n_split, g.t_split_item = self.t_work[6].numel(), p(self.t_work[6])
         return g
 
     @property

@@ -82,6 +82,11 @@ typedef struct dgcn_graph {
   const int32_t* t_work_beg;
   const int32_t* t_work_end;
   const int32_t* t_work_slot;
+  /* index (into the work list) of the FIRST item of every split row: one merge wave per entry */
+  int32_t n_split;
+  int32_t t_n_split;
+  const int32_t* split_item;   /* [n_split]   */
+  const int32_t* t_split_item; /* [t_n_split] */
 } dgcn_graph;
 
 int dgcn_version(void);

@@ -35,7 +35,8 @@ def test_sorted_input_needs_no_permutation():
 def test_work_list_splits_hubs_only():
     ei = synth.tricky_graph()
     g = Graph.from_edge_index(ei, 257, hub_chunk=256)
-    n_work, n_slots, row, beg, end, slot = g.work
+    n_work, n_slots, row, beg, end, slot, split_first = g.work
+    assert split_first.tolist() == [i for i in range(n_work) if int(slot[i]) >= 0 and (i == 0 or int(row[i - 1]) != int(row[i]))]
     deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
     covered = torch.zeros(257, dtype=torch.long)
     for i in range(n_work):
