@@ -63,7 +63,10 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-// Bitonic sort of R*64 u64 values held as v[r] per lane, element index e = r*64 + lane.
+// Bitonic sort of R*64 u64 values, BLOCKED layout: lane l holds elements e = l*R + r, r < R.
+// Compare-exchange partners at distance < R live in the same lane (pure register work); only distances
+// >= R cross lanes (one 64-bit shuffle with lane distance stride/R).  For R = 8 that is 21 shuffling stages
+// out of 45 instead of 39 with the striped layout.
 template <int R>
 __device__ __forceinline__ void bitonic_sort_wave(unsigned long long (&v)[R], int lane) {
   constexpr int TOTAL = R * kWave;
@@ -71,16 +74,12 @@ __device__ __forceinline__ void bitonic_sort_wave(unsigned long long (&v)[R], in
   for (int size = 2; size <= TOTAL; size <<= 1) {
 #pragma unroll
     for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-      if (stride >= kWave) {
-        // partner lives in another register of the same lane: r ^ (stride/64)
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int rs = stride / kWave;
+      if (stride < R) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int pr = r ^ rs;
+          const int pr = r ^ stride;
           if (pr > r) {
-            const int e = r * kWave + lane;
+            const int e = lane * R + r;
             const bool up = (e & size) == 0;  // ascending block
             const unsigned long long a = v[r], b = v[pr];
             const bool swap = up ? (a > b) : (a < b);
@@ -88,12 +87,13 @@ __device__ __forceinline__ void bitonic_sort_wave(unsigned long long (&v)[R], in
           }
         }
       } else {
+        const int lstride = stride / R;            // lane distance of the partner
+        const bool lower = (lane & lstride) == 0;  // this lane holds the lower-indexed element
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int e = r * kWave + lane;
-          const unsigned long long other = shfl_xor_u64(v[r], stride);
+          const int e = lane * R + r;
+          const unsigned long long other = shfl_xor_u64(v[r], lstride);
           const bool up = (e & size) == 0;
-          const bool lower = (lane & stride) == 0;  // this lane holds the lower-indexed element
           const unsigned long long mn = v[r] < other ? v[r] : other;
           const unsigned long long mx = v[r] < other ? other : v[r];
           v[r] = (up == lower) ? mn : mx;
@@ -110,14 +110,14 @@ __device__ __forceinline__ void sort_and_emit(const KnnParams& P, const uint32_t
   unsigned long long v[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int e = r * kWave + lane;
+    const int e = lane * R + r;
     v[r] = (e < K) ? ((static_cast<unsigned long long>(selkey[e]) << 32) | selidx[e]) : ~0ull;
   }
   bitonic_sort_wave<R>(v, lane);
   const int d = P.dilation;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int e = r * kWave + lane;
+    const int e = lane * R + r;
     if (e < K && (e % d) == 0) {
       const int pos = e / d;
       if (pos < P.Kout) {
