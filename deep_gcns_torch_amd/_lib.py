@@ -55,9 +55,10 @@ _SIGNATURES = {
         C.c_size_t, C.c_void_p]),
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_void_p]),
+    "dgcn_knn_dense_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "dgcn_knn_dense_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                     C.c_void_p]),
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_vertex_gemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_dense_edge_reduce_num_partials": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),

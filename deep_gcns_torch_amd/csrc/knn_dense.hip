@@ -32,6 +32,8 @@ struct KnnParams {
   const float* x;
   int64_t sb, sc, sn;  // strides in floats of (B, C, N)
   int B, C, N, K, dilation, Kout;
+  uint8_t* row_flag;   // [B*N] or null.  Filter kernel: writes 1 for rows it could not finish (exact kernel redoes
+                       // them), 0 otherwise.  Exact kernel: when non-null, only rows flagged 1 are processed.
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
@@ -296,6 +298,11 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   const int b = blockIdx.x / tiles_per_b;
   const int i0 = (blockIdx.x % tiles_per_b) * TM;
   const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
+  if (P.row_flag) {  // second pass after the filter kernel: skip tiles with nothing left to do (block-uniform)
+    bool any = false;
+    for (int r = 0; r < TM; ++r) any = any || (i0 + r < N && P.row_flag[static_cast<int64_t>(b) * N + i0 + r] != 0);
+    if (!any) return;
+  }
 
   // ---- phase 0: stage the TM query points, channel-major [c][r] ----
   for (int e = tid; e < C * TM; e += kKnnThreads) {
@@ -428,8 +435,241 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   for (int r = wave; r < TM; r += kKnnWaves) {
     const int i = i0 + r;
     if (i >= N) continue;  // wave-uniform
+    if (P.row_flag && P.row_flag[static_cast<int64_t>(b) * N + i] == 0) continue;
     select_row(P, dist + static_cast<size_t>(r) * Npad, selkey + static_cast<size_t>(r) * Kpad, b, i);
   }
+}
+
+
+// =======================================================================================
+// Candidate-filter kNN (N >= 1024, contiguous points): 16 query rows per workgroup.
+//
+// The exact kernel above is bound by L2->L1 traffic: every 8-row workgroup streams the sample's whole
+// feature block, and the 8 x N distance strip fills the LDS.  Here a per-row threshold tau_r is first
+// estimated from the distances to 256 SAMPLED candidates (rank chosen so that, with overwhelming
+// probability, between K and ~1000 of the N candidates fall below it); the full distance pass then keeps
+// only candidates with key <= tau_r, appended to a 1024-entry per-row list.  16 rows fit (128 KB), so the
+// feature block is streamed half as often, and the select runs on <= 16 candidates per lane without
+// touching the full row again.  Exactness does not depend on the sample: a row whose list holds fewer
+// than K or more than 1024 candidates is flagged and redone by the exact kernel (second launch, which
+// exits immediately for unflagged tiles).  Distances use the same fma chain and association as above.
+// =======================================================================================
+constexpr int kFTM = 16;
+constexpr int kFCap = 1024;
+constexpr int kFSamples = 256;
+
+template <int R>
+__device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* ckey, uint32_t* cidx, int cnt,
+                                                  int b, int i, int lane) {
+  const int K = P.K;
+  uint32_t ck[R], ci[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * kWave + lane;
+    ck[r] = (e < cnt) ? ckey[e] : 0xFFFFFFFFu;
+    ci[r] = (e < cnt) ? cidx[e] : 0xFFFFFFFFu;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // candidates live in registers before their LDS slots are reused
+  const uint32_t tau = kth_smallest<R>(ck, K);
+  const int need_eq = K - count_below<R>(ck, tau, false);
+  // candidates arrive in arbitrary order: among keys == tau take the need_eq LOWEST point ids
+  // (12-bit bisection on the id, ids are < 4096)
+  uint32_t tid_thr = 0;
+#pragma unroll 1
+  for (int bit = 11; bit >= 0; --bit) {
+    const uint32_t cand = tid_thr | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (ck[r] == tau && ci[r] < cand) ? 1 : 0;
+    if (wave_sum(c) < need_eq) tid_thr = cand;
+  }
+  int n_sel = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool take = (ck[r] < tau) || (ck[r] == tau && ci[r] <= tid_thr);
+    const unsigned long long m = __ballot(take);
+    if (take) {
+      const int pos = n_sel + __popcll(m & below);
+      ckey[pos] = ck[r];
+      cidx[pos] = ci[r];
+    }
+    n_sel += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t out_base = (static_cast<int64_t>(b) * P.N + i) * P.Kout;
+  if (K <= 64) sort_and_emit<1>(P, ckey, cidx, lane, K, out_base, i);
+  else if (K <= 128) sort_and_emit<2>(P, ckey, cidx, lane, K, out_base, i);
+  else if (K <= 256) sort_and_emit<4>(P, ckey, cidx, lane, K, out_base, i);
+  else sort_and_emit<8>(P, ckey, cidx, lane, K, out_base, i);
+}
+
+__global__ __launch_bounds__(kKnnThreads) void knn_filter_kernel(const KnnParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = kFTM;
+  const int C = P.C, N = P.N, K = P.K;
+  float* q = reinterpret_cast<float*>(smem);                        // [C][16]
+  float* sq = q + static_cast<size_t>(C) * TM;                      // [16]
+  uint32_t* tau = reinterpret_cast<uint32_t*>(sq + TM);             // [16]
+  int* cnt = reinterpret_cast<int*>(tau + TM);                      // [16]
+  uint32_t* ckey = reinterpret_cast<uint32_t*>(cnt + TM);           // [16][kFCap]
+  uint32_t* cidx = ckey + TM * kFCap;                               // [16][kFCap]
+  uint32_t* skeys = ckey;                                           // [16][256] sample keys (aliased, used first)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int tiles_per_b = (N + TM - 1) / TM;
+  const int b = blockIdx.x / tiles_per_b;
+  const int tile = blockIdx.x % tiles_per_b;
+  const int i0 = tile * TM;
+  const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
+
+  // ---- stage the 16 query points ----
+  for (int e = tid; e < C * TM; e += kKnnThreads) {
+    const int c = e / TM, r = e % TM;
+    q[e] = xb[static_cast<int64_t>(c) * P.sc + min(i0 + r, N - 1)];
+  }
+  __syncthreads();
+  if (tid < TM) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(q[c * TM + tid], q[c * TM + tid], s);
+    sq[tid] = s;
+    cnt[tid] = 0;
+  }
+  __syncthreads();
+
+  // ---- sample: 4 windows of 64 consecutive candidates, rotated per tile ----
+  {
+    const int s = tid % kFSamples;
+    const int rg = tid / kFSamples;                                  // rows rg*8 .. rg*8+7
+    const int quarter = N / 4;
+    const int j = ((s / 64) * quarter + (tile * 64) % quarter + (s % 64)) % N;
+    float acc[8], sj = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float xv = xb[static_cast<int64_t>(c) * P.sc + j];
+      sj = fmaf(xv, xv, sj);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = fmaf(q[c * TM + rg * 8 + r], xv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      skeys[(rg * 8 + r) * kFSamples + s] = key_of((sq[rg * 8 + r] + (-2.f * acc[r])) + sj);
+    }
+  }
+  __syncthreads();
+  for (int rr = wave; rr < TM; rr += kKnnWaves) {
+    uint32_t ks[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ks[u] = skeys[rr * kFSamples + u * kWave + lane];
+    const uint32_t t = kth_smallest<4>(ks, P.sample_rank);
+    if (lane == 0) tau[rr] = t;
+  }
+  __syncthreads();
+
+  // ---- full distance pass, keep only candidates with key <= tau_r ----
+  constexpr int JJ = 4;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int j0 = 0; j0 < N; j0 += kKnnThreads * JJ) {
+    const int cbase = j0 + tid * JJ;  // N % 4 == 0: a block of 4 columns is all-in or all-out
+    const bool in = cbase < N;
+    const float* xc = xb + (in ? cbase : 0);
+    float acc[JJ][TM], sj[JJ];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+      sj[jj] = 0.f;
+#pragma unroll
+      for (int r = 0; r < TM; ++r) acc[jj][r] = 0.f;
+    }
+    constexpr int CH = 4;
+    float4 nxt[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      nxt[u] = (u < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(u) * P.sc)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int c0 = 0; c0 < C; c0 += CH) {
+      float4 cur[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int c = c0 + CH + u;
+        nxt[u] = (c < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(c) * P.sc)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int c = min(c0 + u, C - 1);  // channels past C carry zeros: no contribution
+        const float xv[JJ] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+        float qv[TM];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) qv[r] = q[c * TM + r];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+          sj[jj] = fmaf(xv[jj], xv[jj], sj[jj]);
+#pragma unroll
+          for (int r = 0; r < TM; ++r) acc[jj][r] = fmaf(qv[r], xv[jj], acc[jj][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TM; ++r) {
+      const uint32_t tr = tau[r];
+      const int self = P.exclude_self ? i0 + r : -1;
+      uint32_t key[JJ];
+      bool hit[JJ];
+      unsigned long long m[JJ];
+      int tot = 0;
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) {
+        key[jj] = key_of((sq[r] + (-2.f * acc[jj][r])) + sj[jj]);
+        hit[jj] = in && key[jj] <= tr && (cbase + jj) != self;
+        m[jj] = __ballot(hit[jj]);
+        tot += __popcll(m[jj]);
+      }
+      if (tot) {  // wave-uniform: ONE LDS atomic per (wave, row, sweep) reserves the slots of all 4 columns
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cnt[r], tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+          const int pos = base + __popcll(m[jj] & below);
+          if (hit[jj] && pos < kFCap) {
+            ckey[r * kFCap + pos] = key[jj];
+            cidx[r * kFCap + pos] = static_cast<uint32_t>(cbase + jj);
+          }
+          base += __popcll(m[jj]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per-row select on the candidate lists ----
+  for (int rr = wave; rr < TM; rr += kKnnWaves) {
+    const int i = i0 + rr;
+    if (i >= N) continue;  // wave-uniform
+    const int c = cnt[rr];
+    const bool ok = c >= K && c <= kFCap;
+    if (lane == 0) P.row_flag[static_cast<int64_t>(b) * N + i] = ok ? 0 : 1;
+    if (!ok) continue;
+    uint32_t* ck = ckey + rr * kFCap;
+    uint32_t* ci = cidx + rr * kFCap;
+    if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
+    else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
+    else if (c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
+    else filter_select_row<16>(P, ck, ci, c, b, i, lane);
+  }
+}
+
+size_t knn_filter_lds_bytes(int C) {
+  return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + static_cast<size_t>(kFTM) * kFCap * 8;
 }
 
 size_t knn_lds_bytes(int TM, int C, int Npad, int Kpad) {
@@ -444,9 +684,15 @@ using namespace dgcn;
 // x: (B, C, N) fp32 with element strides (sb, sc, sn).  K = k*dilation neighbours are selected per
 // point (self included, ascending distance); positions 0, d, 2d, ... are written, Kout = ceil(K/d).
 // nn_out / ctr_out: [B, N, Kout] int64 contiguous (ctr_out may be NULL).
+extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (static_cast<size_t>(B) * static_cast<size_t>(N) + 15u) / 16u * 16u;  // one flag byte per query row
+}
+
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
                                   int32_t C, int32_t N, int32_t K, int32_t dilation, int32_t exclude_self,
-                                  int64_t* nn_out, int64_t* ctr_out, void* stream) {
+                                  int64_t* nn_out, int64_t* ctr_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   if (!x || !nn_out) return DGCN_E_NULL;
   if (B < 0 || C <= 0 || N <= 0 || K <= 0 || dilation <= 0) return DGCN_E_SHAPE;
   if (K > N - (exclude_self ? 1 : 0) || K > 512) return DGCN_E_SHAPE;             // sorted winners: 8 u64 per lane
@@ -466,12 +712,21 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.B = B; P.C = C; P.N = N; P.K = K; P.dilation = dilation;
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
+  P.row_flag = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
   P.sample_rank = 0;
   if (N >= 1024) {
-    const double ns = 4.0 * kWave, f = static_cast<double>(K) / N;
-    const int r = static_cast<int>(ceil(ns * f + 3.0 * sqrt(ns * f * (1.0 - f)) + 2.0));
-    if (r <= 160) P.sample_rank = r;   // beyond that the candidate set is no smaller than the row
+    // Sample rank: the number of candidates below the r-th of 256 sample keys has mean r*N/256 and standard
+    // deviation ~ sqrt(r)*N/256.  Aim 3.2 sigma above K, but no higher than the middle of [K, 1024] so that
+    // both "too few" and "too many" (list capacity) stay rare; either way the exact path catches the row.
+    const double ns = 4.0 * kWave, unit = N / ns;
+    const double r0 = K / unit;
+    const double sd0 = unit * sqrt(r0 > 1.0 ? r0 : 1.0);
+    double target = K + 3.2 * sd0 + 2.0 * unit;
+    const double mid = 0.5 * (K + 16.0 * kWave);
+    if (target > mid) target = mid;
+    const int r = static_cast<int>(ceil(target / unit));
+    if (r >= 1 && r <= 200) P.sample_rank = r;
   }
   const int tiles = (N + TM - 1) / TM;
   const dim3 grid(static_cast<unsigned>(B) * tiles), block(kKnnThreads);
@@ -479,6 +734,17 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   hipError_t e = hipSuccess;
   const bool vec4 = (sn == 1) && (N % 4 == 0) && (sc % 4 == 0) && (sb % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+  // Candidate-filter fast path: 16 rows per workgroup; rows it cannot finish are redone below.
+  if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N) &&
+      knn_filter_lds_bytes(C) <= static_cast<size_t>(kLdsBudget)) {
+    P.row_flag = static_cast<uint8_t*>(workspace);
+    const size_t flds = knn_filter_lds_bytes(C);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    const int ftiles = (N + kFTM - 1) / kFTM;
+    hipLaunchKernelGGL(knn_filter_kernel, dim3(static_cast<unsigned>(B) * ftiles), block, flds, s, P);
+  }
 #define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \
   do {                                                                                                      \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<TMV, V4>),                       \

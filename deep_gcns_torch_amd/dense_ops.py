@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fallback inside the library)
 
 
 # ----------------------------------------------------------------------------------------
@@ -25,10 +26,12 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
     lib = _lib.load()
     dev = _lib.require_device(x3)
     B, C, N = x3.shape
+    ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N) if (N >= 1024 and USE_KNN_FILTER) else 0
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     with torch.cuda.device(dev):
         rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,
                                     dilation, 1 if exclude_self else 0, nn_out.data_ptr(), _lib.ptr(ctr_out),
-                                    _lib.current_stream_handle(dev))
+                                    _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_knn_dense_f32")
 
 

@@ -174,10 +174,14 @@ int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshif
  *   ctr_out  same shape or NULL: the centre point id (edge_index[1])
  *   exclude_self != 0: the query point itself is never returned (torch_cluster.knn_graph(loop=False),
  *            gcn_lib/dense/torch_edge.py:97, gcn_lib/sparse/torch_edge.py:46); then K <= N-1
+ *   workspace (optional, dgcn_knn_dense_workspace_bytes): enables the candidate-filter fast path for N >= 1024
+ *            (16 rows per workgroup, per-row sampled threshold, exact fallback for the rows it flags);
+ *            without it every row takes the exact full-row path.  Results are identical either way.
  * Limits: N <= 4096, K <= 512, K <= N. */
+size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N);
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
                        int32_t N, int32_t K, int32_t dilation, int32_t exclude_self, int64_t* nn_out,
-                       int64_t* ctr_out, void* stream);
+                       int64_t* ctr_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Per-vertex GEMM on fp32 MFMA: out[(b*N+n)*M + m] = sum_c x[b,c,n] * W[c*M+m] + bias[m].
  * With W = [(W1-W2)^T | W2^T] this yields P and Q of the EdgeConv split
