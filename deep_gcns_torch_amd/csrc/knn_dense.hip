@@ -455,7 +455,6 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 // exits immediately for unflagged tiles).  Distances use the same fma chain and association as above.
 // =======================================================================================
 constexpr int kFTM = 16;
-constexpr int kFCap = 1024;
 constexpr int kFSamples = 256;
 
 template <int R>
@@ -506,7 +505,10 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
   else sort_and_emit<8>(P, ckey, cidx, lane, K, out_base, i);
 }
 
-__global__ __launch_bounds__(kKnnThreads) void knn_filter_kernel(const KnnParams P) {
+// CAP = per-row candidate list capacity: 512 (64 KB of lists -> two workgroups per CU, their phases overlap)
+// when K leaves enough room below it, else 1024.
+template <int kFCap>
+__global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filter_kernel(const KnnParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kFTM;
   const int C = P.C, N = P.N, K = P.K;
@@ -550,12 +552,20 @@ __global__ __launch_bounds__(kKnnThreads) void knn_filter_kernel(const KnnParams
     float acc[8], sj = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-      const float xv = xb[static_cast<int64_t>(c) * P.sc + j];
-      sj = fmaf(xv, xv, sj);
+    constexpr int SCH = 16;  // 16 channel loads in flight per thread: this stage is pure latency
+    for (int c0 = 0; c0 < C; c0 += SCH) {
+      float xv[SCH];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] = fmaf(q[c * TM + rg * 8 + r], xv, acc[r]);
+      for (int u = 0; u < SCH; ++u) {
+        xv[u] = (c0 + u < C) ? xb[static_cast<int64_t>(c0 + u) * P.sc + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SCH; ++u) {
+        const int c = min(c0 + u, C - 1);
+        sj = fmaf(xv[u], xv[u], sj);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = fmaf(q[c * TM + rg * 8 + r], xv[u], acc[r]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -663,13 +673,28 @@ __global__ __launch_bounds__(kKnnThreads) void knn_filter_kernel(const KnnParams
     uint32_t* ci = cidx + rr * kFCap;
     if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
     else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
-    else if (c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
+    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
     else filter_select_row<16>(P, ck, ci, c, b, i, lane);
   }
 }
 
-size_t knn_filter_lds_bytes(int C) {
-  return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + static_cast<size_t>(kFTM) * kFCap * 8;
+size_t knn_filter_lds_bytes(int C, int cap) {
+  size_t lists = static_cast<size_t>(kFTM) * cap * 8;
+  const size_t samples = static_cast<size_t>(kFTM) * kFSamples * 4;   // aliased with the lists
+  if (lists < samples) lists = samples;
+  return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + lists;
+}
+
+// rank of the 256-sample threshold for a list capacity `cap` (see the comment at the call site)
+int knn_sample_rank(int N, int K, int cap) {
+  const double ns = kFSamples, unit = N / ns;
+  const double r0 = K / unit;
+  const double sd0 = unit * sqrt(r0 > 1.0 ? r0 : 1.0);
+  double target = K + 3.2 * sd0 + 2.0 * unit;
+  const double mid = 0.5 * (K + static_cast<double>(cap));
+  if (target > mid) target = mid;
+  const int r = static_cast<int>(ceil(target / unit));
+  return (r >= 1 && r <= 200) ? r : 0;
 }
 
 size_t knn_lds_bytes(int TM, int C, int Npad, int Kpad) {
@@ -719,14 +744,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     // Sample rank: the number of candidates below the r-th of 256 sample keys has mean r*N/256 and standard
     // deviation ~ sqrt(r)*N/256.  Aim 3.2 sigma above K, but no higher than the middle of [K, 1024] so that
     // both "too few" and "too many" (list capacity) stay rare; either way the exact path catches the row.
-    const double ns = 4.0 * kWave, unit = N / ns;
-    const double r0 = K / unit;
-    const double sd0 = unit * sqrt(r0 > 1.0 ? r0 : 1.0);
-    double target = K + 3.2 * sd0 + 2.0 * unit;
-    const double mid = 0.5 * (K + 16.0 * kWave);
-    if (target > mid) target = mid;
-    const int r = static_cast<int>(ceil(target / unit));
-    if (r >= 1 && r <= 200) P.sample_rank = r;
+    P.sample_rank = knn_sample_rank(N, K, 16 * kWave);
   }
   const int tiles = (N + TM - 1) / TM;
   const dim3 grid(static_cast<unsigned>(B) * tiles), block(kKnnThreads);
@@ -735,15 +753,31 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   const bool vec4 = (sn == 1) && (N % 4 == 0) && (sc % 4 == 0) && (sb % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
   // Candidate-filter fast path: 16 rows per workgroup; rows it cannot finish are redone below.
+  // small lists (two workgroups per CU) when the 3.2-sigma target fits under 512 with margin
+  const bool small_lists = K + 3.2 * (N / 256.0) * sqrt(K / (N / 256.0) > 1.0 ? K / (N / 256.0) : 1.0) + 2.0 * (N / 256.0) + 96 <= 512;
+  const int cap = small_lists ? 512 : 1024;
   if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N) &&
-      knn_filter_lds_bytes(C) <= static_cast<size_t>(kLdsBudget)) {
-    P.row_flag = static_cast<uint8_t*>(workspace);
-    const size_t flds = knn_filter_lds_bytes(C);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
-    if (e != hipSuccess) return static_cast<int>(e);
+      knn_filter_lds_bytes(C, cap) <= static_cast<size_t>(kLdsBudget)) {
+    KnnParams F = P;
+    F.row_flag = static_cast<uint8_t*>(workspace);
+    F.sample_rank = knn_sample_rank(N, K, cap);
+    const size_t flds = knn_filter_lds_bytes(C, cap);
     const int ftiles = (N + kFTM - 1) / kFTM;
-    hipLaunchKernelGGL(knn_filter_kernel, dim3(static_cast<unsigned>(B) * ftiles), block, flds, s, P);
+    const dim3 fgrid(static_cast<unsigned>(B) * ftiles);
+    if (F.sample_rank > 0) {
+      if (cap == 512) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<512>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
+        if (e != hipSuccess) return static_cast<int>(e);
+        hipLaunchKernelGGL(knn_filter_kernel<512>, fgrid, block, flds, s, F);
+      } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<1024>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
+        if (e != hipSuccess) return static_cast<int>(e);
+        hipLaunchKernelGGL(knn_filter_kernel<1024>, fgrid, block, flds, s, F);
+      }
+      P.row_flag = F.row_flag;   // the exact pass below only redoes the rows the filter pass flagged
+    }
   }
 #define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \
   do {                                                                                                      \
