@@ -34,6 +34,7 @@ struct KnnParams {
   int B, C, N, K, dilation, Kout;
   uint8_t* row_flag;   // [B*N] or null.  Filter kernel: writes 1 for rows it could not finish (exact kernel redoes
                        // them), 0 otherwise.  Exact kernel: when non-null, only rows flagged 1 are processed.
+  const float* sqnorm; // [B*N] |x_j|^2 (fma chain over channels), written by knn_sqnorm_kernel for the filter pass
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
@@ -457,6 +458,21 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 constexpr int kFTM = 16;
 constexpr int kFSamples = 256;
 
+// |x_j|^2 of every point as the channel-ordered fma chain used everywhere else in this file.
+__global__ __launch_bounds__(kWgThreads) void knn_sqnorm_kernel(const KnnParams P, float* __restrict__ out) {
+  const int64_t total = static_cast<int64_t>(P.B) * P.N;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = static_cast<int>(idx / P.N), j = static_cast<int>(idx % P.N);
+  const float* xp = P.x + static_cast<int64_t>(b) * P.sb + static_cast<int64_t>(j) * P.sn;
+  float s = 0.f;
+  for (int c = 0; c < P.C; ++c) {
+    const float v = xp[static_cast<int64_t>(c) * P.sc];
+    s = fmaf(v, v, s);
+  }
+  out[idx] = s;
+}
+
 template <int R>
 __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* ckey, uint32_t* cidx, int cnt,
                                                   int b, int i, int lane) {
@@ -582,84 +598,83 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
   }
   __syncthreads();
 
-  // ---- full distance pass, keep only candidates with key <= tau_r ----
-  constexpr int JJ = 4;
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 1
+  return;
+#endif
+  // ---- full distance pass on the matrix cores, keep only candidates with key <= tau_r ----
+  // v_mfma_f32_16x16x4_f32: D(16 rows x 16 cols) += A(16 x 4 ch) * B(4 ch x 16 cols), an exact k-ordered f32
+  // fma chain (bitwise the VALU fmaf chain of the exact kernel).  A = the 16 staged query rows, kept in
+  // registers for a 64-channel chunk; B = candidate features straight from memory: lane l loads the float4
+  // of channel 4*ks + (l>>4), columns col0 + 4*(l&15) .. +3, and component t feeds column tile t, i.e. MFMA
+  // column (l&15) of tile t is point col0 + 4*(l&15) + t.  One wave owns 64 consecutive candidates.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, lk = lane >> 4;
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int j0 = 0; j0 < N; j0 += kKnnThreads * JJ) {
-    const int cbase = j0 + tid * JJ;  // N % 4 == 0: a block of 4 columns is all-in or all-out
-    const bool in = cbase < N;
-    const float* xc = xb + (in ? cbase : 0);
-    float acc[JJ][TM], sj[JJ];
+  const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
+  constexpr int KS = 8;   // k-steps (of 4 channels) per register-resident chunk: 8 float4 loads in flight per lane
+  for (int col0 = wave * 64; col0 < N; col0 += kKnnWaves * 64) {
+    const int cbase = col0 + 4 * li;
+    const bool in = cbase < N;  // N % 4 == 0
+    f32x4 acc[4];
 #pragma unroll
-    for (int jj = 0; jj < JJ; ++jj) {
-      sj[jj] = 0.f;
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < C; cc += 4 * KS) {
+      float a[KS];
+      float4 bx[KS];
 #pragma unroll
-      for (int r = 0; r < TM; ++r) acc[jj][r] = 0.f;
-    }
-    constexpr int CH = 4;
-    float4 nxt[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      nxt[u] = (u < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(u) * P.sc)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int c0 = 0; c0 < C; c0 += CH) {
-      float4 cur[CH];
-#pragma unroll
-      for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
-#pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int c = c0 + CH + u;
-        nxt[u] = (c < C) ? *reinterpret_cast<const float4*>(xc + static_cast<int64_t>(c) * P.sc)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = cc + 4 * ks + lk;
+        a[ks] = (c < C) ? q[c * TM + li] : 0.f;
+        bx[ks] = (c < C && in) ? *reinterpret_cast<const float4*>(xb + static_cast<int64_t>(c) * P.sc + cbase)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int c = min(c0 + u, C - 1);  // channels past C carry zeros: no contribution
-        const float xv[JJ] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-        float qv[TM];
-#pragma unroll
-        for (int r = 0; r < TM; ++r) qv[r] = q[c * TM + r];
-#pragma unroll
-        for (int jj = 0; jj < JJ; ++jj) {
-          sj[jj] = fmaf(xv[jj], xv[jj], sj[jj]);
-#pragma unroll
-          for (int r = 0; r < TM; ++r) acc[jj][r] = fmaf(qv[r], xv[jj], acc[jj][r]);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].w, acc[3], 0, 0, 0);
       }
     }
+    // acc[t][reg] = <x_row, x_col> for row = lk*4 + reg, col = cbase + t
+    float sj[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in) load_vec<4>(sj, sqn + cbase);
 #pragma unroll
-    for (int r = 0; r < TM; ++r) {
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
       const uint32_t tr = tau[r];
       const int self = P.exclude_self ? i0 + r : -1;
-      uint32_t key[JJ];
-      bool hit[JJ];
-      unsigned long long m[JJ];
+      uint32_t key[4];
+      bool hit[4];
+      unsigned long long m[4];
+      const unsigned long long grp = 0xFFFFull << (16 * lk);  // this row's lanes
       int tot = 0;
 #pragma unroll
-      for (int jj = 0; jj < JJ; ++jj) {
-        key[jj] = key_of((sq[r] + (-2.f * acc[jj][r])) + sj[jj]);
-        hit[jj] = in && key[jj] <= tr && (cbase + jj) != self;
-        m[jj] = __ballot(hit[jj]);
-        tot += __popcll(m[jj]);
+      for (int t = 0; t < 4; ++t) {
+        key[t] = key_of((sq[r] + (-2.f * acc[t][reg])) + sj[t]);
+        hit[t] = in && key[t] <= tr && (cbase + t) != self;
+        m[t] = __ballot(hit[t]) & grp;
+        tot += __popcll(m[t]);
       }
-      if (tot) {  // wave-uniform: ONE LDS atomic per (wave, row, sweep) reserves the slots of all 4 columns
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&cnt[r], tot);
-        base = __builtin_amdgcn_readfirstlane(base);
+      // one LDS atomic per (row, wave, reg): the group leader reserves the slots of its row
+      int base = 0;
+      if (li == 0 && tot) base = atomicAdd(&cnt[r], tot);
+      base = __shfl(base, lk * 16);
 #pragma unroll
-        for (int jj = 0; jj < JJ; ++jj) {
-          const int pos = base + __popcll(m[jj] & below);
-          if (hit[jj] && pos < kFCap) {
-            ckey[r * kFCap + pos] = key[jj];
-            cidx[r * kFCap + pos] = static_cast<uint32_t>(cbase + jj);
-          }
-          base += __popcll(m[jj]);
+      for (int t = 0; t < 4; ++t) {
+        const int pos = base + __popcll(m[t] & below);
+        if (hit[t] && pos < kFCap) {
+          ckey[r * kFCap + pos] = key[t];
+          cidx[r * kFCap + pos] = static_cast<uint32_t>(cbase + t);
         }
+        base += __popcll(m[t]);
       }
     }
   }
   __syncthreads();
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 2
+  return;
+#endif
 
   // ---- per-row select on the candidate lists ----
   for (int rr = wave; rr < TM; rr += kKnnWaves) {
@@ -711,7 +726,8 @@ using namespace dgcn;
 // nn_out / ctr_out: [B, N, Kout] int64 contiguous (ctr_out may be NULL).
 extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N) {
   if (B <= 0 || N <= 0) return 0;
-  return (static_cast<size_t>(B) * static_cast<size_t>(N) + 15u) / 16u * 16u;  // one flag byte per query row
+  // |x_j|^2 per point (fp32) followed by one flag byte per query row
+  return static_cast<size_t>(B) * static_cast<size_t>(N) * 4u + (static_cast<size_t>(B) * static_cast<size_t>(N) + 15u) / 16u * 16u;
 }
 
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
@@ -719,6 +735,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
                                   int64_t* nn_out, int64_t* ctr_out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   if (!x || !nn_out) return DGCN_E_NULL;
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return DGCN_E_ALIGN;
   if (B < 0 || C <= 0 || N <= 0 || K <= 0 || dilation <= 0) return DGCN_E_SHAPE;
   if (K > N - (exclude_self ? 1 : 0) || K > 512) return DGCN_E_SHAPE;             // sorted winners: 8 u64 per lane
   if (N > kMaxPerLane * kWave) return DGCN_E_SHAPE;      // 64 keys per lane in the select phase: N <= 4096
@@ -738,6 +755,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
   P.row_flag = nullptr;
+  P.sqnorm = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
   P.sample_rank = 0;
   if (N >= 1024) {
@@ -759,12 +777,17 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N) &&
       knn_filter_lds_bytes(C, cap) <= static_cast<size_t>(kLdsBudget)) {
     KnnParams F = P;
-    F.row_flag = static_cast<uint8_t*>(workspace);
+    float* sqbuf = static_cast<float*>(workspace);
+    F.sqnorm = sqbuf;
+    F.row_flag = reinterpret_cast<uint8_t*>(sqbuf + static_cast<size_t>(B) * N);
     F.sample_rank = knn_sample_rank(N, K, cap);
     const size_t flds = knn_filter_lds_bytes(C, cap);
     const int ftiles = (N + kFTM - 1) / kFTM;
     const dim3 fgrid(static_cast<unsigned>(B) * ftiles);
     if (F.sample_rank > 0) {
+      const int64_t pts = static_cast<int64_t>(B) * N;
+      hipLaunchKernelGGL(knn_sqnorm_kernel, dim3(static_cast<unsigned>((pts + kWgThreads - 1) / kWgThreads)),
+                         dim3(kWgThreads), 0, s, P, sqbuf);
       if (cap == 512) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<512>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
