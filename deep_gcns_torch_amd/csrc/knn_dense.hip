@@ -457,6 +457,8 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 // =======================================================================================
 constexpr int kFTM = 16;
 constexpr int kFSamples = 256;
+constexpr int kFThreads = 1024;   // 16 waves: one per query row in the select phase, 4 per SIMD to hide latency
+constexpr int kFWaves = kFThreads / kWave;
 
 // |x_j|^2 of every point as the channel-ordered fma chain used everywhere else in this file.
 __global__ __launch_bounds__(kWgThreads) void knn_sqnorm_kernel(const KnnParams P, float* __restrict__ out) {
@@ -524,7 +526,7 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
 // CAP = per-row candidate list capacity: 512 (64 KB of lists -> two workgroups per CU, their phases overlap)
 // when K leaves enough room below it, else 1024.
 template <int kFCap>
-__global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filter_kernel(const KnnParams P) {
+__global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kFTM;
   const int C = P.C, N = P.N, K = P.K;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
   const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
 
   // ---- stage the 16 query points ----
-  for (int e = tid; e < C * TM; e += kKnnThreads) {
+  for (int e = tid; e < C * TM; e += kFThreads) {
     const int c = e / TM, r = e % TM;
     q[e] = xb[static_cast<int64_t>(c) * P.sc + min(i0 + r, N - 1)];
   }
@@ -561,13 +563,14 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
 
   // ---- sample: 4 windows of 64 consecutive candidates, rotated per tile ----
   {
+    constexpr int RPT = TM * kFSamples / kFThreads;                  // rows per thread (4)
     const int s = tid % kFSamples;
-    const int rg = tid / kFSamples;                                  // rows rg*8 .. rg*8+7
+    const int rg = tid / kFSamples;                                  // rows rg*RPT .. rg*RPT+RPT-1
     const int quarter = N / 4;
     const int j = ((s / 64) * quarter + (tile * 64) % quarter + (s % 64)) % N;
-    float acc[8], sj = 0.f;
+    float acc[RPT], sj = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
     constexpr int SCH = 16;  // 16 channel loads in flight per thread: this stage is pure latency
     for (int c0 = 0; c0 < C; c0 += SCH) {
       float xv[SCH];
@@ -580,16 +583,16 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
         const int c = min(c0 + u, C - 1);
         sj = fmaf(xv[u], xv[u], sj);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = fmaf(q[c * TM + rg * 8 + r], xv[u], acc[r]);
+        for (int r = 0; r < RPT; ++r) acc[r] = fmaf(q[c * TM + rg * RPT + r], xv[u], acc[r]);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      skeys[(rg * 8 + r) * kFSamples + s] = key_of((sq[rg * 8 + r] + (-2.f * acc[r])) + sj);
+    for (int r = 0; r < RPT; ++r) {
+      skeys[(rg * RPT + r) * kFSamples + s] = key_of((sq[rg * RPT + r] + (-2.f * acc[r])) + sj);
     }
   }
   __syncthreads();
-  for (int rr = wave; rr < TM; rr += kKnnWaves) {
+  for (int rr = wave; rr < TM; rr += kFWaves) {
     uint32_t ks[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ks[u] = skeys[rr * kFSamples + u * kWave + lane];
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
   const unsigned long long below = (1ull << lane) - 1ull;
   const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
   constexpr int KS = 8;   // k-steps (of 4 channels) per register-resident chunk: 8 float4 loads in flight per lane
-  for (int col0 = wave * 64; col0 < N; col0 += kKnnWaves * 64) {
+  for (int col0 = wave * 64; col0 < N; col0 += kFWaves * 64) {
     const int cbase = col0 + 4 * li;
     const bool in = cbase < N;  // N % 4 == 0
     f32x4 acc[4];
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(kKnnThreads, (kFCap == 512 ? 4 : 2)) void knn_filte
 #endif
 
   // ---- per-row select on the candidate lists ----
-  for (int rr = wave; rr < TM; rr += kKnnWaves) {
+  for (int rr = wave; rr < TM; rr += kFWaves) {
     const int i = i0 + rr;
     if (i >= N) continue;  // wave-uniform
     const int c = cnt[rr];
@@ -792,12 +795,12 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<512>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
         if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(knn_filter_kernel<512>, fgrid, block, flds, s, F);
+        hipLaunchKernelGGL(knn_filter_kernel<512>, fgrid, dim3(kFThreads), flds, s, F);
       } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<1024>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
         if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(knn_filter_kernel<1024>, fgrid, block, flds, s, F);
+        hipLaunchKernelGGL(knn_filter_kernel<1024>, fgrid, dim3(kFThreads), flds, s, F);
       }
       P.row_flag = F.row_flag;   // the exact pass below only redoes the rows the filter pass flagged
     }
