@@ -118,13 +118,103 @@ def all_gather_rows(x_local: torch.Tensor, part: PartitionedGraph, group=None) -
     return _AllGatherRows.apply(x_local, part.max_rows, group)
 
 
+def _channel_chunks(C: int, nchunk: int):
+    """Contiguous channel blocks (multiples of 4 channels so rows stay 16-byte aligned)."""
+    nchunk = max(1, min(nchunk, C // 4 if C >= 4 else 1))
+    base = (C // nchunk) // 4 * 4
+    if base == 0:
+        return [(0, C)]
+    cuts, lo = [], 0
+    for i in range(nchunk):
+        hi = C if i == nchunk - 1 else lo + base
+        cuts.append((lo, hi))
+        lo = hi
+    return cuts
+
+
+class _PipelinedPartitionedAggregate(torch.autograd.Function):
+    """Channel-pipelined form of ``local_aggregate(all_gather(x_local), graph)``.
+
+    Every aggregator works per channel, so the layer splits exactly into independent channel blocks.  All
+    block all-gathers are enqueued up front on the collective's stream; the compute stream waits only for
+    block i before aggregating it, so the exchange of block i+1 overlaps the kernel of block i.  The backward
+    mirrors it: the reduce-scatter of block i is left in flight while block i+1's gradient kernel runs, and
+    everything is awaited once at the end.  (With the stock "wait after every collective" form the two never
+    overlap.)"""
+
+    @staticmethod
+    def forward(ctx, x_local, part, group, local_aggregate, aggr, kw, nchunk):
+        world = dist.get_world_size(group)
+        n_local, C = x_local.shape
+        mr = part.max_rows
+        cuts = _channel_chunks(C, nchunk)
+        tensor_coll = _supports_tensor_collectives(group)
+        fulls, works = [], []
+        for lo, hi in cuts:
+            send = x_local.new_zeros(mr, hi - lo)
+            send[:n_local] = x_local[:, lo:hi]
+            full = x_local.new_empty(world * mr, hi - lo)
+            if tensor_coll:
+                w = dist.all_gather_into_tensor(full, send, group=group, async_op=True)
+            else:
+                w = dist.all_gather(list(full.view(world, mr, hi - lo).unbind(0)), send, group=group, async_op=True)
+            fulls.append(full)
+            works.append(w)
+        outs, leaves = [], []
+        for full, w in zip(fulls, works):
+            w.wait()                                     # stream-level wait for THIS block only
+            with torch.enable_grad():
+                leaf = full.detach().requires_grad_(x_local.requires_grad)
+                out = local_aggregate(leaf, part.graph, aggr=aggr, **kw)
+            leaves.append(leaf)
+            outs.append(out)
+        ctx.part, ctx.group, ctx.cuts, ctx.tensor_coll = part, group, cuts, tensor_coll
+        ctx.n_local = n_local
+        ctx.leaves, ctx.outs = leaves, outs              # nested graphs of the per-block aggregations
+        return torch.cat([o.detach() for o in outs], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        part, group = ctx.part, ctx.group
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        mr = part.max_rows
+        pieces, works, tmps = [], [], []
+        for (lo, hi), leaf, out in zip(ctx.cuts, ctx.leaves, ctx.outs):
+            if out.requires_grad:
+                gfull, = torch.autograd.grad(out, leaf, g[:, lo:hi].contiguous())
+                gfull = gfull.contiguous()
+            else:                                         # a rank without local edges contributes nothing
+                gfull = torch.zeros_like(leaf)
+            if ctx.tensor_coll:
+                dst = gfull.new_empty(mr, hi - lo)
+                works.append(dist.reduce_scatter_tensor(dst, gfull, op=dist.ReduceOp.SUM, group=group, async_op=True))
+                pieces.append(dst)
+            else:
+                tmp = gfull.clone()
+                works.append(dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=True))
+                pieces.append(tmp.view(world, mr, hi - lo)[rank])
+            tmps.append(gfull)                            # keep alive until the collective has consumed it
+        for w in works:
+            w.wait()
+        ctx.leaves = ctx.outs = None
+        grad = torch.cat([p[:ctx.n_local] for p in pieces], dim=1)
+        return grad, None, None, None, None, None, None
+
+
 def partitioned_gen_aggregate(x_local: torch.Tensor, part: PartitionedGraph, aggr: str = "softmax", group=None,
-                              local_aggregate=None, **kw) -> torch.Tensor:
+                              local_aggregate=None, pipeline_chunks: int = 4, **kw) -> torch.Tensor:
     """Aggregation of this rank's destination rows; ``x_local`` = this rank's feature rows.
-    ``local_aggregate(x_full, graph, aggr=..., **kw)`` defaults to the HIP op; the CPU/gloo tests
-    inject the oracle there to exercise partitioning + collectives without a GPU."""
+
+    ``pipeline_chunks`` > 1 splits the channels into that many blocks and overlaps the exchange of one block
+    with the aggregation of the previous one (see ``_PipelinedPartitionedAggregate``); 1 gives the plain
+    all-gather -> aggregate composition.  ``local_aggregate(x_full, graph, aggr=..., **kw)`` defaults to the HIP
+    op; the CPU/gloo tests inject the oracle there to exercise partitioning + collectives without a GPU."""
     if local_aggregate is None:
         from . import ops
         local_aggregate = ops.gen_aggregate
+    C = x_local.size(1)
+    if pipeline_chunks > 1 and dist.get_world_size(group) > 1 and C >= 8 and C % 4 == 0:
+        return _PipelinedPartitionedAggregate.apply(x_local, part, group, local_aggregate, aggr, kw, pipeline_chunks)
     x_full = all_gather_rows(x_local, part, group)
     return local_aggregate(x_full, part.graph, aggr=aggr, **kw)

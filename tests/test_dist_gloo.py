@@ -29,7 +29,7 @@ def _oracle_local(x_full, graph, aggr="softmax", **kw):
     return sparse_ref.gen_propagate(x_full, ei, aggr=aggr, dim_size=graph.n_dst, **kw)
 
 
-def _worker(rank, world, port, aggr, kw, q):
+def _worker(rank, world, port, aggr, kw, q, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,7 +42,7 @@ def _worker(rank, world, port, aggr, kw, q):
         probe = torch.randn(n, C, generator=g, dtype=torch.float64)
         part = PartitionedGraph.from_edge_index(ei, n, rank, world)
         xl = x[part.lo:part.hi].clone().requires_grad_(True)
-        out = partitioned_gen_aggregate(xl, part, aggr=aggr, local_aggregate=_oracle_local, **kw)
+        out = partitioned_gen_aggregate(xl, part, aggr=aggr, local_aggregate=_oracle_local, pipeline_chunks=chunks, **kw)
         (out * probe[part.lo:part.hi]).sum().backward()
         q.put((rank, part.bounds, out.detach(), xl.grad.detach(), part.n_local_edges))
     finally:
@@ -50,14 +50,15 @@ def _worker(rank, world, port, aggr, kw, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("aggr,kw", [("softmax", dict(t=0.7)), ("power", dict(p=2.0)), ("mean", {})])
-def test_partitioned_aggregate_world2_matches_single_process(aggr, kw):
+@pytest.mark.parametrize("aggr,kw,chunks", [("softmax", dict(t=0.7), 1), ("power", dict(p=2.0), 1), ("mean", {}, 1),
+                                            ("softmax", dict(t=0.7), 4), ("max", {}, 3)])
+def test_partitioned_aggregate_world2_matches_single_process(aggr, kw, chunks):
     from oracle import sparse_ref
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, aggr, kw, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, aggr, kw, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
