@@ -37,6 +37,13 @@ def test_partitioned_aggregate_on_rccl_single_rank():
             (ref * probe).sum().backward()
             torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-7)
             torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
+            # channel-pipelined form (async block collectives on RCCL, HIP kernel per 16-channel block)
+            from deep_gcns_torch_amd.dist import _PipelinedPartitionedAggregate
+            xc = x.clone().requires_grad_(True)
+            outp = _PipelinedPartitionedAggregate.apply(xc, part, None, ops.gen_aggregate, aggr, kw, 4)
+            (outp * probe).sum().backward()
+            torch.testing.assert_close(outp, ref, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(xc.grad, xb.grad, rtol=1e-5, atol=1e-6)
     finally:
         if created:
             dist.destroy_process_group()
