@@ -24,6 +24,7 @@
 namespace dgcn {
 namespace {
 
+constexpr float kShiftSafe = 80.f;  // |L| below this keeps exp(-L) and exp(t*m) inside the fp32 range
 constexpr float kPowLo = 1e-7f;  // torch_message.py:69
 constexpr float kPowHi = 1e1f;
 
@@ -54,6 +55,7 @@ struct FwdParams {
   float* out;
   void* aux1;
   float* aux2;
+  int32_t* range_flag;  // softmax: set to 1 when some |L_i| >= kShiftSafe (the backward then gathers two rows)
   float* ws;  // partial slots: [slot][4][C]
 };
 
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
               res[j] = st.c[j] * inv;
               x1[j] = any ? st.a[j] + fast_log(st.b[j]) : 0.f;
               x2[j] = st.d[j] * inv;
+              if (P.range_flag && !(fabsf(x1[j]) < kShiftSafe)) atomicOr(P.range_flag, 1);  // rare
             } else if constexpr (MODE == DGCN_AGGR_POWER) {
               const float q = st.b[j] / fmaxf(deg, 1.f);
               const float r = fminf(fmaxf(q, kPowLo), kPowHi);
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
       res = st.c[0] * inv;
       x1 = any ? st.a[0] + fast_log(st.b[0]) : 0.f;
       x2 = st.d[0] * inv;
+      if (P.range_flag && !(fabsf(x1) < kShiftSafe)) atomicOr(P.range_flag, 1);
     } else if constexpr (MODE == DGCN_AGGR_POWER) {
       const float q = st.b[0] / fmaxf(deg, 1.f);
       const float r = fminf(fmaxf(q, kPowLo), kPowHi);
@@ -732,7 +736,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
                                      const float* edge_attr, int32_t channels, int32_t mode,
                                      int32_t msg, int32_t flags, float t, float p, float eps,
                                      const float* t_dev, const float* p_dev, float* out,
-                                     void* aux1, float* aux2, void* workspace,
+                                     void* aux1, float* aux2, int32_t* range_flag, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   (void)flags;
   if (!g || !x || !out) return DGCN_E_NULL;
@@ -758,6 +762,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
+  P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
 
   const int n_items = g->n_work ? g->n_work : g->n_dst;
 #ifdef DGCN_FWD_WAVES_PER_CU

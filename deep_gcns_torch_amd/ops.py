@@ -22,7 +22,7 @@ _MODES = {
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
-SHIFT_MAX_RANGE = 60.0             # max_i L - min_i L per channel below which exp(K-L), exp(tm-K) stay in fp32 range
+SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr.hip)
 
 
 def _scalar_arg(v):
@@ -70,16 +70,20 @@ class _GenAggregate(torch.autograd.Function):
             if (mode == _lib.AGGR_SOFTMAX and learn_t) or (mode == _lib.AGGR_POWER and learn_p):
                 aux2 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         flags = (_lib.FLAG_LEARN_T if learn_t else 0) | (_lib.FLAG_LEARN_P if learn_p else 0)
+        range_flag = None
+        if need_grad and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
+            range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
         with torch.cuda.device(dev):
             rc = lib.dgcn_gen_aggr_fwd_f32(
                 graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
                 t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
-                _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(ws), ws_bytes,
+                _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                 _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_gen_aggr_fwd_f32")
         if need_grad:
+            ctx.range_flag = range_flag
             ctx.save_for_backward(x, edge_attr, t_param, p_param, aux1, aux2, out)
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
             ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
@@ -124,12 +128,12 @@ class _GenAggregate(torch.autograd.Function):
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
             gshift = kshift = shift_ok = None
-            if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
-                # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  The
-                # range check stays on the device (no host sync); the kernel falls back to two gathers.
-                lmin, lmax = torch.aminmax(aux1, dim=0)
-                kshift = ((lmin + lmax) * 0.5).contiguous()
-                shift_ok = ((lmax - lmin).amax() < SHIFT_MAX_RANGE).to(torch.int32)
+            if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and ctx.range_flag is not None:
+                # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  K_c = 0
+                # is safe whenever every |L_i| < 80, which the FORWARD kernel checked on the fly (range_flag);
+                # the decision stays on the device (no host sync) and the kernel falls back to two gathers.
+                kshift = torch.zeros(C, device=dev, dtype=torch.float32)
+                shift_ok = (ctx.range_flag == 0).to(torch.int32)
                 gshift = torch.empty_like(gcoef)
                 with torch.cuda.device(dev):
                     rc = lib.dgcn_softmax_bwd_prep_f32(gcoef.data_ptr(), aux1.data_ptr(), kshift.data_ptr(),

@@ -115,6 +115,8 @@ int dgcn_selftest_axpy_f32(float a, const float* x, float* y, int64_t n, void* s
  *              (-1 for an empty row).  ADD/MEAN: unused.
  *   aux2       [n_dst, C] or NULL.  SOFTMAX+LEARN_T: sum_e w_e m_e^2.
  *              POWER+LEARN_P: sum_e u_e^p ln u_e.  Otherwise unused.
+ *   range_flag optional device int32, zeroed by the caller: SOFTMAX sets it to 1 when some |L_i| >= 80, i.e. when
+ *              the single-gather backward with shift 0 would leave the fp32 range (decided on the device).
  *   workspace  >= dgcn_gen_aggr_fwd_workspace_bytes(g, C) bytes (0 unless rows are split).
  */
 size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
@@ -123,7 +125,7 @@ int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           const float* edge_attr, int32_t channels, int32_t mode,
                           int32_t msg, int32_t flags, float t, float p, float eps,
                           const float* t_dev, const float* p_dev, float* out, void* aux1,
-                          float* aux2, void* workspace, size_t workspace_bytes,
+                          float* aux2, int32_t* range_flag, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /*

@@ -34,16 +34,16 @@ def test_argument_errors_do_not_launch():
     g = _lib.DgcnGraph()
     g.n_dst, g.n_src, g.n_edges = 4, 4, 0
     assert lib.dgcn_gen_aggr_fwd_f32(None, None, 0, None, 4, 3, 1, 0, 1.0, 1.0, 1e-7, None, None, None,
-                                     None, None, None, 0, None) == -1
+                                     None, None, None, None, 0, None) == -1
     import ctypes as C
     buf = (C.c_float * 64)()
     ptr = C.addressof(buf)
     # bad mode
     assert lib.dgcn_gen_aggr_fwd_f32(C.byref(g), ptr, 4, None, 4, 99, 1, 0, 1.0, 1.0, 1e-7, None, None, ptr,
-                                     None, None, None, 0, None) == -4
+                                     None, None, None, None, 0, None) == -4
     # bad stride
     assert lib.dgcn_gen_aggr_fwd_f32(C.byref(g), ptr, 2, None, 4, 3, 1, 0, 1.0, 1.0, 1e-7, None, None, ptr,
-                                     None, None, None, 0, None) == -2
+                                     None, None, None, None, 0, None) == -2
     assert lib.dgcn_selftest_axpy_f32(1.0, None, None, 4, None) == -1
 
 

@@ -164,8 +164,8 @@ def test_arxiv_shape_properties():
 
 @pytest.mark.parametrize("t,expect_shifted", [(0.1, True), (1.0, True), (40.0, False)])
 def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_shifted):
-    """The softmax backward gathers ONE pre-scaled row per edge when max L - min L < 60 per channel,
-    otherwise (decided on the device, no host sync) two rows.  Both must match the float64 oracle."""
+    """The softmax backward gathers ONE pre-scaled row per edge when every |L_i| < 80 (checked by the forward
+    kernel), otherwise (decided on the device, no host sync) two rows.  Both must match the float64 oracle."""
     from deep_gcns_torch_amd import ops
     from oracle import sparse_ref
     dev = _dev()
@@ -198,8 +198,7 @@ def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_s
     den = torch.zeros(257, 64, dtype=torch.float64).index_add_(0, ei[1], torch.exp(s - mx[ei[1]]))
     has = torch.bincount(ei[1], minlength=257) > 0
     lse[has] = (mx + torch.log(den.clamp_min(1e-300)))[has]
-    rng = float((lse.amax(0) - lse.amin(0)).max())
-    assert (rng < 60.0) == expect_shifted
+    assert (float(lse.abs().max()) < 80.0) == expect_shifted
     if not expect_shifted:
         assert torch.equal(grads[True], grads[False])     # same two-gather code path, bit-identical
 
