@@ -157,8 +157,9 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
  *   out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])          (channels % 4 == 0)
  * With it, dL/dm_e = g_i exp(t m_e - L_i) = out_i * exp(t m_e - kshift_c): the edge walk gathers ONE row
  * per edge instead of two.  The caller passes (gshift=out, kshift, shift_ok) to dgcn_gen_aggr_bwd_f32;
- * shift_ok is a DEVICE flag (1 when max_i L - min_i L is small enough for fp32, decided without a host
- * sync); when it is 0, or the three pointers are NULL, the kernel uses the two-gather form. */
+ * shift_ok is a DEVICE flag (1 when every |L_i - kshift_c| keeps both factors inside the fp32 range; with
+ * kshift = 0 it is the negation of the forward's range_flag, so it is decided without a host sync or an
+ * extra pass over L); when it is 0, or the three pointers are NULL, the kernel uses the two-gather form. */
 int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshift, float* out,
                               int64_t n_rows, int32_t channels, void* stream);
 
