@@ -87,7 +87,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="profiling aid: skip the backward")
     ap.add_argument("--force-partitioned", action="store_true",
-                    help="run the RCCL destination-partitioned path even with one rank (sanity check)")
+                    help="run the RCCL multi-rank path even with one rank (sanity check)")
+    ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather"],
+                    help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
+    ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,14 +144,19 @@ def main():
             return out
     else:
         from deep_gcns_torch_amd import dist as ddist
-        part = ddist.PartitionedGraph.from_edge_index(ei, n, rank, world)
+        scheme = args.scheme
+        if scheme == "auto" and world == 1:
+            scheme = "transposed"
+        part = ddist.build_partition(ei, n, C, rank, world, scheme=scheme)
+        transposed = isinstance(part, ddist.TransposedGraph)
         del ei
         x = x_full[part.lo:part.hi].clone().requires_grad_(True)
         g_loc = g_full[part.lo:part.hi].clone()
         del x_full, g_full
+        extra = dict(pipeline_chunks=args.pipeline_chunks) if args.pipeline_chunks else {}
 
         def fwd():
-            return ddist.partitioned_gen_aggregate(x, part, aggr=args.aggr, t=args.t)
+            return ddist.aggregate(x, part, aggr=args.aggr, t=args.t, **extra)
 
         def step():
             out = fwd()
@@ -165,6 +173,9 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if dist is not None:          # RCCL prints a banner through C stdio at communicator creation: flush it now so
+        import ctypes             # the JSON line stays the LAST line of stdout
+        ctypes.CDLL(None).fflush(None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -194,7 +205,7 @@ def main():
         if not partitioned:
             algo = fwd_bytes(E, n, C)
         else:
-            algo = fwd_bytes(part.n_local_edges, part.hi - part.lo, C)
+            algo = fwd_bytes(E, n, C // world) if transposed else fwd_bytes(part.n_local_edges, part.hi - part.lo, C)
         achieved = algo / (fwd_ms_avg * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -222,10 +233,14 @@ def main():
                 "workload": f"GENConv {args.aggr} aggregation (t={args.t}) fwd+bwd, ogbn-{args.shape}-shaped "
                             f"{args.graph} random graph N={n} E={E} C={C}"
                             + (" [fwd only]" if args.fwd_only else ""),
-                "parallelism": "single GPU" if not partitioned else f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd",
+                "parallelism": ("single GPU" if not partitioned else
+                                (f"node-partitioned rows x{world}, channel-transposed exchange (RCCL all-to-all in/out, "
+                                 f"each rank aggregates all edges for C/{world} channels)" if transposed else
+                                 f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd")),
             },
             "roofline": {
-                "kernel": "gen_aggr_fwd_kernel<SOFTMAX> (dgcn_gen_aggr_fwd_f32)",
+                "kernel": "gen_aggr_fwd_kernel<SOFTMAX> (dgcn_gen_aggr_fwd_f32)"
+                          + (" + exchange (whole forward of one rank)" if partitioned else ""),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -237,7 +252,7 @@ def main():
                 "launch_ms_min": fwd_ms[0],
                 "frac_of_measured_copy_6290GBs": achieved / 6290.0,
             },
-            "fwd_edges_per_s": (E if not partitioned else part.n_local_edges) / (fwd_ms_avg * 1e-3),
+            "fwd_edges_per_s": (E if (not partitioned or transposed) else part.n_local_edges) / (fwd_ms_avg * 1e-3),
         }
         if world == 1 and not partitioned and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t)

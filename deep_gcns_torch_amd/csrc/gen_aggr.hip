@@ -85,20 +85,56 @@ struct Work {
   int row, beg, end, slot;
 };
 
-__device__ __forceinline__ Work fetch_work(const WalkGraph& g, int item) {
+// SW = lanes that share one work item.  SW == 64: the whole wave, everything wave-uniform (SGPRs).
+// SW < 64 (narrow rows): 64/SW sub-groups walk different items side by side; an out-of-range item is empty.
+template <int SW>
+__device__ __forceinline__ int maybe_uni(int v) {
+  if constexpr (SW == kWave) return uni(v);
+  return v;
+}
+
+template <int SW>
+__device__ __forceinline__ bool any_sub(bool c) {
+  if constexpr (SW == kWave) return c;
+  return __any(c);
+}
+
+template <int SW>
+__device__ __forceinline__ bool all_sub(bool c) {
+  if constexpr (SW == kWave) return c;
+  return __all(c);
+}
+
+template <int SW>
+__device__ __forceinline__ Work fetch_work(const WalkGraph& g, int item, int n_items) {
   Work w;
+  if (item >= n_items) {   // past the end (sub-group tail, or the look-ahead of the last items): empty
+    w.row = -1; w.beg = 0; w.end = 0; w.slot = -1;
+    return w;
+  }
   if (g.n_work) {
-    w.row = uni(g.work_row[item]);
-    w.beg = uni(g.work_beg[item]);
-    w.end = uni(g.work_end[item]);
-    w.slot = uni(g.work_slot[item]);
+    w.row = maybe_uni<SW>(g.work_row[item]);
+    w.beg = maybe_uni<SW>(g.work_beg[item]);
+    w.end = maybe_uni<SW>(g.work_end[item]);
+    w.slot = maybe_uni<SW>(g.work_slot[item]);
   } else {
     w.row = item;
-    w.beg = uni(g.rowptr[item]);
-    w.end = uni(g.rowptr[item + 1]);
+    w.beg = maybe_uni<SW>(g.rowptr[item]);
+    w.end = maybe_uni<SW>(g.rowptr[item + 1]);
     w.slot = -1;
   }
   return w;
+}
+
+// First/next block of <= SW column ids (and original edge ids) of an item, one per lane of the sub-group.
+template <int SW, bool NEED_EID>
+__device__ __forceinline__ void load_cols(const WalkGraph& g, const Work& w, int blk, int sl, int& col, int& eid) {
+  col = 0;
+  eid = 0;
+  if (sl < w.end - blk) {
+    col = g.col[blk + sl];
+    if constexpr (NEED_EID) eid = g.eperm ? g.eperm[blk + sl] : blk + sl;
+  }
 }
 
 // Block b runs on XCD b % 8 (observed dispatch order; used for L2 affinity only).  Remap so
@@ -121,7 +157,8 @@ __device__ __forceinline__ float fast_pow(float u, float p) {  // u > 0
 // forward
 // ---------------------------------------------------------------------------------------
 // Per-channel reduction state.  Meaning by mode:
-//   SOFTMAX: a = running max M of t*m, b = sum exp(s-M), c = sum exp(s-M)*m, d = sum exp(s-M)*m^2
+//   SOFTMAX: a = running max M' of s' = t*log2(e)*m, b = sum 2^(s'-M'), c = sum 2^(s'-M')*m, d = sum 2^(s'-M')*m^2
+//            (inside the edge loop c, d hold the sums over r = m - eps; see softmax_fold)
 //   POWER  : b = sum u^p, d = sum u^p ln u
 //   ADD/MEAN: b = sum m
 //   MAX    : a = best m, idx = original edge id of the first maximal edge
@@ -150,8 +187,8 @@ __device__ __forceinline__ void state_merge(State<VEC>& s, const State<VEC>& o) 
   for (int j = 0; j < VEC; ++j) {
     if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
       const float nm = fmaxf(s.a[j], o.a[j]);
-      const float s1 = (s.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp(s.a[j] - nm);
-      const float s2 = (o.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp(o.a[j] - nm);
+      const float s1 = (s.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp2(s.a[j] - nm);   // a is in the log2 domain
+      const float s2 = (o.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp2(o.a[j] - nm);
       s.b[j] = s.b[j] * s1 + o.b[j] * s2;
       s.c[j] = s.c[j] * s1 + o.c[j] * s2;
       s.d[j] = s.d[j] * s1 + o.d[j] * s2;
@@ -193,55 +230,118 @@ __device__ __forceinline__ State<VEC> state_shfl_xor(const State<VEC>& s, int of
   return o;
 }
 
+// ---- softmax fold, written for VALU economy ------------------------------------------------------------
+// The forward kernel is co-limited by HBM and VALU issue (16 G channel-visits per launch at the products
+// shape), so the per-element work is kept minimal:
+//   * everything in the log2 domain: s' = t*log2(e)*m, weights exp2(s' - max') -> one v_exp_f32 per element, no
+//     extra multiply;
+//   * m = relu(z) + eps is never formed: s' = fma(t2, relu(z), t2*eps), and sum(e*m) = sum(e*relu(z)) + eps*sum(e)
+//     is fixed up once per row;
+//   * channel PAIRS as 2-vectors so mul/add/fma become v_pk_*_f32 (two channels per instruction);
+//   * full batches (all U*G edge slots valid) take a variant without any masking.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vrelu(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));   // one instruction (fmaxf adds a canonicalising max)
+  return r;
+}
+__device__ __forceinline__ f2 vrelu(f2 v) { return f2{vrelu(v.x), vrelu(v.y)}; }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ float vexp2(float a) { return fast_exp2(a); }
+__device__ __forceinline__ f2 vexp2(f2 a) { return f2{fast_exp2(a.x), fast_exp2(a.y)}; }
+__device__ __forceinline__ float vsplat(float, float v) { return v; }
+__device__ __forceinline__ f2 vsplat(f2, float v) { return f2{v, v}; }
+
+// T = float or f2.  (a, D, A, A2) = running max' / sum e / sum e*r / sum e*r^2 with r = relu(z) (or z).
+template <typename T, int U, bool RELU, bool WITH_D, bool FULL>
+__device__ __forceinline__ void softmax_fold(T& a, T& D, T& A, T& A2, const T (&z)[U], const bool (&ok)[U],
+                                             float t2, float c0) {
+  T r[U], s[U];
+  const T vt2 = vsplat(a, t2), vc0 = vsplat(a, c0);
+  T nm = a;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    r[u] = RELU ? vrelu(z[u]) : z[u];
+    s[u] = r[u] * vt2 + vc0;
+    if constexpr (!FULL) {
+      if (u > 0) s[u] = ok[u] ? s[u] : vsplat(a, DGCN_NEG_INF);   // ok[0] holds (caller's guard)
+    }
+    nm = vmax(nm, s[u]);
+  }
+  const T sc = vexp2(a - nm);   // exp2(-inf) = 0 on the first batch
+  D = D * sc;
+  A = A * sc;
+  if constexpr (WITH_D) A2 = A2 * sc;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const T e = vexp2(s[u] - nm);   // 0 for masked edges
+    D = D + e;
+    if constexpr (WITH_D) {
+      const T er = e * r[u];
+      A = A + er;
+      A2 = er * r[u] + A2;
+    } else {
+      A = e * r[u] + A;
+    }
+  }
+  a = nm;
+}
+
 // Fold U gathered rows (this lane's VEC channels of each) into the state.
-template <int MODE, int VEC, int U>
+template <int MODE, int VEC, int U, bool RELU, bool WITH_D, bool FULL>
 __device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][VEC],
-                                           const bool (&ok)[U], const int (&eid)[U], int msg,
-                                           float eps, float t, float p) {
-  if (!ok[0]) return;  // ok[] is monotone in u: nothing valid for this edge group
+                                           const bool (&ok)[U], const int (&eid)[U], float eps,
+                                           float t2, float c0, float p) {
+  if constexpr (!FULL) {
+    if (!ok[0]) return;  // ok[] is monotone in u: nothing valid for this edge group
+  }
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    if constexpr (VEC % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; j += 2) {
+        f2 a = {st.a[j], st.a[j + 1]}, D = {st.b[j], st.b[j + 1]}, A = {st.c[j], st.c[j + 1]};
+        f2 A2 = {st.d[j], st.d[j + 1]};
+        f2 z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) z[u] = f2{v[u][j], v[u][j + 1]};
+        softmax_fold<f2, U, RELU, WITH_D, FULL>(a, D, A, A2, z, ok, t2, c0);
+        st.a[j] = a.x; st.a[j + 1] = a.y;
+        st.b[j] = D.x; st.b[j + 1] = D.y;
+        st.c[j] = A.x; st.c[j + 1] = A.y;
+        st.d[j] = A2.x; st.d[j + 1] = A2.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) z[u] = v[u][j];
+        softmax_fold<float, U, RELU, WITH_D, FULL>(st.a[j], st.b[j], st.c[j], st.d[j], z, ok, t2, c0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
-      float m[U], s[U];
-      float bm = DGCN_NEG_INF;
+    if constexpr (MODE == DGCN_AGGR_POWER) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        m[u] = msg_apply(v[u][j], msg, eps);
-        s[u] = ok[u] ? t * m[u] : DGCN_NEG_INF;
-        bm = fmaxf(bm, s[u]);
-      }
-      const float nm = fmaxf(st.a[j], bm);
-      const float sc = fast_exp(st.a[j] - nm);  // exp(-inf) = 0 on the first batch
-      float D = st.b[j] * sc, A = st.c[j] * sc, A2 = st.d[j] * sc;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float e = fast_exp(s[u] - nm);  // 0 for masked edges
-        const float em = e * m[u];
-        D += e;
-        A += em;
-        A2 = fmaf(em, m[u], A2);
-      }
-      st.a[j] = nm;
-      st.b[j] = D;
-      st.c[j] = A;
-      st.d[j] = A2;
-    } else if constexpr (MODE == DGCN_AGGR_POWER) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          const float m = msg_apply(v[u][j], msg, eps);
+        if (FULL || ok[u]) {
+          const float m = RELU ? vrelu(v[u][j]) + eps : v[u][j];
           const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
           const float l2 = fast_log2(uu);
           const float up = fast_exp2(p * l2);
           st.b[j] += up;
-          st.d[j] = fmaf(up, l2 * 0.6931471805599453f, st.d[j]);
+          if constexpr (WITH_D) st.d[j] = fmaf(up, l2 * 0.6931471805599453f, st.d[j]);
         }
       }
     } else if constexpr (MODE == DGCN_AGGR_MAX) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (ok[u]) {
-          const float m = msg_apply(v[u][j], msg, eps);
+        if (FULL || ok[u]) {
+          const float m = RELU ? vrelu(v[u][j]) + eps : v[u][j];
           // strict '>' keeps the FIRST maximal edge (edges arrive in increasing id per group)
           if (m > st.a[j] || st.idx[j] < 0) {
             st.a[j] = m;
@@ -252,15 +352,21 @@ __device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][V
     } else {  // ADD / MEAN
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (ok[u]) st.b[j] += msg_apply(v[u][j], msg, eps);
+        if (FULL || ok[u]) st.b[j] += RELU ? vrelu(v[u][j]) + eps : v[u][j];
       }
     }
   }
 }
 
-template <int MODE, int VEC, int LPR, bool HAS_EA>
-__global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParams P) {
-  constexpr int G = kWave / LPR;            // edges walked in parallel by one wave
+// Address of row `src`: a 32x32->64 multiply (one v_mad_u64_u32); the host checks 0 <= stride < 2^31.
+__device__ __forceinline__ const float* row_ptr(const float* base, int src, uint32_t stride) {
+  return base + static_cast<uint64_t>(static_cast<uint32_t>(src)) * stride;
+}
+
+template <int MODE, int VEC, int LPR, int SW, bool HAS_EA, bool RELU, bool WITH_D>
+__device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
+  constexpr int G = SW / LPR;               // edges of one item walked in parallel
+  constexpr int R = kWave / SW;             // items walked side by side by one wave
 #ifdef DGCN_FWD_U
   constexpr int U = DGCN_FWD_U;
 #else
@@ -269,69 +375,109 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
   constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
 
   const int lane = lane_id();
-  const int g = lane / LPR;
-  const int cl = lane % LPR;
+  const int sl = lane % SW;                 // lane within its sub-group
+  const int sbase = lane - sl;
+  const int g = sl / LPR;
+  const int cl = sl % LPR;
   const int C = P.C;
+  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
   const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
   const int total_waves = gridDim.x * kWavesPerWg;
   const int wave0 = virtual_block() * kWavesPerWg + (threadIdx.x >> 6);
   const float t = P.t_dev ? *P.t_dev : P.t;
   const float p = P.p_dev ? *P.p_dev : P.p;
   const float eps = P.eps;
-  const int msg = P.msg;
+  const float eps_r = RELU ? eps : 0.f;     // the part of m = relu(z) + eps that the softmax fold leaves out
+  const float t2 = t * 1.4426950408889634f; // log2 domain
+  const float c0 = t2 * eps_r;
 
-  for (int item = wave0; item < n_items; item += total_waves) {
-    const Work w = fetch_work(P.g, item);
+  // Software pipeline over the items of this wave: while item i is walked, the column ids of item i+1 and the
+  // row bounds of item i+2 are already in flight, so a row does not start with two dependent memory latencies.
+  const int stride = total_waves * R;
+  const int sub = lane / SW;
+  Work w = fetch_work<SW>(P.g, wave0 * R + sub, n_items);
+  Work wn = fetch_work<SW>(P.g, wave0 * R + stride + sub, n_items);
+  int col0, eid0;
+  load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+  for (int base = wave0 * R; base < n_items; base += stride) {
+    int coln, eidn;
+    load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
+    const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
     for (int cb = 0; cb < C; cb += LPR * VEC) {
-      const int c0 = cb + cl * VEC;
-      const bool act = c0 < C;
+      const int c0ch = cb + cl * VEC;
+      const bool act = c0ch < C;
       State<VEC> st;
       state_init<MODE, VEC>(st);
 
-      for (int blk = w.beg; blk < w.end; blk += kWave) {
-        const int nb = min(kWave, w.end - blk);
-        int mycol = 0, myeid = 0;
-        if (lane < nb) {
-          mycol = P.g.col[blk + lane];
-          if constexpr (NEED_EID) myeid = P.g.eperm ? P.g.eperm[blk + lane] : blk + lane;
-        }
-        for (int s0 = 0; s0 < nb; s0 += G * U) {
+      int mycol = col0, myeid = eid0;
+      for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
+        const int nb = max(0, min(SW, w.end - blk));
+        if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
+        for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
           float v[U][VEC];
           bool ok[U];
           int eid[U];
+          const bool full = all_sub<SW>(nb - s0 >= G * U) && (cb + LPR * VEC <= C);   // wave-uniform
+          if (full) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int ei = s0 + u * G + g;
-            ok[u] = ei < nb;
-            const int src = __shfl(mycol, ei & (kWave - 1));
-            eid[u] = 0;
-            if constexpr (NEED_EID) eid[u] = __shfl(myeid, ei & (kWave - 1));
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v[u][j] = 0.f;
-            if (ok[u] && act) {
-              load_vec<VEC>(v[u], P.x + static_cast<int64_t>(src) * P.x_stride + c0);
+            for (int u = 0; u < U; ++u) {
+              const int ei = s0 + u * G + g;
+              ok[u] = true;
+              const int src = __shfl(mycol, sbase + (ei & (SW - 1)));
+              eid[u] = 0;
+              if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
+              load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
               if constexpr (HAS_EA) {
                 float a[VEC];
-                load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0);
+                load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
               }
             }
+            accumulate<MODE, VEC, U, RELU, WITH_D, true>(st, v, ok, eid, eps, t2, c0, p);
+          } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int ei = s0 + u * G + g;
+              ok[u] = ei < nb;
+              const int src = __shfl(mycol, sbase + (ei & (SW - 1)));
+              eid[u] = 0;
+              if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) v[u][j] = 0.f;
+              if (ok[u] && act) {
+                load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
+                if constexpr (HAS_EA) {
+                  float a[VEC];
+                  load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+                }
+              }
+            }
+            accumulate<MODE, VEC, U, RELU, WITH_D, false>(st, v, ok, eid, eps, t2, c0, p);
           }
-          accumulate<MODE, VEC, U>(st, v, ok, eid, msg, eps, t, p);
         }
       }
 
-      // combine the G edge groups of this wave (all lanes participate)
+      // combine the G edge groups of each item (all lanes participate)
 #pragma unroll
-      for (int off = LPR; off < kWave; off <<= 1) {
+      for (int off = LPR; off < SW; off <<= 1) {
         const State<VEC> o = state_shfl_xor<MODE, VEC>(st, off);
         state_merge<MODE, VEC>(st, o);
       }
 
-      if (g == 0 && act) {
+      if (g == 0 && act && w.row >= 0) {
+        if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+          // back to sums over m = r + eps:  sum e m = A + eps D,  sum e m^2 = A2 + 2 eps A + eps^2 D
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if constexpr (WITH_D) st.d[j] = fmaf(eps_r, fmaf(eps_r, st.b[j], 2.f * st.c[j]), st.d[j]);
+            st.c[j] = fmaf(eps_r, st.b[j], st.c[j]);
+          }
+        }
         if (w.slot >= 0) {
-          float* ws = P.ws + (static_cast<int64_t>(w.slot) * 4) * C + c0;
+          float* ws = P.ws + (static_cast<int64_t>(w.slot) * 4) * C + c0ch;
           if constexpr (MODE == DGCN_AGGR_MAX) {
             float fi[VEC];
 #pragma unroll
@@ -345,7 +491,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
             store_vec<VEC>(ws + 3 * C, st.d);
           }
         } else {
-          const int64_t o = static_cast<int64_t>(w.row) * C + c0;
+          const int64_t o = static_cast<int64_t>(w.row) * C + c0ch;
           const float deg = static_cast<float>(w.end - w.beg);
           float res[VEC], x1[VEC], x2[VEC];
           int xi[VEC];
@@ -356,7 +502,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
               const bool any = st.b[j] > 0.f;
               const float inv = any ? 1.f / st.b[j] : 0.f;
               res[j] = st.c[j] * inv;
-              x1[j] = any ? st.a[j] + fast_log(st.b[j]) : 0.f;
+              x1[j] = any ? (st.a[j] + fast_log2(st.b[j])) * 0.6931471805599453f : 0.f;
               x2[j] = st.d[j] * inv;
               if (P.range_flag && !(fabsf(x1[j]) < kShiftSafe)) atomicOr(P.range_flag, 1);  // rare
             } else if constexpr (MODE == DGCN_AGGR_POWER) {
@@ -384,6 +530,21 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParam
         }
       }
     }
+    w = wn;
+    wn = wnn;
+    col0 = coln;
+    eid0 = eidn;
+  }
+}
+
+// WITH_D (second moment for learnable t / p) is a kernel-level parameter: its extra accumulators must not
+// cost the common variant registers.  The message kind is a wave-uniform branch inside (same register budget).
+template <int MODE, int VEC, int LPR, int SW, bool HAS_EA, bool WITH_D>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParams P) {
+  if (P.msg == DGCN_MSG_RELU_EPS) {
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, HAS_EA, true, WITH_D>(P);
+  } else {
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, HAS_EA, false, WITH_D>(P);
   }
 }
 
@@ -426,7 +587,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
       const bool any = st.b[0] > 0.f;
       const float inv = any ? 1.f / st.b[0] : 0.f;
       res = st.c[0] * inv;
-      x1 = any ? st.a[0] + fast_log(st.b[0]) : 0.f;
+      x1 = any ? (st.a[0] + fast_log2(st.b[0])) * 0.6931471805599453f : 0.f;
       x2 = st.d[0] * inv;
       if (P.range_flag && !(fabsf(x1) < kShiftSafe)) atomicOr(P.range_flag, 1);
     } else if constexpr (MODE == DGCN_AGGR_POWER) {
@@ -458,15 +619,18 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
 // ---------------------------------------------------------------------------------------
 constexpr int kModeSoftmaxShifted = 100;  // internal: softmax backward with ONE gathered row per edge
 
-template <int MODE, int VEC, int LPR, bool HAS_EA>
+template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
 __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
-  constexpr int G = kWave / LPR;
+  constexpr int G = SW / LPR;
+  constexpr int R = kWave / SW;
   constexpr int U = (VEC == 4) ? 4 : 8;
   constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
 
   const int lane = lane_id();
-  const int g = lane / LPR;
-  const int cl = lane % LPR;
+  const int sl = lane % SW;
+  const int sbase = lane - sl;
+  const int g = sl / LPR;
+  const int cl = sl % LPR;
   const int C = P.C;
   const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
   const int total_waves = gridDim.x * kWavesPerWg;
@@ -477,27 +641,33 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   const int msg = P.msg;
   const bool learn_t = P.learn_t != 0;
 
-  for (int item = wave0; item < n_items; item += total_waves) {
-    const Work w = fetch_work(P.g, item);
+  // same software pipeline over items as in the forward kernel
+  const int stride = total_waves * R;
+  const int sub = lane / SW;
+  Work w = fetch_work<SW>(P.g, wave0 * R + sub, n_items);
+  Work wn = fetch_work<SW>(P.g, wave0 * R + stride + sub, n_items);
+  int col0, eid0;
+  load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+  for (int base = wave0 * R; base < n_items; base += stride) {
+    int coln, eidn;
+    load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
+    const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
     for (int cb = 0; cb < C; cb += LPR * VEC) {
       const int c0 = cb + cl * VEC;
       const bool act = c0 < C;
       float xs[VEC], acc[VEC], ksh[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; ksh[j] = 0.f; }
-      if (act) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
+      if (act && w.row >= 0) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
       if constexpr (MODE == kModeSoftmaxShifted) {
         if (act) load_vec<VEC>(ksh, P.kshift + c0);
       }
 
-      for (int blk = w.beg; blk < w.end; blk += kWave) {
-        const int nb = min(kWave, w.end - blk);
-        int mycol = 0, myeid = 0;
-        if (lane < nb) {
-          mycol = P.g.col[blk + lane];
-          if constexpr (NEED_EID) myeid = P.g.eperm ? P.g.eperm[blk + lane] : blk + lane;
-        }
-        for (int s0 = 0; s0 < nb; s0 += G * U) {
+      int mycol = col0, myeid = eid0;
+      for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
+        const int nb = max(0, min(SW, w.end - blk));
+        if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
+        for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
           float gc[U][VEC], a1[U][VEC], oo[U][VEC], ea[U][VEC];
           int ai[U][VEC];
           bool ok[U];
@@ -506,9 +676,9 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
           for (int u = 0; u < U; ++u) {
             const int ei = s0 + u * G + g;
             ok[u] = ei < nb;
-            const int dst = __shfl(mycol, ei & (kWave - 1));
+            const int dst = __shfl(mycol, sbase + (ei & (SW - 1)));
             eid[u] = 0;
-            if constexpr (NEED_EID) eid[u] = __shfl(myeid, ei & (kWave - 1));
+            if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               gc[u][j] = 0.f; a1[u][j] = 0.f; oo[u][j] = 0.f; ea[u][j] = 0.f; ai[u][j] = -1;
@@ -570,11 +740,11 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         }
       }
 #pragma unroll
-      for (int off = LPR; off < kWave; off <<= 1) {
+      for (int off = LPR; off < SW; off <<= 1) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], off);
       }
-      if (g == 0 && act) {
+      if (g == 0 && act && w.row >= 0) {
         if (w.slot >= 0) {
           store_vec<VEC>(P.ws + static_cast<int64_t>(w.slot) * C + c0, acc);
         } else {
@@ -582,19 +752,23 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         }
       }
     }
+    w = wn;
+    wn = wnn;
+    col0 = coln;
+    eid0 = eidn;
   }
 }
 
-template <int MODE, int VEC, int LPR, bool HAS_EA>
+template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
   if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
     // single-gather form when the caller prepared it and the device-side range check passed
     if (P.gshift != nullptr && !P.learn_t && *P.shift_ok != 0) {
-      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, HAS_EA>(P);
+      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, SW, HAS_EA>(P);
       return;
     }
   }
-  gen_aggr_bwd_body<MODE, VEC, LPR, HAS_EA>(P);
+  gen_aggr_bwd_body<MODE, VEC, LPR, SW, HAS_EA>(P);
 }
 
 // out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])   (node-wise prologue of the single-gather backward)
@@ -640,33 +814,59 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
 // ---------------------------------------------------------------------------------------
 int lanes_per_row(int C, int vec) {
   const int need = (C + vec - 1) / vec;
-  int lpr = 8;
+  int lpr = 4;
   while (lpr < need && lpr < kWave) lpr <<= 1;
   return lpr;
 }
 
 int round_up8(int v) { return (v + 7) / 8 * 8; }
 
-template <int MODE, int VEC, int LPR>
+// Sub-group width for narrow rows: 4 edge groups per item (two merge steps instead of four, and the item
+// bookkeeping shared by 64/SW rows).  DGCN_SUBGROUP=64 in the environment forces one item per wave.
+int subgroup_width(int lpr) {
+  static const int forced = [] {
+    const char* e = getenv("DGCN_SUBGROUP");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == kWave) return kWave;
+  const int sw = lpr * 4;
+  return sw < kWave ? sw : kWave;
+}
+
+template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
+void launch_fwd_d(const FwdParams& P, int grid, hipStream_t s) {
+  constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
+  if constexpr (CAN_D) {
+    if (P.aux2) {
+      hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, HAS_EA, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, HAS_EA, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+}
+
+template <int MODE, int VEC, int LPR, int SW>
 void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
   if (P.ea) {
-    hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    launch_fwd_d<MODE, VEC, LPR, SW, true>(P, grid, s);
   } else {
-    hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    launch_fwd_d<MODE, VEC, LPR, SW, false>(P, grid, s);
   }
 }
 
 template <int MODE>
 void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
   if (vec == 4) {
+    const bool sub = subgroup_width(lpr) < kWave;
     switch (lpr) {
-      case 8: launch_fwd_ea<MODE, 4, 8>(P, grid, s); break;
-      case 16: launch_fwd_ea<MODE, 4, 16>(P, grid, s); break;
-      case 32: launch_fwd_ea<MODE, 4, 32>(P, grid, s); break;
-      default: launch_fwd_ea<MODE, 4, 64>(P, grid, s); break;
+      case 4: sub ? launch_fwd_ea<MODE, 4, 4, 16>(P, grid, s) : launch_fwd_ea<MODE, 4, 4, 64>(P, grid, s); break;
+      case 8: sub ? launch_fwd_ea<MODE, 4, 8, 32>(P, grid, s) : launch_fwd_ea<MODE, 4, 8, 64>(P, grid, s); break;
+      case 16: launch_fwd_ea<MODE, 4, 16, 64>(P, grid, s); break;
+      case 32: launch_fwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
+      default: launch_fwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
     }
   } else {
-    launch_fwd_ea<MODE, 1, 64>(P, grid, s);
+    launch_fwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
     const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
@@ -674,26 +874,28 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
   }
 }
 
-template <int MODE, int VEC, int LPR>
+template <int MODE, int VEC, int LPR, int SW>
 void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
   if (P.ea) {
-    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
   } else {
-    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
   }
 }
 
 template <int MODE>
 void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
   if (vec == 4) {
+    const bool sub = subgroup_width(lpr) < kWave;
     switch (lpr) {
-      case 8: launch_bwd_ea<MODE, 4, 8>(P, grid, s); break;
-      case 16: launch_bwd_ea<MODE, 4, 16>(P, grid, s); break;
-      case 32: launch_bwd_ea<MODE, 4, 32>(P, grid, s); break;
-      default: launch_bwd_ea<MODE, 4, 64>(P, grid, s); break;
+      case 4: sub ? launch_bwd_ea<MODE, 4, 4, 16>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s); break;
+      case 8: sub ? launch_bwd_ea<MODE, 4, 8, 32>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s); break;
+      case 16: launch_bwd_ea<MODE, 4, 16, 64>(P, grid, s); break;
+      case 32: launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
+      default: launch_bwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
     }
   } else {
-    launch_bwd_ea<MODE, 1, 64>(P, grid, s);
+    launch_bwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
     const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
@@ -741,6 +943,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   (void)flags;
   if (!g || !x || !out) return DGCN_E_NULL;
   if (g->n_dst < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
+  if (x_stride > 0x7fffffffLL) return DGCN_E_SHAPE;   // row addresses use a 32x32->64 multiply
   if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
   if (msg != DGCN_MSG_IDENTITY && msg != DGCN_MSG_RELU_EPS) return DGCN_E_MODE;
   if (g->n_dst == 0) return DGCN_OK;
@@ -764,7 +967,8 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
 
-  const int n_items = g->n_work ? g->n_work : g->n_dst;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;   // items walked side by side by one wave
+  const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
 #ifdef DGCN_FWD_WAVES_PER_CU
   const int grid = round_up8(grid_for_waves(n_items, DGCN_FWD_WAVES_PER_CU));
 #else
@@ -823,7 +1027,8 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   }
   P.ws = static_cast<float*>(workspace);
 
-  const int n_items = g->t_n_work ? g->t_n_work : g->n_src;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;
+  const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
   const int grid = round_up8(grid_for_waves(n_items));
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (mode) {

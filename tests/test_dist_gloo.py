@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from deep_gcns_torch_amd import synth
-from deep_gcns_torch_amd.dist import PartitionedGraph, balanced_bounds, partitioned_gen_aggregate
+from deep_gcns_torch_amd.dist import (PartitionedGraph, TransposedGraph, balanced_bounds, partitioned_gen_aggregate,
+                                      transposed_gen_aggregate, transposed_supported)
 
 
 def _free_port():
@@ -107,3 +108,73 @@ def test_balanced_bounds_and_padded_remap():
     b = balanced_bounds(torch.bincount(u[1], minlength=5000), 8)
     shares = [int(((u[1] >= b[r]) & (u[1] < b[r + 1])).sum()) for r in range(8)]
     assert max(shares) < 1.05 * (u.size(1) / 8)
+
+
+def _worker_transposed(rank, world, port, aggr, kw, q, chunks):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        n, C = 257, 16
+        ei = synth.tricky_graph()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(n, C, generator=g, dtype=torch.float64)
+        probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+        tg = TransposedGraph.from_edge_index(ei, n, rank, world)
+        assert tg.n_edges == ei.size(1)                       # every rank holds the whole graph
+        xl = x[tg.lo:tg.hi].clone().requires_grad_(True)
+        out = transposed_gen_aggregate(xl, tg, aggr=aggr, local_aggregate=_oracle_local, pipeline_chunks=chunks, **kw)
+        (out * probe[tg.lo:tg.hi]).sum().backward()
+        q.put((rank, tg.bounds, out.detach(), xl.grad.detach(), tg.max_rows))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("aggr,kw,chunks", [("softmax", dict(t=0.7), 1), ("softmax", dict(t=0.7), 2),
+                                            ("power", dict(p=2.0), 2), ("max", {}, 1), ("mean", {}, 2)])
+def test_channel_transposed_aggregate_world2_matches_single_process(aggr, kw, chunks):
+    """all_to_all (rows -> channel block) -> aggregation of ALL edges on 8 of the 16 channels -> all_to_all back;
+    uneven row ranges (128 / 129 rows) exercise the padded layout."""
+    from oracle import sparse_ref
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transposed, args=(r, world, port, aggr, kw, q, chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    ref = sparse_ref.gen_propagate(x, ei, aggr=aggr, **kw)
+    (ref * probe).sum().backward()
+    assert res[0][1] == [0, 128, 257] and res[0][4] == 129
+    torch.testing.assert_close(torch.cat([r[2] for r in res]), ref.detach(), rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(torch.cat([r[3] for r in res]), x.grad, rtol=1e-10, atol=1e-12)
+
+
+def test_transposed_graph_padded_ids_round_trip():
+    ei = synth.tricky_graph()
+    n = 257
+    for world in (1, 2, 4, 8):
+        tgs = [TransposedGraph.from_edge_index(ei, n, r, world, need_transpose=False) for r in range(world)]
+        mr = tgs[0].max_rows
+        bt = torch.tensor(tgs[0].bounds)
+        for tg in tgs:
+            assert tg.graph.n_dst == world * mr and tg.graph.n_src == world * mr and tg.n_edges == ei.size(1)
+            col = tg.graph.col.long()
+            drow = torch.repeat_interleave(torch.arange(tg.graph.n_dst), (tg.graph.rowptr[1:] - tg.graph.rowptr[:-1]).long())
+            src = bt[col // mr] + col % mr
+            dst = bt[drow // mr] + drow % mr
+            assert bool((col % mr < (bt[col // mr + 1] - bt[col // mr])).all())
+            assert torch.equal(torch.sort(src * 1000 + dst).values, torch.sort(ei[0] * 1000 + ei[1]).values)
+    assert transposed_supported(128, 8) and not transposed_supported(100, 8)
+    assert not transposed_supported(128, 8, edge_attr=torch.zeros(1))

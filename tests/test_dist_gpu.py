@@ -44,6 +44,14 @@ def test_partitioned_aggregate_on_rccl_single_rank():
             (outp * probe).sum().backward()
             torch.testing.assert_close(outp, ref, rtol=1e-6, atol=1e-7)
             torch.testing.assert_close(xc.grad, xb.grad, rtol=1e-5, atol=1e-6)
+            # channel-transposed scheme: all_to_all_single on RCCL, whole graph in the padded layout, 2 sub-blocks
+            from deep_gcns_torch_amd.dist import TransposedGraph, transposed_gen_aggregate
+            tg = TransposedGraph.from_edge_index(ei, 257, 0, 1)
+            xd = x.clone().requires_grad_(True)
+            outt = transposed_gen_aggregate(xd, tg, aggr=aggr, pipeline_chunks=2, **kw)
+            (outt * probe).sum().backward()
+            torch.testing.assert_close(outt, ref, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(xd.grad, xb.grad, rtol=1e-5, atol=1e-6)
     finally:
         if created:
             dist.destroy_process_group()

@@ -103,29 +103,36 @@ def test_known_answers_on_device():
     assert ops.gen_aggregate(xm, e1, aggr="add")[1, 0].item() == pytest.approx(1e-7, rel=1e-6)
 
 
+@pytest.mark.parametrize("C,with_ea", [(128, False), (64, True), (32, False), (32, True), (16, False), (16, True)])
 @pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.1)), ("power", dict(p=2.0)), ("max", {}), ("mean", {})])
-def test_vs_oracle_powerlaw_graph(aggr, kw):
+def test_vs_oracle_powerlaw_graph(aggr, kw, C, with_ea):
     """Mid-size power-law graph (hubs on both sides -> split rows in both walks) vs the CPU oracle.
+    C = 32 / 16 take the sub-group kernels (2 / 4 rows side by side in one wave), with and without edge features.
     The oracle is evaluated in float64: on hub rows (1e4+ edges) the fp32 sequential scatter_add of
     the reference path itself carries ~1e-4 relative rounding noise, so fp32-vs-fp32 would compare
     two roundings; fp64 is the value both approximate.  Tolerance stays 1e-4 relative."""
     from deep_gcns_torch_amd import ops, synth
     from oracle import sparse_ref
     dev = _dev()
-    n, C = 20000, 128
+    n = 20000
     ei = synth.powerlaw_graph(n, 150_000, seed=9, exponent=2.1)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(n, C, generator=g)
     probe = torch.randn(n, C, generator=g)
+    ea = torch.randn(ei.size(1), C, generator=g) if with_ea else None
     xr = x.double().requires_grad_(True)
-    ref = sparse_ref.gen_propagate(xr, ei, aggr=aggr, **kw)
+    er = ea.double().requires_grad_(True) if with_ea else None
+    ref = sparse_ref.gen_propagate(xr, ei, edge_attr=er, aggr=aggr, **kw)
     (ref * probe.double()).sum().backward()
     xd = x.to(dev).requires_grad_(True)
-    out = ops.gen_aggregate(xd, ei.to(dev), aggr=aggr, **kw)
+    ed = ea.to(dev).requires_grad_(True) if with_ea else None
+    out = ops.gen_aggregate(xd, ei.to(dev), edge_attr=ed, aggr=aggr, **kw)
     (out * probe.to(dev)).sum().backward()
     torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=RTOL, atol=1e-6)
     gs = xr.grad.abs().max().item()
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=RTOL, atol=2e-6 * max(gs, 1.0))
+    if with_ea:
+        torch.testing.assert_close(ed.grad.cpu().double(), er.grad, rtol=RTOL, atol=2e-6 * max(gs, 1.0))
 
 
 def test_arxiv_shape_properties():
