@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather"],
                     help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
+    ap.add_argument("--node-groups", type=int, default=0, help="transposed scheme: node groups (0 = library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,19 +145,59 @@ def main():
             return out
     else:
         from deep_gcns_torch_amd import dist as ddist
-        scheme = args.scheme
-        if scheme == "auto" and world == 1:
-            scheme = "transposed"
-        part = ddist.build_partition(ei, n, C, rank, world, scheme=scheme)
-        transposed = isinstance(part, ddist.TransposedGraph)
-        del ei
-        x = x_full[part.lo:part.hi].clone().requires_grad_(True)
-        g_loc = g_full[part.lo:part.hi].clone()
-        del x_full, g_full
+        x = g_loc = None
         extra = dict(pipeline_chunks=args.pipeline_chunks) if args.pipeline_chunks else {}
 
-        def fwd():
-            return ddist.aggregate(x, part, aggr=args.aggr, t=args.t, **extra)
+        def make(scheme, node_groups):
+            """(partition, x_local, g_local, fwd) for one exchange scheme; rows are re-sliced per scheme because the
+            row ownership (bounds) differs between them."""
+            part = ddist.build_partition(ei, n, C, rank, world, scheme=scheme, node_groups=node_groups)
+            xl = x_full[part.lo:part.hi].clone().requires_grad_(True)
+            gl = g_full[part.lo:part.hi].clone()
+            return part, xl, gl, (lambda: ddist.aggregate(xl, part, aggr=args.aggr, t=args.t, **extra))
+
+        def timed(fwd_fn, xl, gl, reps):
+            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                o = fwd_fn()
+                if not args.fwd_only:
+                    torch.autograd.grad(o, xl, gl)
+            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / reps * 1e3
+
+        wn_default = ddist.default_node_groups(C, world)
+        if args.scheme == "auto":
+            # the exchange is bound by the xGMI links and RCCL's per-collective efficiency: try the applicable schemes
+            # for a few untimed steps and keep the fastest (same choice on every rank: max-over-ranks timings)
+            cands = [("allgather", 1)]
+            if world > 1 or args.force_partitioned:
+                if ddist.transposed_supported(C, world, None, 1):
+                    cands.append(("transposed", 1))
+                if wn_default > 1 and ddist.transposed_supported(C, world, None, wn_default):
+                    cands.append(("transposed", wn_default))
+        else:
+            cands = [(args.scheme, args.node_groups or (wn_default if args.scheme == "transposed" else 1))]
+        tuned = {}
+        best = None
+        for sch, wn in cands:
+            cand = make(sch, wn)
+            if len(cands) > 1:
+                timed(cand[3], cand[1], cand[2], 2)
+                ms = timed(cand[3], cand[1], cand[2], 3)
+                tuned[f"{sch}/node_groups={wn}"] = round(ms, 3)
+                if best is None or ms < best[0]:
+                    best = (ms, sch, wn, cand)
+                else:
+                    del cand
+                torch.cuda.empty_cache()
+            else:
+                best = (0.0, sch, wn, cand)
+        _, scheme, node_groups, (part, x, g_loc, fwd) = best
+        transposed = isinstance(part, ddist.TransposedGraph)
+        del ei, x_full, g_full
 
         def step():
             out = fwd()
@@ -205,7 +246,10 @@ def main():
         if not partitioned:
             algo = fwd_bytes(E, n, C)
         else:
-            algo = fwd_bytes(E, n, C // world) if transposed else fwd_bytes(part.n_local_edges, part.hi - part.lo, C)
+            if transposed:
+                algo = fwd_bytes(part.n_edges, n // part.node_groups, C // part.channel_groups)
+            else:
+                algo = fwd_bytes(part.n_local_edges, part.hi - part.lo, C)
         achieved = algo / (fwd_ms_avg * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -234,8 +278,9 @@ def main():
                             f"{args.graph} random graph N={n} E={E} C={C}"
                             + (" [fwd only]" if args.fwd_only else ""),
                 "parallelism": ("single GPU" if not partitioned else
-                                (f"node-partitioned rows x{world}, channel-transposed exchange (RCCL all-to-all in/out, "
-                                 f"each rank aggregates all edges for C/{world} channels)" if transposed else
+                                (f"node-partitioned rows x{world}, channel-transposed exchange (RCCL all-to-all in/out; "
+                                 f"{part.node_groups} node group(s) x {part.channel_groups} channel group(s): each rank "
+                                 f"aggregates {part.n_edges} edges for {C // part.channel_groups} channels)" if transposed else
                                  f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd")),
             },
             "roofline": {
@@ -252,8 +297,10 @@ def main():
                 "launch_ms_min": fwd_ms[0],
                 "frac_of_measured_copy_6290GBs": achieved / 6290.0,
             },
-            "fwd_edges_per_s": (E if (not partitioned or transposed) else part.n_local_edges) / (fwd_ms_avg * 1e-3),
+            "fwd_edges_per_s": (E if not partitioned else (part.n_edges if transposed else part.n_local_edges)) / (fwd_ms_avg * 1e-3),
         }
+        if partitioned and tuned:
+            res["config"]["autotuned_ms_per_step"] = tuned
         if world == 1 and not partitioned and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t)
         print(json.dumps(res), flush=True)

@@ -400,9 +400,11 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
   int col0, eid0;
   load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
   for (int base = wave0 * R; base < n_items; base += stride) {
+#ifndef DGCN_NO_PREFETCH
     int coln, eidn;
     load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
     const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
+#endif
     for (int cb = 0; cb < C; cb += LPR * VEC) {
       const int c0ch = cb + cl * VEC;
       const bool act = c0ch < C;
@@ -530,17 +532,27 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
         }
       }
     }
+#ifndef DGCN_NO_PREFETCH
     w = wn;
     wn = wnn;
     col0 = coln;
     eid0 = eidn;
+#else
+    w = fetch_work<SW>(P.g, base + stride + sub, n_items);
+    load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+#endif
   }
 }
 
 // WITH_D (second moment for learnable t / p) is a kernel-level parameter: its extra accumulators must not
 // cost the common variant registers.  The message kind is a wave-uniform branch inside (same register budget).
+#ifdef DGCN_FWD_WPE
+#define DGCN_FWD_OCC __attribute__((amdgpu_waves_per_eu(DGCN_FWD_WPE, DGCN_FWD_WPE)))
+#else
+#define DGCN_FWD_OCC
+#endif
 template <int MODE, int VEC, int LPR, int SW, bool HAS_EA, bool WITH_D>
-__global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_kernel(const FwdParams P) {
+__global__ __launch_bounds__(kWgThreads) DGCN_FWD_OCC void gen_aggr_fwd_kernel(const FwdParams P) {
   if (P.msg == DGCN_MSG_RELU_EPS) {
     gen_aggr_fwd_body<MODE, VEC, LPR, SW, HAS_EA, true, WITH_D>(P);
   } else {

@@ -30,6 +30,11 @@ Per direction that is 2*N*C/W floats per rank instead of (W-1)*N*C/W: W-1 = 7 x 
 for graphs without locality, where the all-gather scheme is bound by the per-link xGMI rate.  It also
 load-balances any degree distribution exactly.  It needs edge-feature-free aggregation and C % (4*W) == 0;
 `aggregate(...)` picks the scheme.
+
+2-D form (``node_groups`` = Wn > 1, W = Wn * Wc): rank (a, b) aggregates channel block b (C/Wc channels) for the
+destination rows of node group a only.  Gathered rows stay >= 128 bytes when C/W would fall below 32 channels
+(C = 128 on 8 ranks: 4 channel groups x 2 node groups), at the price of a Wn-fold replicated input exchange and a
+sum over node groups in the backward exchange (both still all-to-all, no reduction collective).
 """
 from __future__ import annotations
 
@@ -242,22 +247,42 @@ def partitioned_gen_aggregate(x_local: torch.Tensor, part: PartitionedGraph, agg
 
 
 # ------------------------------------------------------------------------------------------------
-# channel-transposed scheme
+# channel-transposed scheme (optionally 2-D: node groups x channel groups)
 # ------------------------------------------------------------------------------------------------
 def equal_row_bounds(num_nodes: int, world: int) -> List[int]:
     return [num_nodes * r // world for r in range(world + 1)]
 
 
-class TransposedGraph:
-    """The WHOLE graph on every rank, source and destination ids in the padded row layout
-    (``owner * max_rows + local index``) that the equal-split all-to-all produces."""
+def default_node_groups(channels: int, world: int) -> int:
+    """Fewest node groups that keep a rank's channel block at >= 32 channels: a gathered row is then at least one
+    128-byte line (MI355X fetches whole lines: 16-channel rows cost the same HBM/MALL traffic as 32-channel ones)."""
+    wn = 1
+    while (world // wn) > 1 and channels // (world // wn) < 32 and world % (wn * 2) == 0:
+        wn *= 2
+    return wn
 
-    def __init__(self, graph: Graph, bounds: List[int], rank: int, world: int, max_rows: int):
-        self.graph = graph            # n_src = n_dst = world * max_rows
+
+class TransposedGraph:
+    """Rank (a, b) = (node group, channel group), rank = a * Wc + b, W = Wn * Wc.
+
+    It aggregates, for channel block b (C / Wc channels), the edges whose DESTINATION row belongs to node group a
+    (the rows owned by ranks a*Wc .. a*Wc+Wc-1), reading source rows of the whole graph.  Ids are in the padded
+    row layout ``owner * max_rows + local index`` that the equal-split all-to-all produces; destinations are
+    re-based to the group.  Wn = 1 is the pure channel transpose: every rank walks ALL edges for C / W channels."""
+
+    def __init__(self, graph: Graph, bounds: List[int], rank: int, world: int, max_rows: int, node_groups: int):
+        self.graph = graph            # n_src = world * max_rows, n_dst = channel_groups * max_rows
         self.bounds = bounds
         self.rank, self.world = rank, world
         self.lo, self.hi = bounds[rank], bounds[rank + 1]
         self.max_rows = max_rows
+        self.node_groups = node_groups
+        self.channel_groups = world // node_groups
+        self.node_group = rank // self.channel_groups
+        self.channel_group = rank % self.channel_groups
+        in_group = [mr if r // self.channel_groups == self.node_group else 0
+                    for r, mr in enumerate([max_rows] * world)]
+        self.group_splits = in_group  # rows exchanged with each rank in the group-local all-to-all
 
     @property
     def n_local(self) -> int:
@@ -269,9 +294,15 @@ class TransposedGraph:
 
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int,
-                        bounds: Optional[List[int]] = None, need_transpose: bool = True) -> "TransposedGraph":
+                        bounds: Optional[List[int]] = None, need_transpose: bool = True,
+                        node_groups: int = 1) -> "TransposedGraph":
+        assert world % node_groups == 0
+        wc = world // node_groups
         if bounds is None:
-            bounds = equal_row_bounds(num_nodes, world)   # every rank walks all edges: only rows need balancing
+            if node_groups == 1:      # every rank walks all edges: only the rows need balancing
+                bounds = equal_row_bounds(num_nodes, world)
+            else:                     # node groups split the edges by destination: balance in-edges
+                bounds = balanced_bounds(torch.bincount(edge_index[1], minlength=num_nodes), world)
         assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == num_nodes
         max_rows = max(max(bounds[r + 1] - bounds[r] for r in range(world)), 1)
         b = torch.tensor(bounds, device=edge_index.device, dtype=edge_index.dtype)
@@ -280,59 +311,97 @@ class TransposedGraph:
             owner = torch.bucketize(ids, b[1:], right=True)
             return owner * max_rows + (ids - b[owner])
 
-        g = Graph(padded(edge_index[0]), padded(edge_index[1]), n_src=world * max_rows, n_dst=world * max_rows,
-                  need_transpose=need_transpose)
-        return cls(g, list(bounds), rank, world, max_rows)
+        src, dst = padded(edge_index[0]), padded(edge_index[1])
+        if node_groups > 1:
+            a = rank // wc
+            mine = (dst >= a * wc * max_rows) & (dst < (a + 1) * wc * max_rows)
+            src, dst = src[mine], dst[mine] - a * wc * max_rows
+        g = Graph(src, dst, n_src=world * max_rows, n_dst=wc * max_rows, need_transpose=need_transpose)
+        return cls(g, list(bounds), rank, world, max_rows, node_groups)
 
 
-def _rows_to_channel_block(x_local: torch.Tensor, tg: TransposedGraph, lo: int, hi: int, group, async_op: bool):
-    """Node-owned rows (n_local, C) -> channels [rank*Cw+lo, rank*Cw+hi) of ALL rows, (world*max_rows, hi-lo)."""
-    world, mr, n_local = tg.world, tg.max_rows, tg.n_local
-    Cw = x_local.size(1) // world
-    send = x_local.new_zeros(world, mr, hi - lo) if n_local != mr else x_local.new_empty(world, mr, hi - lo)
-    send[:, :n_local] = x_local.view(n_local, world, Cw)[:, :, lo:hi].transpose(0, 1)
-    recv = x_local.new_empty(world * mr, hi - lo)
-    work = dist.all_to_all_single(recv, send.view(world * mr, hi - lo), group=group, async_op=async_op)
+def _replicate_rows_to_blocks(x_local: torch.Tensor, tg: TransposedGraph, lo: int, hi: int, group, async_op: bool):
+    """Node-owned rows (n_local, C) -> sub-block [lo, hi) of this rank's channel block for ALL rows,
+    (world*max_rows, hi-lo).  Every node group gets its own copy (Wn-fold replication of the send)."""
+    world, mr, n_local, wc, wn = tg.world, tg.max_rows, tg.n_local, tg.channel_groups, tg.node_groups
+    Cw = x_local.size(1) // wc
+    cs = hi - lo
+    send = x_local.new_zeros(wn, wc, mr, cs) if n_local != mr else x_local.new_empty(wn, wc, mr, cs)
+    send[:, :, :n_local] = x_local.view(n_local, wc, Cw)[:, :, lo:hi].transpose(0, 1).unsqueeze(0)
+    recv = x_local.new_empty(world * mr, cs)
+    work = dist.all_to_all_single(recv, send.view(world * mr, cs), group=group, async_op=async_op)
     return recv, work
 
 
-def _channel_block_to_rows(y: torch.Tensor, group, async_op: bool):
-    """(world*max_rows, cs) block of all rows -> (world, max_rows, cs): [r] = my rows, rank r's channels."""
+def _sum_blocks_into_rows(dst_local: torch.Tensor, y: torch.Tensor, tg: TransposedGraph, lo: int, hi: int, group):
+    """Adjoint of ``_replicate_rows_to_blocks``: y (world*max_rows, cs) = this rank's values for all rows; every row
+    owner receives the Wn x Wc pieces of its rows, sums over node groups and places the channel blocks."""
     recv = torch.empty_like(y)
-    work = dist.all_to_all_single(recv, y.contiguous(), group=group, async_op=async_op)
+    work = dist.all_to_all_single(recv, y.contiguous(), group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        world, mr, n_local, wc, wn = tg.world, tg.max_rows, tg.n_local, tg.channel_groups, tg.node_groups
+        Cw = dst_local.size(1) // wc
+        pieces = recv.view(wn, wc, mr, hi - lo)
+        summed = pieces[0] if wn == 1 else pieces.sum(0)
+        dst_local.view(n_local, wc, Cw)[:, :, lo:hi] = summed[:, :n_local].transpose(0, 1)
+    return finish
+
+
+def _group_blocks_to_rows(dst_local: torch.Tensor, y: torch.Tensor, tg: TransposedGraph, lo: int, hi: int, group):
+    """y (Wc*max_rows, cs) = rows of this rank's node group, its channel sub-block -> each row owner in the group
+    receives the Wc channel blocks of its rows (all-to-all inside the node group; other ranks exchange nothing)."""
+    recv = torch.empty_like(y)
+    sp = tg.group_splits
+    work = dist.all_to_all_single(recv, y.contiguous(), output_split_sizes=sp, input_split_sizes=sp, group=group,
+                                  async_op=True)
+
+    def finish():
+        work.wait()
+        mr, n_local, wc = tg.max_rows, tg.n_local, tg.channel_groups
+        Cw = dst_local.size(1) // wc
+        dst_local.view(n_local, wc, Cw)[:, :, lo:hi] = recv.view(wc, mr, hi - lo)[:, :n_local].transpose(0, 1)
+    return finish
+
+
+def _group_rows_to_blocks(g_local: torch.Tensor, tg: TransposedGraph, lo: int, hi: int, group, async_op: bool):
+    """Adjoint of ``_group_blocks_to_rows``: node-owned rows (n_local, C) -> (Wc*max_rows, cs) rows of the node
+    group for this rank's channel sub-block."""
+    mr, n_local, wc = tg.max_rows, tg.n_local, tg.channel_groups
+    Cw = g_local.size(1) // wc
+    cs = hi - lo
+    send = g_local.new_zeros(wc, mr, cs) if n_local != mr else g_local.new_empty(wc, mr, cs)
+    send[:, :n_local] = g_local.view(n_local, wc, Cw)[:, :, lo:hi].transpose(0, 1)
+    recv = g_local.new_empty(wc * mr, cs)
+    sp = tg.group_splits
+    work = dist.all_to_all_single(recv, send.view(wc * mr, cs), output_split_sizes=sp, input_split_sizes=sp,
+                                  group=group, async_op=async_op)
     return recv, work
-
-
-def _scatter_block_into_rows(dst_local: torch.Tensor, recv: torch.Tensor, tg: TransposedGraph, lo: int, hi: int):
-    world, mr, n_local = tg.world, tg.max_rows, tg.n_local
-    Cw = dst_local.size(1) // world
-    dst_local.view(n_local, world, Cw)[:, :, lo:hi] = recv.view(world, mr, hi - lo)[:, :n_local].transpose(0, 1)
 
 
 class _TransposedAggregate(torch.autograd.Function):
-    """all_to_all (rows -> channel block) -> local aggregation over ALL edges -> all_to_all back, pipelined
-    over sub-blocks of the rank's channel block so the exchanges overlap the kernels (see module docstring)."""
+    """all_to_all (rows -> channel block) -> local aggregation -> all_to_all back, pipelined over sub-blocks of the
+    rank's channel block so the exchanges overlap the kernels (see module docstring)."""
 
     @staticmethod
     def forward(ctx, x_local, tg, group, local_aggregate, aggr, kw, nchunk):
-        world = tg.world
         n_local, C = x_local.shape
         x_local = x_local.contiguous()
-        cuts = _channel_chunks(C // world, nchunk)
-        ins = [_rows_to_channel_block(x_local, tg, lo, hi, group, True) for lo, hi in cuts]
+        cuts = _channel_chunks(C // tg.channel_groups, nchunk)
+        ins = [_replicate_rows_to_blocks(x_local, tg, lo, hi, group, True) for lo, hi in cuts]
         out_local = x_local.new_empty(n_local, C)
-        leaves, outs, backs = [], [], []
-        for (blk, w) in ins:
+        leaves, outs, finishers = [], [], []
+        for (lo, hi), (blk, w) in zip(cuts, ins):
             w.wait()
             with torch.enable_grad():
                 leaf = blk.requires_grad_(x_local.requires_grad)
                 out = local_aggregate(leaf, tg.graph, aggr=aggr, **kw)
             leaves.append(leaf)
             outs.append(out)
-            backs.append(_channel_block_to_rows(out.detach(), group, True))
-        for (lo, hi), (recv, w) in zip(cuts, backs):
-            w.wait()
-            _scatter_block_into_rows(out_local, recv, tg, lo, hi)
+            finishers.append(_group_blocks_to_rows(out_local, out.detach(), tg, lo, hi, group))
+        for fin in finishers:
+            fin()
         ctx.tg, ctx.group, ctx.cuts = tg, group, cuts
         ctx.leaves, ctx.outs = leaves, outs
         return out_local
@@ -341,45 +410,45 @@ class _TransposedAggregate(torch.autograd.Function):
     def backward(ctx, g):
         tg, group, cuts = ctx.tg, ctx.group, ctx.cuts
         g = g.contiguous()
-        ins = [_rows_to_channel_block(g, tg, lo, hi, group, True) for lo, hi in cuts]
+        ins = [_group_rows_to_blocks(g, tg, lo, hi, group, True) for lo, hi in cuts]
         grad_local = g.new_empty(g.shape)
-        backs = []
-        for (gblk, w), leaf, out in zip(ins, ctx.leaves, ctx.outs):
+        finishers = []
+        for (lo, hi), (gblk, w), leaf, out in zip(cuts, ins, ctx.leaves, ctx.outs):
             w.wait()
             if out.requires_grad:
                 gfull, = torch.autograd.grad(out, leaf, gblk)
-            else:                                         # graph without edges
+            else:                                         # no local edges
                 gfull = torch.zeros_like(leaf)
-            backs.append(_channel_block_to_rows(gfull, group, True))
-        for (lo, hi), (recv, w) in zip(cuts, backs):
-            w.wait()
-            _scatter_block_into_rows(grad_local, recv, tg, lo, hi)
+            finishers.append(_sum_blocks_into_rows(grad_local, gfull, tg, lo, hi, group))
+        for fin in finishers:
+            fin()
         ctx.leaves = ctx.outs = None
         return grad_local, None, None, None, None, None, None
 
 
-def transposed_supported(C: int, world: int, edge_attr=None) -> bool:
-    return edge_attr is None and C % (4 * world) == 0
+def transposed_supported(C: int, world: int, edge_attr=None, node_groups: int = 1) -> bool:
+    return edge_attr is None and world % node_groups == 0 and C % (4 * (world // node_groups)) == 0
 
 
 def transposed_gen_aggregate(x_local: torch.Tensor, tg: TransposedGraph, aggr: str = "softmax", group=None,
                              local_aggregate=None, pipeline_chunks: Optional[int] = None, **kw) -> torch.Tensor:
     """Aggregation of this rank's rows through the channel-transposed exchange; ``x_local`` = this rank's
-    feature rows ``x[tg.lo:tg.hi]`` (n_local, C) with C % (4*world) == 0, no edge features, t/p not learnable
-    (their gradients would need a cross-rank sum: use the all-gather scheme for those)."""
+    feature rows ``x[tg.lo:tg.hi]`` (n_local, C) with C % (4*channel_groups) == 0, no edge features, t/p not
+    learnable (their gradients would need a cross-rank sum: use the all-gather scheme for those)."""
     if local_aggregate is None:
         from . import ops
         local_aggregate = ops.gen_aggregate
     C = x_local.size(1)
-    if not transposed_supported(C, tg.world, kw.get("edge_attr")):
-        raise ValueError(f"channel-transposed scheme needs no edge features and C % (4*world) == 0 (C={C}, world={tg.world})")
+    if not transposed_supported(C, tg.world, kw.get("edge_attr"), tg.node_groups):
+        raise ValueError("channel-transposed scheme needs no edge features and C % (4*channel_groups) == 0 "
+                         f"(C={C}, world={tg.world}, node_groups={tg.node_groups})")
     if kw.get("learn_t") or kw.get("learn_p"):
         raise ValueError("learnable t/p: use the all-gather scheme (partitioned_gen_aggregate)")
     if x_local.size(0) != tg.n_local:
         raise ValueError(f"x_local has {x_local.size(0)} rows, this rank owns {tg.n_local}")
     if pipeline_chunks is None:
         # sub-blocks narrower than 32 channels (one 128-byte line per gathered row) waste gather bandwidth
-        pipeline_chunks = max(1, min(4, (C // tg.world) // 32))
+        pipeline_chunks = max(1, min(4, (C // tg.channel_groups) // 32))
     return _TransposedAggregate.apply(x_local, tg, group, local_aggregate, aggr, kw, pipeline_chunks)
 
 
@@ -391,13 +460,19 @@ def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **
 
 
 def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, rank: int, world: int,
-                    scheme: str = "auto", edge_attr=None, need_transpose: bool = True):
-    """``scheme``: "transposed", "allgather" or "auto" (transposed whenever it applies: it moves W-1 times
-    fewer bytes per rank; graphs whose partitions reference few remote rows are the all-gather scheme's case)."""
+                    scheme: str = "auto", edge_attr=None, need_transpose: bool = True,
+                    node_groups: Optional[int] = None):
+    """``scheme``: "transposed", "allgather" or "auto" (transposed whenever it applies: it moves several times
+    fewer bytes per rank; graphs whose partitions reference few remote rows are the all-gather scheme's case).
+    ``node_groups`` (transposed only): None = ``default_node_groups(channels, world)``."""
+    if node_groups is None:
+        node_groups = default_node_groups(channels, world)
     if scheme == "auto":
-        scheme = "transposed" if (world > 1 and transposed_supported(channels, world, edge_attr)) else "allgather"
+        ok = world > 1 and transposed_supported(channels, world, edge_attr, node_groups)
+        scheme = "transposed" if ok else "allgather"
     if scheme == "transposed":
-        return TransposedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
+        return TransposedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose,
+                                               node_groups=node_groups)
     if scheme == "allgather":
         return PartitionedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
     raise ValueError(f"unknown scheme {scheme!r}")

@@ -110,7 +110,7 @@ def test_balanced_bounds_and_padded_remap():
     assert max(shares) < 1.05 * (u.size(1) / 8)
 
 
-def _worker_transposed(rank, world, port, aggr, kw, q, chunks):
+def _worker_transposed(rank, world, port, aggr, kw, q, chunks, node_groups=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -121,12 +121,13 @@ def _worker_transposed(rank, world, port, aggr, kw, q, chunks):
         g = torch.Generator().manual_seed(5)
         x = torch.randn(n, C, generator=g, dtype=torch.float64)
         probe = torch.randn(n, C, generator=g, dtype=torch.float64)
-        tg = TransposedGraph.from_edge_index(ei, n, rank, world)
-        assert tg.n_edges == ei.size(1)                       # every rank holds the whole graph
+        tg = TransposedGraph.from_edge_index(ei, n, rank, world, node_groups=node_groups)
+        if node_groups == 1:
+            assert tg.n_edges == ei.size(1)                   # every rank holds the whole graph
         xl = x[tg.lo:tg.hi].clone().requires_grad_(True)
         out = transposed_gen_aggregate(xl, tg, aggr=aggr, local_aggregate=_oracle_local, pipeline_chunks=chunks, **kw)
         (out * probe[tg.lo:tg.hi]).sum().backward()
-        q.put((rank, tg.bounds, out.detach(), xl.grad.detach(), tg.max_rows))
+        q.put((rank, tg.bounds, out.detach(), xl.grad.detach(), tg.max_rows, tg.n_edges))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -178,3 +179,34 @@ def test_transposed_graph_padded_ids_round_trip():
             assert torch.equal(torch.sort(src * 1000 + dst).values, torch.sort(ei[0] * 1000 + ei[1]).values)
     assert transposed_supported(128, 8) and not transposed_supported(100, 8)
     assert not transposed_supported(128, 8, edge_attr=torch.zeros(1))
+
+
+@pytest.mark.parametrize("world,node_groups,aggr,kw,chunks", [(4, 2, "softmax", dict(t=0.7), 1), (4, 2, "max", {}, 2),
+                                                             (2, 2, "power", dict(p=2.0), 1), (4, 4, "mean", {}, 1)])
+def test_two_dimensional_transposed_aggregate_matches_single_process(world, node_groups, aggr, kw, chunks):
+    """node groups x channel groups: replicated input all-to-all, group-local output all-to-all (uneven splits),
+    and in the backward the sum over node groups.  (4,4) and (2,2) degenerate to pure node partitioning."""
+    from oracle import sparse_ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transposed, args=(r, world, port, aggr, kw, q, chunks, node_groups))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    ref = sparse_ref.gen_propagate(x, ei, aggr=aggr, **kw)
+    (ref * probe).sum().backward()
+    wc = world // node_groups
+    # each node group holds every edge exactly once (per channel group)
+    assert sum(r[5] for r in res) == wc * ei.size(1)
+    torch.testing.assert_close(torch.cat([r[2] for r in res]), ref.detach(), rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(torch.cat([r[3] for r in res]), x.grad, rtol=1e-10, atol=1e-12)
