@@ -86,6 +86,16 @@ _SIGNATURES = {
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
+    "dgcn_rows_num_partials": (C.c_int32, [C.c_int64, C.c_int32]),
+    "dgcn_rows_stats_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dgcn_rows_bn_apply_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_void_p]),
+    "dgcn_rows_bn_bwd_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_bn_bwd_finalize_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_void_p,
+                                                C.c_void_p]),
+    "dgcn_rows_bn_bwd_apply_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,350 @@
+// Node-wise normalisation of (rows, C) feature matrices for gfx950: BatchNorm1d (training and eval) with an
+// optional fused ReLU, forward and backward.
+//
+// Replaces nn.BatchNorm1d as returned by norm_layer('batch', C)   gcn_lib/sparse/torch_nn.py:23-34
+// and the Lin -> BatchNorm1d -> ReLU run inside MLP               gcn_lib/sparse/torch_nn.py:50-71
+// around GENConv (examples/ogb/ogbn_arxiv/model.py:90-106: norm -> relu -> dropout -> conv -> residual).
+//
+// All kernels are HBM streaming passes over row-major data; a thread owns one VEC-wide channel group, so the
+// per-channel coefficients live in registers and every access is a coalesced 16-byte load:
+//   forward  : rows_stats (read x)               -> partial sums  -> dgcn_bn_finalize_f32 (dense_bn.hip)
+//              rows_bn_apply (read x, write y)      y = [relu](scale*x + shift)
+//   backward : rows_bn_bwd_stats (read g, x[, y]) -> partial sums of g' and g'*xhat, g' = g*[y>0]
+//              rows_bn_bwd_finalize                 dgamma, dbeta, the two batch-mean coefficients
+//              rows_bn_bwd_apply (read g, x[, y], write dx)   dx = scale*(g' - c1 - xhat*c2)
+// Sums are accumulated per workgroup in a fixed order and combined in fp64: deterministic.
+
+#include "dgcn_common.h"
+
+namespace dgcn {
+namespace {
+
+constexpr int kMaxParts = 512;
+constexpr int kFinThreads = 1024;
+constexpr int kFinTile = 64;
+constexpr int kFinRows = kFinThreads / kFinTile;
+
+struct RowsGeom {
+  int cg;    // channel groups per row (C / VEC)
+  int rpp;   // rows per pass of one workgroup (256 / cg)
+};
+
+__host__ __device__ inline RowsGeom rows_geom(int C, int vec) {
+  RowsGeom g;
+  g.cg = C / vec;
+  g.rpp = kWgThreads / g.cg;
+  return g;
+}
+
+// ---- forward statistics: partial[wg][0][c] = sum x, partial[wg][1][c] = sum x^2 over the workgroup's row slab
+template <int VEC>
+__global__ __launch_bounds__(kWgThreads) void rows_stats_kernel(const float* __restrict__ x, int64_t ld, int64_t rows,
+                                                               int C, float* __restrict__ partial, int64_t slab) {
+  __shared__ float red[2][kWgThreads * VEC];
+  const RowsGeom G = rows_geom(C, VEC);
+  const int cgi = threadIdx.x % G.cg;
+  const int rl = threadIdx.x / G.cg;
+  const int64_t r0 = blockIdx.x * slab;
+  const int64_t r1 = min(rows, r0 + slab);
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (rl < G.rpp) {
+    const float* p = x + cgi * VEC;
+    int64_t r = r0 + rl;
+    for (; r + 3 * G.rpp < r1; r += 4 * G.rpp) {   // four independent loads in flight
+      float a[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load_vec<VEC>(a[u], p + (r + static_cast<int64_t>(u) * G.rpp) * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s[j] += a[u][j]; q[j] = fmaf(a[u][j], a[u][j], q[j]); }
+      }
+    }
+    for (; r < r1; r += G.rpp) {
+      float a[VEC];
+      load_vec<VEC>(a, p + r * ld);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += a[j]; q[j] = fmaf(a[j], a[j], q[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][(rl * G.cg + cgi) * VEC + j] = s[j];
+    red[1][(rl * G.cg + cgi) * VEC + j] = q[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kWgThreads) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < G.rpp; ++k) { t0 += red[0][k * C + c]; t1 += red[1][k * C + c]; }   // fixed order
+    partial[(static_cast<int64_t>(blockIdx.x) * 2) * C + c] = t0;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = t1;
+  }
+}
+
+// ---- forward apply: y = [relu](scale*x + shift)
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(kWgThreads) void rows_bn_apply_kernel(const float* __restrict__ x, int64_t ld,
+                                                                  const float* __restrict__ bnbuf,
+                                                                  float* __restrict__ y, int64_t rows, int C) {
+  const RowsGeom G = rows_geom(C, VEC);
+  const int cgi = threadIdx.x % G.cg;
+  const int rl = threadIdx.x / G.cg;
+  if (rl >= G.rpp) return;
+  float sc[VEC], sh[VEC];
+  load_vec<VEC>(sc, bnbuf + cgi * VEC);
+  load_vec<VEC>(sh, bnbuf + C + cgi * VEC);
+  const int64_t step = static_cast<int64_t>(gridDim.x) * G.rpp;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * G.rpp + rl; r < rows; r += step) {
+    float a[VEC], o[VEC];
+    load_vec<VEC>(a, x + r * ld + cgi * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      o[j] = fmaf(a[j], sc[j], sh[j]);
+      if (RELU) o[j] = fmaxf(o[j], 0.f);
+    }
+    store_vec<VEC>(y + r * C + cgi * VEC, o);
+  }
+}
+
+// ---- backward statistics: partial[wg][0][c] = sum g', partial[wg][1][c] = sum g'*xhat
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(kWgThreads) void rows_bn_bwd_stats_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ x, int64_t ld,
+                                                                      const float* __restrict__ y,
+                                                                      const float* __restrict__ bnbuf, int64_t rows,
+                                                                      int C, float* __restrict__ partial,
+                                                                      int64_t slab) {
+  __shared__ float red[2][kWgThreads * VEC];
+  const RowsGeom G = rows_geom(C, VEC);
+  const int cgi = threadIdx.x % G.cg;
+  const int rl = threadIdx.x / G.cg;
+  const int64_t r0 = blockIdx.x * slab;
+  const int64_t r1 = min(rows, r0 + slab);
+  float s[VEC], q[VEC], mean[VEC], istd[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; mean[j] = 0.f; istd[j] = 0.f; }
+  if (rl < G.rpp) {
+    load_vec<VEC>(mean, bnbuf + 2 * C + cgi * VEC);
+    load_vec<VEC>(istd, bnbuf + 3 * C + cgi * VEC);
+    for (int64_t r = r0 + rl; r < r1; r += 2 * G.rpp) {
+      float gg[2][VEC], xx[2][VEC], yy[2][VEC];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t rr = r + static_cast<int64_t>(u) * G.rpp;
+        ok[u] = rr < r1;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { gg[u][j] = 0.f; xx[u][j] = 0.f; yy[u][j] = 1.f; }
+        if (ok[u]) {
+          load_vec<VEC>(gg[u], g + rr * C + cgi * VEC);
+          load_vec<VEC>(xx[u], x + rr * ld + cgi * VEC);
+          if (RELU) load_vec<VEC>(yy[u], y + rr * C + cgi * VEC);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float gp = (RELU && !(yy[u][j] > 0.f)) ? 0.f : gg[u][j];
+          const float xh = (xx[u][j] - mean[j]) * istd[j];
+          s[j] += gp;
+          q[j] = fmaf(gp, xh, q[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    red[0][(rl * G.cg + cgi) * VEC + j] = s[j];
+    red[1][(rl * G.cg + cgi) * VEC + j] = q[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kWgThreads) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < G.rpp; ++k) { t0 += red[0][k * C + c]; t1 += red[1][k * C + c]; }
+    partial[(static_cast<int64_t>(blockIdx.x) * 2) * C + c] = t0;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = t1;
+  }
+}
+
+// ---- backward finalize: coef[0] = dgamma = sum g'*xhat, coef[1] = dbeta = sum g', coef[2] = c1, coef[3] = c2
+__global__ __launch_bounds__(kFinThreads) void rows_bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                          int nparts, int C, double count,
+                                                                          int training, float* __restrict__ coef) {
+  __shared__ double red[kFinRows][2][kFinTile];
+  const int cc = threadIdx.x % kFinTile;
+  const int r = threadIdx.x / kFinTile;
+  for (int c0 = 0; c0 < C; c0 += kFinTile) {
+    const int c = c0 + cc;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+#pragma unroll 4
+      for (int p = r; p < nparts; p += kFinRows) {
+        s1 += static_cast<double>(partial[(static_cast<int64_t>(p) * 2) * C + c]);
+        s2 += static_cast<double>(partial[(static_cast<int64_t>(p) * 2 + 1) * C + c]);
+      }
+    }
+    red[r][0][cc] = s1;
+    red[r][1][cc] = s2;
+    __syncthreads();
+    if (r == 0 && c < C) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int q = 0; q < kFinRows; ++q) { t1 += red[q][0][cc]; t2 += red[q][1][cc]; }
+      coef[c] = static_cast<float>(t2);
+      coef[C + c] = static_cast<float>(t1);
+      coef[2 * C + c] = training ? static_cast<float>(t1 / count) : 0.f;
+      coef[3 * C + c] = training ? static_cast<float>(t2 / count) : 0.f;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- backward apply: dx = scale*(g' - c1 - xhat*c2)
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(kWgThreads) void rows_bn_bwd_apply_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ x, int64_t ld,
+                                                                      const float* __restrict__ y,
+                                                                      const float* __restrict__ bnbuf,
+                                                                      const float* __restrict__ coef,
+                                                                      float* __restrict__ dx, int64_t rows, int C) {
+  const RowsGeom G = rows_geom(C, VEC);
+  const int cgi = threadIdx.x % G.cg;
+  const int rl = threadIdx.x / G.cg;
+  if (rl >= G.rpp) return;
+  float sc[VEC], mean[VEC], istd[VEC], c1[VEC], c2[VEC];
+  load_vec<VEC>(sc, bnbuf + cgi * VEC);
+  load_vec<VEC>(mean, bnbuf + 2 * C + cgi * VEC);
+  load_vec<VEC>(istd, bnbuf + 3 * C + cgi * VEC);
+  load_vec<VEC>(c1, coef + 2 * C + cgi * VEC);
+  load_vec<VEC>(c2, coef + 3 * C + cgi * VEC);
+  const int64_t step = static_cast<int64_t>(gridDim.x) * G.rpp;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * G.rpp + rl; r < rows; r += step) {
+    float gg[VEC], xx[VEC], yy[VEC], o[VEC];
+    load_vec<VEC>(gg, g + r * C + cgi * VEC);
+    load_vec<VEC>(xx, x + r * ld + cgi * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) yy[j] = 1.f;
+    if (RELU) load_vec<VEC>(yy, y + r * C + cgi * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float gp = (RELU && !(yy[j] > 0.f)) ? 0.f : gg[j];
+      const float xh = (xx[j] - mean[j]) * istd[j];
+      o[j] = sc[j] * (gp - c1[j] - xh * c2[j]);
+    }
+    store_vec<VEC>(dx + r * C + cgi * VEC, o);
+  }
+}
+
+int pick_vec(int C, int64_t ld, const void* a, const void* b, const void* c, const void* d) {
+  auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (C % 4 == 0 && C / 4 <= kWgThreads && ld % 4 == 0 && al(a) && al(b) && al(c) && al(d)) return 4;
+  return 1;
+}
+
+int stream_grid(int64_t rows, int rpp) {
+  int64_t wgs = (rows + rpp - 1) / rpp;
+  const int64_t cap = static_cast<int64_t>(kNumCU) * 16;
+  if (wgs > cap) wgs = cap;
+  return static_cast<int>(wgs < 1 ? 1 : wgs);
+}
+
+}  // namespace
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int32_t dgcn_rows_num_partials(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int64_t want = (rows + 63) / 64;   // at least 64 rows per workgroup
+  return static_cast<int32_t>(want < kMaxParts ? want : kMaxParts);
+}
+
+extern "C" int dgcn_rows_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t C, float* partial,
+                                   void* stream) {
+  if (!x || !partial) return DGCN_E_NULL;
+  if (rows <= 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  const int vec = pick_vec(C, ld, x, nullptr, nullptr, nullptr);
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const int nparts = dgcn_rows_num_partials(rows, C);
+  const int64_t slab = (rows + nparts - 1) / nparts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec == 4) {
+    hipLaunchKernelGGL(rows_stats_kernel<4>, dim3(nparts), dim3(kWgThreads), 0, s, x, ld, rows, C, partial, slab);
+  } else {
+    hipLaunchKernelGGL(rows_stats_kernel<1>, dim3(nparts), dim3(kWgThreads), 0, s, x, ld, rows, C, partial, slab);
+  }
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_bn_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu, float* y,
+                                      int64_t rows, int32_t C, void* stream) {
+  if (!x || !bnbuf || !y) return DGCN_E_NULL;
+  if (rows < 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  if (rows == 0) return DGCN_OK;
+  const int vec = pick_vec(C, ld, x, y, bnbuf, nullptr);
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const RowsGeom G = rows_geom(C, vec);
+  const int grid = stream_grid(rows, G.rpp);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec == 4) {
+    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<4, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+    else hipLaunchKernelGGL((rows_bn_apply_kernel<4, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+  } else {
+    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<1, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+    else hipLaunchKernelGGL((rows_bn_apply_kernel<1, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+  }
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_bn_bwd_stats_f32(const float* g, const float* x, int64_t ld, const float* y,
+                                          const float* bnbuf, float* partial, int64_t rows, int32_t C,
+                                          void* stream) {
+  if (!g || !x || !bnbuf || !partial) return DGCN_E_NULL;
+  if (rows <= 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  const int vec = pick_vec(C, ld, x, g, y, bnbuf);
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const int nparts = dgcn_rows_num_partials(rows, C);
+  const int64_t slab = (rows + nparts - 1) / nparts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec == 4) {
+    if (y) hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<4, true>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
+    else hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<4, false>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
+  } else {
+    if (y) hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<1, true>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
+    else hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<1, false>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
+  }
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, double count,
+                                             int32_t training, float* coef, void* stream) {
+  if (!partial || !coef) return DGCN_E_NULL;
+  if (C <= 0 || nparts <= 0 || count <= 0.0) return DGCN_E_SHAPE;
+  hipLaunchKernelGGL(rows_bn_bwd_finalize_kernel, dim3(1), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream),
+                     partial, nparts, C, count, training, coef);
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* y,
+                                          const float* bnbuf, const float* coef, float* dx, int64_t rows,
+                                          int32_t C, void* stream) {
+  if (!g || !x || !bnbuf || !coef || !dx) return DGCN_E_NULL;
+  if (rows < 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  if (rows == 0) return DGCN_OK;
+  int vec = pick_vec(C, ld, x, g, y, dx);
+  if (vec == 4 && ((reinterpret_cast<uintptr_t>(bnbuf) | reinterpret_cast<uintptr_t>(coef)) & 15u)) vec = 1;
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const RowsGeom G = rows_geom(C, vec);
+  const int grid = stream_grid(rows, G.rpp);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec == 4) {
+    if (y) hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<4, true>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
+    else hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<4, false>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
+  } else {
+    if (y) hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<1, true>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
+    else hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<1, false>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
+  }
+  return launch_status();
+}

@@ -1,13 +1,15 @@
-"""Node-wise building blocks of the sparse library (stock PyTorch; not on the named hot path).
+"""Node-wise building blocks of the sparse library (library GEMMs; BatchNorm1d [+ReLU] on the HIP row kernels).
 
 Mirrors the public surface of the reference's gcn_lib/sparse/torch_nn.py -- act_layer :9-20,
 norm_layer :23-34, MultiSeq :37-47, MLP :50-71, AtomEncoder :74-92, BondEncoder :95-113 --
 with identical constructor signatures and ``state_dict`` keys (Sequential indices: Linear,
 norm, act, [dropout] per hidden layer; nothing after the last Linear when ``last_lin``).
 """
+import torch
 from torch import nn
 
 from ...nn_util import TallLinear
+from ...node_ops import BatchNorm1d
 from ...utils.data_util import get_atom_feature_dims, get_bond_feature_dims
 
 __all__ = ["act_layer", "norm_layer", "MultiSeq", "MLP", "AtomEncoder", "BondEncoder"]
@@ -29,7 +31,7 @@ def norm_layer(norm_type, nc):
     """1-D normalisation factory: batch | layer | instance."""
     kind = norm_type.lower()
     if kind == "batch":
-        return nn.BatchNorm1d(nc, affine=True)
+        return BatchNorm1d(nc, affine=True)          # an nn.BatchNorm1d; (rows, C) inputs run on the HIP kernels
     if kind == "layer":
         return nn.LayerNorm(nc, elementwise_affine=True)
     if kind == "instance":
@@ -70,6 +72,21 @@ class MLP(nn.Sequential):
                 stages.append(nn.Dropout2d(drop))
         self.m = stages
         super().__init__(*stages)
+
+    def forward(self, x):
+        # same stage order as nn.Sequential; BatchNorm1d directly followed by ReLU runs as one fused kernel pair
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, BatchNorm1d) and i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                    and isinstance(x, torch.Tensor) and x.dim() == 2):
+                x = m(x, fuse_relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class _SumOfEmbeddings(nn.Module):

@@ -274,6 +274,37 @@ int dgcn_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, do
 int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int32_t C, float* dst, int64_t ld,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Node-wise BatchNorm1d on row-major (rows, C) features, optional fused ReLU  (SURVEY.md §8 f1).
+ * Replaces nn.BatchNorm1d from norm_layer('batch', C) (gcn_lib/sparse/torch_nn.py:23-34) and the
+ * Lin -> BatchNorm1d -> ReLU run inside MLP (gcn_lib/sparse/torch_nn.py:50-71).
+ *   forward : dgcn_rows_stats_f32 -> dgcn_bn_finalize_f32 (above; count = rows) -> dgcn_rows_bn_apply_f32
+ *   backward: dgcn_rows_bn_bwd_stats_f32 -> dgcn_rows_bn_bwd_finalize_f32 -> dgcn_rows_bn_bwd_apply_f32
+ * x has row stride ld (floats); g, y, dx are contiguous (rows, C).  C % 4 == 0 with 16-byte aligned pointers takes
+ * the float4 path (C <= 1024), anything else a scalar path (C <= 256).  y (the forward output) is only read as the
+ * ReLU mask [y > 0]; pass NULL when no ReLU was fused.
+ * ------------------------------------------------------------------------------------ */
+int32_t dgcn_rows_num_partials(int64_t rows, int32_t C);
+
+/* partial [dgcn_rows_num_partials][2][C] = per-workgroup sum x, sum x^2 (fixed order). */
+int dgcn_rows_stats_f32(const float* x, int64_t ld, int64_t rows, int32_t C, float* partial, void* stream);
+
+/* y = scale*x + shift (bnbuf rows 0,1), then max(.,0) when relu != 0. */
+int dgcn_rows_bn_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu, float* y,
+                           int64_t rows, int32_t C, void* stream);
+
+/* partial [nparts][2][C] = sum g', sum g'*xhat with g' = g*[y>0] and xhat = (x-mean)*invstd (bnbuf rows 2,3). */
+int dgcn_rows_bn_bwd_stats_f32(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
+                               float* partial, int64_t rows, int32_t C, void* stream);
+
+/* coef [4][C] = dgamma, dbeta, c1 = sum g'/count, c2 = sum g'*xhat/count (c1 = c2 = 0 when training == 0). */
+int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, double count,
+                                  int32_t training, float* coef, void* stream);
+
+/* dx = scale*(g' - c1 - xhat*c2). */
+int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
+                               const float* coef, float* dx, int64_t rows, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""GPU: node-wise BatchNorm1d [+ReLU] HIP kernels (csrc/rows_norm.hip) against stock torch.nn.BatchNorm1d evaluated
+on the CPU in float64 -- outputs, running statistics, and all three gradients; training and eval; float4 and scalar
+layouts; strided rows.  Tolerance 1e-5 relative (fp32 op, fp64 reference)."""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _ref(x, bn_ref, relu, probe):
+    xr = x.double().requires_grad_(True)
+    y = bn_ref(xr)
+    if relu:
+        y = torch.relu(y)
+    (y * probe.double()).sum().backward()
+    return y.detach(), xr.grad
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 128), (4097, 256), (777, 100), (513, 50), (64, 7), (2, 128), (169343, 128)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_rows_matches_torch(rows, C, training, relu):
+    from deep_gcns_torch_amd.node_ops import BatchNorm1d
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows * 31 + C)
+    x = torch.randn(rows, C, generator=g) * 1.7 + 0.3
+    probe = torch.randn(rows, C, generator=g)
+    ref = nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, generator=g).double())
+        ref.bias.copy_(torch.randn(C, generator=g).double())
+        ref.running_mean.copy_(torch.randn(C, generator=g).double() * 0.1)
+        ref.running_var.copy_(torch.rand(C, generator=g).double() + 0.5)
+    ours = BatchNorm1d(C)
+    ours.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    ours = ours.to(dev)
+    ref.train(training)
+    ours.train(training)
+    y_ref, gx_ref = _ref(x, ref, relu, probe)
+    xd = x.to(dev).requires_grad_(True)
+    y = ours(xd, fuse_relu=relu) if relu else ours(xd)
+    (y * probe.to(dev)).sum().backward()
+    scale = max(1.0, float(y_ref.abs().max()))
+    torch.testing.assert_close(y.detach().cpu().double(), y_ref, rtol=RTOL, atol=2e-6 * scale)
+    # dx = scale*(g' - mean g' - xhat*mean(g' xhat)) cancels heavily when there are few rows: the error scales with
+    # the size of the TERMS (|g| * |gamma| * invstd), not with the (much smaller) result
+    var = x.double().var(0, unbiased=False) if training else ref.running_var
+    nat = float(probe.abs().max() * ref.weight.abs().max() * (1.0 / torch.sqrt(var + ref.eps)).max())
+    gs = max(1.0, float(gx_ref.abs().max()))
+    torch.testing.assert_close(xd.grad.cpu().double(), gx_ref, rtol=RTOL, atol=1e-5 * gs + 2e-6 * nat)
+    gw = max(1.0, float(ref.weight.grad.abs().max()))
+    rt = RTOL if rows > 8 else 3e-4      # two rows: xhat = +-1 up to eps/var, fp32 (x - mean)*invstd is ill-conditioned
+    torch.testing.assert_close(ours.weight.grad.cpu().double(), ref.weight.grad, rtol=rt, atol=1e-5 * gw)
+    torch.testing.assert_close(ours.bias.grad.cpu().double(), ref.bias.grad, rtol=rt, atol=1e-5 * gw)
+    torch.testing.assert_close(ours.running_mean.cpu().double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ours.running_var.cpu().double(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_batchnorm_variants_strided_no_affine_cumulative_momentum():
+    from deep_gcns_torch_amd.node_ops import BatchNorm1d
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    wide = torch.randn(300, 96, generator=g)
+    x = wide[:, 16:80]                                            # row stride 96, 64 channels, 16-byte aligned
+    for kw in (dict(affine=False), dict(momentum=None), dict(track_running_stats=False)):
+        ref = nn.BatchNorm1d(64, **kw).double()
+        ours = BatchNorm1d(64, **kw).to(dev)
+        for _ in range(3):                                        # several steps: cumulative average changes
+            y_ref = ref(x.double())
+            y = ours(wide.to(dev)[:, 16:80])
+        torch.testing.assert_close(y.cpu().double(), y_ref, rtol=RTOL, atol=1e-5)
+        if ref.running_mean is not None:
+            torch.testing.assert_close(ours.running_mean.cpu().double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(ours.running_var.cpu().double(), ref.running_var, rtol=1e-5, atol=1e-6)
+        ref.eval(); ours.eval()
+        torch.testing.assert_close(ours(x.to(dev)).cpu().double(), ref(x.double()), rtol=RTOL, atol=1e-5)
+    # 3-D input and a single training row keep torch's behaviour (stock path)
+    bn = BatchNorm1d(8).to(dev)
+    assert bn(torch.randn(4, 8, 5, device=dev)).shape == (4, 8, 5)
+    with pytest.raises(ValueError):
+        bn(torch.randn(1, 8, device=dev))
+
+
+def test_mlp_fuses_batchnorm_relu_and_matches_stock_sequential():
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from gcn_lib.sparse.torch_nn import MLP, norm_layer
+    from deep_gcns_torch_amd.node_ops import BatchNorm1d
+    dev = _dev()
+    assert isinstance(norm_layer("batch", 16), BatchNorm1d) and isinstance(norm_layer("batch", 16), nn.BatchNorm1d)
+    torch.manual_seed(0)
+    mlp = MLP([64, 128, 64], norm="batch", last_lin=True).to(dev)
+    assert list(mlp.state_dict().keys())[:4] == ["0.weight", "0.bias", "1.weight", "1.bias"]
+    stock = nn.Sequential(nn.Linear(64, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, 64)).to(dev)
+    stock.load_state_dict(mlp.state_dict())
+    x = torch.randn(20000, 64, device=dev)
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya, yb = mlp(xa), stock(xb)
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    torch.testing.assert_close(ya, yb, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-7)
+    for (na, pa), (nb, pb) in zip(mlp.named_parameters(), stock.named_parameters()):
+        torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6, msg=lambda m: f"{na}: {m}")
