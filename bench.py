@@ -22,6 +22,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL peer access)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -32,9 +32,10 @@ struct KnnParams {
   const float* x;
   int64_t sb, sc, sn;  // strides in floats of (B, C, N)
   int B, C, N, K, dilation, Kout;
-  uint8_t* row_flag;   // [B*N] or null.  Filter kernel: writes 1 for rows it could not finish (exact kernel redoes
-                       // them), 0 otherwise.  Exact kernel: when non-null, only rows flagged 1 are processed.
-  const float* sqnorm; // [B*N] |x_j|^2 (fma chain over channels), written by knn_sqnorm_kernel for the filter pass
+  int* redo;           // null, or [1 + B*N]: redo[0] = number of rows the filter kernel could not finish, redo[1..] =
+                       // their flat ids b*N+i (any order).  Exact kernel: when non-null, one listed row per tile.
+  float* sqnorm;       // [B*N] |x_j|^2 (fma chain over channels), written by knn_prep_kernel for the filter pass
+  uint32_t* tau;       // [B*N] per-row sample threshold (ordered-uint key), written by knn_prep_kernel
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
@@ -296,14 +297,20 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int tiles_per_b = (N + TM - 1) / TM;
-  const int b = blockIdx.x / tiles_per_b;
-  const int i0 = (blockIdx.x % tiles_per_b) * TM;
-  const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
-  if (P.row_flag) {  // second pass after the filter kernel: skip tiles with nothing left to do (block-uniform)
-    bool any = false;
-    for (int r = 0; r < TM; ++r) any = any || (i0 + r < N && P.row_flag[static_cast<int64_t>(b) * N + i0 + r] != 0);
-    if (!any) return;
+  // redo pass (TM == 1): the tiles are the rows the filter kernel listed, a fixed grid strides over the list
+  const int n_tiles = P.redo ? P.redo[0] : static_cast<int>(gridDim.x);
+  for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+  int b, i0;
+  if (P.redo) {
+    const int row = P.redo[1 + tile_id];
+    b = row / N;
+    i0 = row % N;
+  } else {
+    b = tile_id / tiles_per_b;
+    i0 = (tile_id % tiles_per_b) * TM;
   }
+  const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
+  __syncthreads();   // the previous tile's LDS contents are dead
 
   // ---- phase 0: stage the TM query points, channel-major [c][r] ----
   for (int e = tid; e < C * TM; e += kKnnThreads) {
@@ -431,14 +438,14 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 
   // ---- phases 2-5: one wave per query row ----
 #ifdef KNN_SKIP_SELECT
-  if (KNN_SKIP_SELECT) return;
+  if (KNN_SKIP_SELECT) continue;
 #endif
   for (int r = wave; r < TM; r += kKnnWaves) {
     const int i = i0 + r;
     if (i >= N) continue;  // wave-uniform
-    if (P.row_flag && P.row_flag[static_cast<int64_t>(b) * N + i] == 0) continue;
     select_row(P, dist + static_cast<size_t>(r) * Npad, selkey + static_cast<size_t>(r) * Kpad, b, i);
   }
+  }  // tiles
 }
 
 
@@ -455,24 +462,88 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 // than K or more than 1024 candidates is flagged and redone by the exact kernel (second launch, which
 // exits immediately for unflagged tiles).  Distances use the same fma chain and association as above.
 // =======================================================================================
+constexpr int kRedoGrid = 1024;   // workgroups of the list-driven exact pass (4 per CU)
 constexpr int kFTM = 16;
 constexpr int kFSamples = 256;
 constexpr int kFThreads = 1024;   // 16 waves: one per query row in the select phase, 4 per SIMD to hide latency
 constexpr int kFWaves = kFThreads / kWave;
 
-// |x_j|^2 of every point as the channel-ordered fma chain used everywhere else in this file.
-__global__ __launch_bounds__(kWgThreads) void knn_sqnorm_kernel(const KnnParams P, float* __restrict__ out) {
-  const int64_t total = static_cast<int64_t>(P.B) * P.N;
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int b = static_cast<int>(idx / P.N), j = static_cast<int>(idx % P.N);
-  const float* xp = P.x + static_cast<int64_t>(b) * P.sb + static_cast<int64_t>(j) * P.sn;
-  float s = 0.f;
-  for (int c = 0; c < P.C; ++c) {
-    const float v = xp[static_cast<int64_t>(c) * P.sc];
-    s = fmaf(v, v, s);
+constexpr int kPrepThreads = kFSamples;   // one thread per sampled candidate
+
+// Pre-pass of the filter path, 16 query rows per (small, high-occupancy) workgroup:
+//   sqnorm[b,i] = |x_i|^2 as the channel-ordered fma chain used everywhere else in this file;
+//   tau[b,i]    = the sample_rank-th smallest key among the distances to 256 sampled candidates (4 windows of 64
+//                 consecutive points, rotated per tile) -- the per-row threshold of the candidate filter;
+//   redo[0]     = 0 (the filter kernel appends the rows it cannot finish).
+// Kept out of the filter kernel because it is pure latency (64 dependent-ish loads per thread) and that kernel
+// runs one 1024-thread workgroup per CU: there it cost 65-85 us per call, here ~15.
+__global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(const KnnParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = kFTM;
+  const int C = P.C, N = P.N;
+  float* q = reinterpret_cast<float*>(smem);                        // [C][16]
+  float* sq = q + static_cast<size_t>(C) * TM;                      // [16]
+  uint32_t* skeys = reinterpret_cast<uint32_t*>(sq + TM);           // [16][256]
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int tiles_per_b = (N + TM - 1) / TM;
+  const int b = blockIdx.x / tiles_per_b;
+  const int tile = blockIdx.x % tiles_per_b;
+  const int i0 = tile * TM;
+  const float* xb = P.x + static_cast<int64_t>(b) * P.sb;
+  if (blockIdx.x == 0 && tid == 0) P.redo[0] = 0;
+
+  for (int e = tid; e < C * TM; e += kPrepThreads) {
+    const int c = e / TM, r = e % TM;
+    q[e] = xb[static_cast<int64_t>(c) * P.sc + min(i0 + r, N - 1)];
   }
-  out[idx] = s;
+  __syncthreads();
+  if (tid < TM) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(q[c * TM + tid], q[c * TM + tid], s);
+    sq[tid] = s;
+    if (i0 + tid < N) P.sqnorm[static_cast<int64_t>(b) * N + i0 + tid] = s;
+  }
+  __syncthreads();
+  {
+    const int s = tid;
+    const int quarter = N / 4;
+    const int j = ((s / 64) * quarter + (tile * 64) % quarter + (s % 64)) % N;
+    float acc[TM], sj = 0.f;
+#pragma unroll
+    for (int r = 0; r < TM; ++r) acc[r] = 0.f;
+    constexpr int SCH = 16;  // channel loads in flight per thread
+    for (int c0 = 0; c0 < C; c0 += SCH) {
+      float xv[SCH];
+#pragma unroll
+      for (int u = 0; u < SCH; ++u) xv[u] = (c0 + u < C) ? xb[static_cast<int64_t>(c0 + u) * P.sc + j] : 0.f;
+#pragma unroll
+      for (int u = 0; u < SCH; ++u) {
+        const int c = min(c0 + u, C - 1);      // channels past C carry zeros
+        sj = fmaf(xv[u], xv[u], sj);
+        const float4* qc = reinterpret_cast<const float4*>(q + c * TM);   // wave-wide broadcast reads
+#pragma unroll
+        for (int r4 = 0; r4 < TM / 4; ++r4) {
+          const float4 qq = qc[r4];
+          acc[4 * r4 + 0] = fmaf(qq.x, xv[u], acc[4 * r4 + 0]);
+          acc[4 * r4 + 1] = fmaf(qq.y, xv[u], acc[4 * r4 + 1]);
+          acc[4 * r4 + 2] = fmaf(qq.z, xv[u], acc[4 * r4 + 2]);
+          acc[4 * r4 + 3] = fmaf(qq.w, xv[u], acc[4 * r4 + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TM; ++r) skeys[r * kFSamples + s] = key_of((sq[r] + (-2.f * acc[r])) + sj);
+  }
+  __syncthreads();
+  for (int rr = wave; rr < TM; rr += kPrepThreads / kWave) {
+    uint32_t ks[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ks[u] = skeys[rr * kFSamples + u * kWave + lane];
+    const uint32_t t = kth_smallest<4>(ks, P.sample_rank);
+    if (lane == 0 && i0 + rr < N) P.tau[static_cast<int64_t>(b) * N + i0 + rr] = t;
+  }
 }
 
 template <int R>
@@ -536,7 +607,6 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
   int* cnt = reinterpret_cast<int*>(tau + TM);                      // [16]
   uint32_t* ckey = reinterpret_cast<uint32_t*>(cnt + TM);           // [16][kFCap]
   uint32_t* cidx = ckey + TM * kFCap;                               // [16][kFCap]
-  uint32_t* skeys = ckey;                                           // [16][256] sample keys (aliased, used first)
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -552,52 +622,11 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
     const int c = e / TM, r = e % TM;
     q[e] = xb[static_cast<int64_t>(c) * P.sc + min(i0 + r, N - 1)];
   }
-  __syncthreads();
-  if (tid < TM) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(q[c * TM + tid], q[c * TM + tid], s);
-    sq[tid] = s;
+  if (tid < TM) {   // row norms and sample thresholds come from knn_prep_kernel
+    const int64_t row = static_cast<int64_t>(b) * N + min(i0 + tid, N - 1);
+    sq[tid] = P.sqnorm[row];
+    tau[tid] = P.tau[row];
     cnt[tid] = 0;
-  }
-  __syncthreads();
-
-  // ---- sample: 4 windows of 64 consecutive candidates, rotated per tile ----
-  {
-    constexpr int RPT = TM * kFSamples / kFThreads;                  // rows per thread (4)
-    const int s = tid % kFSamples;
-    const int rg = tid / kFSamples;                                  // rows rg*RPT .. rg*RPT+RPT-1
-    const int quarter = N / 4;
-    const int j = ((s / 64) * quarter + (tile * 64) % quarter + (s % 64)) % N;
-    float acc[RPT], sj = 0.f;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
-    constexpr int SCH = 16;  // 16 channel loads in flight per thread: this stage is pure latency
-    for (int c0 = 0; c0 < C; c0 += SCH) {
-      float xv[SCH];
-#pragma unroll
-      for (int u = 0; u < SCH; ++u) {
-        xv[u] = (c0 + u < C) ? xb[static_cast<int64_t>(c0 + u) * P.sc + j] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < SCH; ++u) {
-        const int c = min(c0 + u, C - 1);
-        sj = fmaf(xv[u], xv[u], sj);
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) acc[r] = fmaf(q[c * TM + rg * RPT + r], xv[u], acc[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      skeys[(rg * RPT + r) * kFSamples + s] = key_of((sq[rg * RPT + r] + (-2.f * acc[r])) + sj);
-    }
-  }
-  __syncthreads();
-  for (int rr = wave; rr < TM; rr += kFWaves) {
-    uint32_t ks[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ks[u] = skeys[rr * kFSamples + u * kWave + lane];
-    const uint32_t t = kth_smallest<4>(ks, P.sample_rank);
-    if (lane == 0) tau[rr] = t;
   }
   __syncthreads();
 
@@ -685,8 +714,10 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
     if (i >= N) continue;  // wave-uniform
     const int c = cnt[rr];
     const bool ok = c >= K && c <= kFCap;
-    if (lane == 0) P.row_flag[static_cast<int64_t>(b) * N + i] = ok ? 0 : 1;
-    if (!ok) continue;
+    if (!ok) {   // hand the row to the exact kernel
+      if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = b * N + i;
+      continue;
+    }
     uint32_t* ck = ckey + rr * kFCap;
     uint32_t* ci = cidx + rr * kFCap;
     if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
@@ -697,10 +728,11 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
 }
 
 size_t knn_filter_lds_bytes(int C, int cap) {
-  size_t lists = static_cast<size_t>(kFTM) * cap * 8;
-  const size_t samples = static_cast<size_t>(kFTM) * kFSamples * 4;   // aliased with the lists
-  if (lists < samples) lists = samples;
-  return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + lists;
+  return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + static_cast<size_t>(kFTM) * cap * 8;
+}
+
+size_t knn_prep_lds_bytes(int C) {
+  return (static_cast<size_t>(C) * kFTM + kFTM) * 4 + static_cast<size_t>(kFTM) * kFSamples * 4;
 }
 
 // rank of the 256-sample threshold for a list capacity `cap` (see the comment at the call site)
@@ -729,8 +761,9 @@ using namespace dgcn;
 // nn_out / ctr_out: [B, N, Kout] int64 contiguous (ctr_out may be NULL).
 extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N) {
   if (B <= 0 || N <= 0) return 0;
-  // |x_j|^2 per point (fp32) followed by one flag byte per query row
-  return static_cast<size_t>(B) * static_cast<size_t>(N) * 4u + (static_cast<size_t>(B) * static_cast<size_t>(N) + 15u) / 16u * 16u;
+  // |x_j|^2 (fp32) and the sample threshold (u32) per point, then the redo list: a counter + up to B*N row ids
+  const size_t pts = static_cast<size_t>(B) * static_cast<size_t>(N);
+  return (pts * 12u + 4u + 15u) / 16u * 16u;
 }
 
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
@@ -749,7 +782,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   const int Npad = (N + 3) / 4 * 4;
   int TM = 8;
   while (TM > 1 && knn_lds_bytes(TM, C, Npad, Kpad) > static_cast<size_t>(kLdsBudget)) TM >>= 1;
-  const size_t lds = knn_lds_bytes(TM, C, Npad, Kpad);
+  size_t lds = knn_lds_bytes(TM, C, Npad, Kpad);
   if (lds > static_cast<size_t>(kLdsBudget)) return DGCN_E_SHAPE;
 
   KnnParams P;
@@ -757,8 +790,9 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.B = B; P.C = C; P.N = N; P.K = K; P.dilation = dilation;
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
-  P.row_flag = nullptr;
+  P.redo = nullptr;
   P.sqnorm = nullptr;
+  P.tau = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
   P.sample_rank = 0;
   if (N >= 1024) {
@@ -767,8 +801,9 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     // both "too few" and "too many" (list capacity) stay rare; either way the exact path catches the row.
     P.sample_rank = knn_sample_rank(N, K, 16 * kWave);
   }
-  const int tiles = (N + TM - 1) / TM;
-  const dim3 grid(static_cast<unsigned>(B) * tiles), block(kKnnThreads);
+  int tiles = (N + TM - 1) / TM;
+  dim3 grid(static_cast<unsigned>(B) * tiles);
+  const dim3 block(kKnnThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipSuccess;
   const bool vec4 = (sn == 1) && (N % 4 == 0) && (sc % 4 == 0) && (sb % 4 == 0) &&
@@ -780,17 +815,20 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N) &&
       knn_filter_lds_bytes(C, cap) <= static_cast<size_t>(kLdsBudget)) {
     KnnParams F = P;
-    float* sqbuf = static_cast<float*>(workspace);
-    F.sqnorm = sqbuf;
-    F.row_flag = reinterpret_cast<uint8_t*>(sqbuf + static_cast<size_t>(B) * N);
+    const size_t pts = static_cast<size_t>(B) * N;
+    F.sqnorm = static_cast<float*>(workspace);
+    F.tau = reinterpret_cast<uint32_t*>(F.sqnorm + pts);
+    F.redo = reinterpret_cast<int*>(F.tau + pts);
     F.sample_rank = knn_sample_rank(N, K, cap);
     const size_t flds = knn_filter_lds_bytes(C, cap);
+    const size_t plds = knn_prep_lds_bytes(C);
     const int ftiles = (N + kFTM - 1) / kFTM;
     const dim3 fgrid(static_cast<unsigned>(B) * ftiles);
-    if (F.sample_rank > 0) {
-      const int64_t pts = static_cast<int64_t>(B) * N;
-      hipLaunchKernelGGL(knn_sqnorm_kernel, dim3(static_cast<unsigned>((pts + kWgThreads - 1) / kWgThreads)),
-                         dim3(kWgThreads), 0, s, P, sqbuf);
+    if (F.sample_rank > 0 && plds <= static_cast<size_t>(kLdsBudget)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_prep_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
+      if (e != hipSuccess) return static_cast<int>(e);
+      hipLaunchKernelGGL(knn_prep_kernel, fgrid, dim3(kPrepThreads), plds, s, F);
       if (cap == 512) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<512>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
@@ -802,7 +840,13 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
         if (e != hipSuccess) return static_cast<int>(e);
         hipLaunchKernelGGL(knn_filter_kernel<1024>, fgrid, dim3(kFThreads), flds, s, F);
       }
-      P.row_flag = F.row_flag;   // the exact pass below only redoes the rows the filter pass flagged
+      // The exact pass below only redoes the rows the filter pass listed: one row per tile (a redo then costs one
+      // row's distance strip, not eight), a fixed grid striding over the device-side list.
+      P.redo = F.redo;
+      TM = 1;
+      lds = knn_lds_bytes(TM, C, Npad, Kpad);
+      tiles = N;
+      grid = dim3(kRedoGrid);
     }
   }
 #define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \

@@ -178,7 +178,8 @@ int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshif
  *   exclude_self != 0: the query point itself is never returned (torch_cluster.knn_graph(loop=False),
  *            gcn_lib/dense/torch_edge.py:97, gcn_lib/sparse/torch_edge.py:46); then K <= N-1
  *   workspace (optional, dgcn_knn_dense_workspace_bytes): enables the candidate-filter fast path for N >= 1024
- *            (16 rows per workgroup, per-row sampled threshold, exact fallback for the rows it flags);
+ *            (pre-pass: |x_j|^2 and a per-row sampled threshold; 16 rows per workgroup on the matrix cores; the
+ *            rows it cannot finish are listed on the device and redone by the exact path);
  *            without it every row takes the exact full-row path.  Results are identical either way.
  * Limits: N <= 4096, K <= 512, K <= N. */
 size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N);
