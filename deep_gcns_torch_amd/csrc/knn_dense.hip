@@ -134,18 +134,20 @@ __device__ __forceinline__ void sort_and_emit(const KnnParams& P, const uint32_t
 
 // Exact K-th smallest (0-based K-1) of the R*64 keys held as k[r] per lane: largest tau with
 // count(key < tau) < K.  32 steps of R compare+add and one DPP wave reduction.
-template <int R>
+// LOW > 0 resolves only bits 31..LOW and fills the rest with ones: an upper bound of the K-th key that is
+// good enough for a pre-filter threshold (never for the final selection).
+template <int R, int LOW = 0>
 __device__ __forceinline__ uint32_t kth_smallest(const uint32_t (&k)[R], int K) {
   uint32_t tau = 0;
 #pragma unroll 1
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 31; bit >= LOW; --bit) {
     const uint32_t cand = tau | (1u << bit);
     int c4[4] = {0, 0, 0, 0};  // independent chains: a single add-carry chain serialises on its latency
 #pragma unroll
     for (int s = 0; s < R; ++s) c4[s & 3] += (k[s] < cand) ? 1 : 0;
     if (wave_sum((c4[0] + c4[1]) + (c4[2] + c4[3])) < K) tau = cand;
   }
-  return tau;
+  return tau | ((1u << LOW) - 1u);
 }
 
 template <int R>
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(const KnnParams 
     uint32_t ks[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ks[u] = skeys[rr * kFSamples + u * kWave + lane];
-    const uint32_t t = kth_smallest<4>(ks, P.sample_rank);
+    const uint32_t t = kth_smallest<4, 12>(ks, P.sample_rank);   // 12 low mantissa bits of a threshold do not matter
     if (lane == 0 && i0 + rr < N) P.tau[static_cast<int64_t>(b) * N + i0 + rr] = t;
   }
 }
@@ -560,17 +562,21 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();  // candidates live in registers before their LDS slots are reused
   const uint32_t tau = kth_smallest<R>(ck, K);
-  const int need_eq = K - count_below<R>(ck, tau, false);
-  // candidates arrive in arbitrary order: among keys == tau take the need_eq LOWEST point ids
-  // (12-bit bisection on the id, ids are < 4096)
-  uint32_t tid_thr = 0;
+  const int n_lt = count_below<R>(ck, tau, false);
+  const int need_eq = K - n_lt;
+  // candidates arrive in arbitrary order: among keys == tau take the need_eq LOWEST point ids (12-bit bisection
+  // on the id, ids are < 4096) -- only when the tie at tau is real, i.e. more keys equal tau than are needed
+  uint32_t tid_thr = 0xFFFFFFFFu;
+  if (count_below<R>(ck, tau, true) - n_lt != need_eq) {
+    tid_thr = 0;
 #pragma unroll 1
-  for (int bit = 11; bit >= 0; --bit) {
-    const uint32_t cand = tid_thr | (1u << bit);
-    int c = 0;
+    for (int bit = 11; bit >= 0; --bit) {
+      const uint32_t cand = tid_thr | (1u << bit);
+      int c = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) c += (ck[r] == tau && ci[r] < cand) ? 1 : 0;
-    if (wave_sum(c) < need_eq) tid_thr = cand;
+      for (int r = 0; r < R; ++r) c += (ck[r] == tau && ci[r] < cand) ? 1 : 0;
+      if (wave_sum(c) < need_eq) tid_thr = cand;
+    }
   }
   int n_sel = 0;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -596,7 +602,7 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
 
 // CAP = per-row candidate list capacity: 512 (64 KB of lists -> two workgroups per CU, their phases overlap)
 // when K leaves enough room below it, else 1024.
-template <int kFCap>
+template <int kFCap, int KS>
 __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kFTM;
@@ -643,31 +649,89 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
   const int li = lane & 15, lk = lane >> 4;
   const unsigned long long below = (1ull << lane) - 1ull;
   const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
-  constexpr int KS = 8;   // k-steps (of 4 channels) per register-resident chunk: 8 float4 loads in flight per lane
-  for (int col0 = wave * 64; col0 < N; col0 += kFWaves * 64) {
+  // Channel chunks of 4*KS channels are DOUBLE BUFFERED (A/B): the loads of the next chunk -- or of the next
+  // column block's first chunk -- are in flight while the current chunk's MFMAs (and the append code below) run.
+  // Without this the 4 waves of a SIMD convoy: all wait for L2 together, then queue on the MFMA pipe together, and
+  // load time, MFMA time and append time simply add up (measured 95 + 110 + 68 us per call).
+  constexpr int CHUNK = 4 * KS;
+  const int cpb = ((C + CHUNK - 1) / CHUNK + 1) & ~1;   // chunks per column block, rounded up to even (zero-padded)
+  // Loads are UNCONDITIONAL (clamped addresses) so that they sit in straight-line code and the compiler can wait
+  // with an exact vmcnt instead of vmcnt(0): a channel past C gets a zero A operand (the B value, real data from
+  // the clamped address, is multiplied away), a column block past N is discarded by `in` in the append code.
+  auto load_chunk = [&](int col0, int cc, float (&a)[KS], float4 (&bx)[KS]) {
+    const int cb = min(col0 + 4 * li, N - 4);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = cc + 4 * ks + lk;
+      const int cl = min(c, C - 1);
+      const float qa = q[cl * TM + li];
+      a[ks] = (c < C) ? qa : 0.f;
+      bx[ks] = *reinterpret_cast<const float4*>(xb + static_cast<int64_t>(cl) * P.sc + cb);
+    }
+  };
+  auto mfma_chunk = [&](f32x4 (&acc)[4], const float (&a)[KS], const float4 (&bx)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#ifdef KNNF_NO_MFMA
+      acc[0][0] += a[ks] * bx[ks].x; acc[1][0] += a[ks] * bx[ks].y; acc[2][0] += a[ks] * bx[ks].z; acc[3][0] += a[ks] * bx[ks].w;
+#else
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].w, acc[3], 0, 0, 0);
+#endif
+    }
+  };
+  constexpr int kColStride = kFWaves * 64;
+  float aA[KS], aB[KS];
+  float4 bA[KS], bB[KS];
+  load_chunk(wave * 64, 0, aA, bA);
+#ifdef KNNF_STAGGER
+  // waves w, w+4, w+8, w+12 share a SIMD: start them a fraction of a block apart so that their load / MFMA /
+  // append phases interleave instead of marching in step
+  for (int d = 0; d < (wave >> 2); ++d) __builtin_amdgcn_s_sleep(KNNF_STAGGER);
+#endif
+  for (int col0 = wave * 64; col0 < N; col0 += kColStride) {
     const int cbase = col0 + 4 * li;
     const bool in = cbase < N;  // N % 4 == 0
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < C; cc += 4 * KS) {
-      float a[KS];
-      float4 bx[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int c = cc + 4 * ks + lk;
-        a[ks] = (c < C) ? q[c * TM + li] : 0.f;
-        bx[ks] = (c < C && in) ? *reinterpret_cast<const float4*>(xb + static_cast<int64_t>(c) * P.sc + cbase)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bx[ks].w, acc[3], 0, 0, 0);
-      }
+    for (int ch = 0; ch < cpb; ch += 2) {
+      // sched_barrier: keep "issue the next chunk's loads, THEN run this chunk's MFMAs" -- left alone, the
+      // scheduler sinks every load next to its first use (lower register pressure, no overlap at all)
+      load_chunk(col0, (ch + 1) * CHUNK, aB, bB);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef KNNF_SETPRIO
+      __builtin_amdgcn_s_setprio(KNNF_SETPRIO);
+#endif
+      mfma_chunk(acc, aA, bA);
+#ifdef KNNF_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // next A chunk: this block's, or the first of the next block (clamped past the end: loaded, never used)
+      const bool more = ch + 2 < cpb;
+      load_chunk(more ? col0 : col0 + kColStride, more ? (ch + 2) * CHUNK : 0, aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef KNNF_SETPRIO
+      __builtin_amdgcn_s_setprio(KNNF_SETPRIO);
+#endif
+      mfma_chunk(acc, aB, bB);
+#ifdef KNNF_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef KNNF_NO_APPEND
+    {
+      float tsum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tsum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+      if (tsum == 123.456f) cnt[0] = 1;
+      continue;
+    }
+#endif
     // acc[t][reg] = <x_row, x_col> for row = lk*4 + reg, col = cbase + t
     float sj[4] = {0.f, 0.f, 0.f, 0.f};
     if (in) load_vec<4>(sj, sqn + cbase);
@@ -723,6 +787,7 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
     if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
     else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
     else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
+    else if (c <= 12 * kWave) filter_select_row<12>(P, ck, ci, c, b, i, lane);
     else filter_select_row<16>(P, ck, ci, c, b, i, lane);
   }
 }
@@ -829,17 +894,21 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
       if (e != hipSuccess) return static_cast<int>(e);
       hipLaunchKernelGGL(knn_prep_kernel, fgrid, dim3(kPrepThreads), plds, s, F);
+      // chunk = 4*KS channels, two chunks per column block: KS sized so that C fills both
+      const int ks = C > 16 ? 4 : 2;   // (KS = 8 double-buffered needs > 128 VGPRs: spills)
+#define DGCN_KNNF_LAUNCH(CAP, KSV)                                                                           \
+  do {                                                                                                        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<CAP, KSV>),                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));              \
+    if (e != hipSuccess) return static_cast<int>(e);                                                          \
+    hipLaunchKernelGGL((knn_filter_kernel<CAP, KSV>), fgrid, dim3(kFThreads), flds, s, F);                    \
+  } while (0)
       if (cap == 512) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<512>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
-        if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(knn_filter_kernel<512>, fgrid, dim3(kFThreads), flds, s, F);
+        if (ks == 4) DGCN_KNNF_LAUNCH(512, 4); else DGCN_KNNF_LAUNCH(512, 2);
       } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel<1024>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(flds));
-        if (e != hipSuccess) return static_cast<int>(e);
-        hipLaunchKernelGGL(knn_filter_kernel<1024>, fgrid, dim3(kFThreads), flds, s, F);
+        if (ks == 4) DGCN_KNNF_LAUNCH(1024, 4); else DGCN_KNNF_LAUNCH(1024, 2);
       }
+#undef DGCN_KNNF_LAUNCH
       // The exact pass below only redoes the rows the filter pass listed: one row per tile (a redo then costs one
       // row's distance strip, not eight), a fixed grid striding over the device-side list.
       P.redo = F.redo;
