@@ -56,6 +56,7 @@ struct FwdParams {
   void* aux1;
   float* aux2;
   int32_t* range_flag;  // softmax: set to 1 when some |L_i| >= kShiftSafe (the backward then gathers two rows)
+  int add_root;         // out_i += x_i (the GENConv residual h = x + m fused into the epilogue)
   float* ws;  // partial slots: [slot][4][C]
 };
 
@@ -76,6 +77,7 @@ struct BwdParams {
   const float* gshift;    // [n_dst, C] g_i * exp(kshift_c - L_i)  (single-gather softmax backward) or null
   const float* kshift;    // [C] per-channel shift
   const int32_t* shift_ok;  // device flag: 1 = the shifted form is numerically safe for this call
+  const float* groot;     // [n_src, C] upstream gradient added to grad_x (backward of add_root) or null
   float* grad_x;
   float* grad_ea;
   float* ws;  // partial slots: [slot][C]
@@ -522,6 +524,12 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
               res[j] = st.b[j];
             }
           }
+          if (P.add_root) {
+            float xr[VEC];
+            load_vec<VEC>(xr, row_ptr(P.x, w.row, xs32) + c0ch);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) res[j] += xr[j];
+          }
           store_vec<VEC>(P.out + o, res);
           if constexpr (MODE == DGCN_AGGR_MAX) {
             if (P.aux1) store_vec_i<VEC>(static_cast<int32_t*>(P.aux1) + o, xi);
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
     } else {
       res = st.b[0];
     }
-    P.out[o] = res;
+    P.out[o] = P.add_root ? res + P.x[static_cast<int64_t>(row) * P.x_stride + c] : res;
     if constexpr (MODE == DGCN_AGGR_MAX) {
       if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = st.idx[0];
     } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
@@ -760,6 +768,12 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         if (w.slot >= 0) {
           store_vec<VEC>(P.ws + static_cast<int64_t>(w.slot) * C + c0, acc);
         } else {
+          if (P.groot) {
+            float gr[VEC];
+            load_vec<VEC>(gr, P.groot + static_cast<int64_t>(w.row) * C + c0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += gr[j];
+          }
           store_vec<VEC>(P.grad_x + static_cast<int64_t>(w.row) * C + c0, acc);
         }
       }
@@ -817,7 +831,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
   for (int c = lane; c < C; c += kWave) {
     float acc = 0.f;
     for (int i = i0; i < i1; ++i) acc += P.ws[static_cast<int64_t>(P.g.work_slot[i]) * C + c];
-    P.grad_x[static_cast<int64_t>(row) * C + c] = acc;
+    P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
   }
 }
 
@@ -952,8 +966,8 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
                                      const float* t_dev, const float* p_dev, float* out,
                                      void* aux1, float* aux2, int32_t* range_flag, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  (void)flags;
   if (!g || !x || !out) return DGCN_E_NULL;
+  if ((flags & DGCN_FLAG_ADD_ROOT) && g->n_dst > g->n_src) return DGCN_E_SHAPE;   // root rows are x[0 .. n_dst)
   if (g->n_dst < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
   if (x_stride > 0x7fffffffLL) return DGCN_E_SHAPE;   // row addresses use a 32x32->64 multiply
   if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
@@ -978,6 +992,7 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
+  P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
 
   const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;   // items walked side by side by one wave
   const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
@@ -1002,8 +1017,8 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
                                      int32_t msg, int32_t flags, float t, float p, float eps,
                                      const float* t_dev, const float* p_dev, const float* gcoef,
                                      const void* aux1, const float* out, const float* gshift,
-                                     const float* kshift, const int32_t* shift_ok, float* grad_x,
-                                     float* grad_edge_attr, void* workspace,
+                                     const float* kshift, const int32_t* shift_ok, const float* groot,
+                                     float* grad_x, float* grad_edge_attr, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
   if (g->n_src < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
@@ -1019,7 +1034,7 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   if (g->t_n_work && g->t_n_slots > 0 && !workspace) return DGCN_E_NULL;
 
   const bool vec4 = (channels % 4 == 0) && (x_stride % 4 == 0) && aligned16(x) && aligned16(gcoef) &&
-                    aligned16(grad_x) && (!edge_attr || aligned16(edge_attr)) &&
+                    aligned16(grad_x) && (!edge_attr || aligned16(edge_attr)) && (!groot || aligned16(groot)) &&
                     (!aux1 || aligned16(aux1)) && (!out || aligned16(out)) &&
                     (!grad_edge_attr || aligned16(grad_edge_attr)) &&
                     (!workspace || aligned16(workspace));
@@ -1034,6 +1049,7 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
   P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr;
+  P.groot = groot;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
   }

@@ -44,18 +44,32 @@ class GenMessagePassing(torch.nn.Module):
                 self.y = torch.nn.Parameter(torch.Tensor([y]), requires_grad=learn_y)
 
     # -- fused path ---------------------------------------------------------------------
-    def _aggregate_fused(self, x, graph: Graph, edge_attr=None, relu_eps=True, eps=1e-7):
+    def fusable_root(self) -> bool:
+        """Whether ``x + aggregate`` can come out of the aggregation kernel itself (no degree scaling, no learnable
+        temperature / exponent: their gradients read the bare aggregate)."""
+        aggr = self.aggr
+        if aggr in ("softmax_sum", "power_sum"):
+            return False
+        if aggr in _SOFTMAX and self.learn_t:
+            return False
+        if aggr in _POWER and isinstance(self.p, torch.nn.Parameter):
+            return False
+        return True
+
+    def _aggregate_fused(self, x, graph: Graph, edge_attr=None, relu_eps=True, eps=1e-7, add_root=False):
         """AGGR_i over relu(x_src + edge_attr) + eps (or the raw rows), then the optional
         degree scaling deg^sigmoid(y) of the ``*_sum`` variants (torch_message.py:60-63,77-80)."""
         aggr = self.aggr
         if aggr is None or aggr in ("add", "mean", "max"):
-            out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr or "add", relu_eps=relu_eps, eps=eps)
+            out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr or "add", relu_eps=relu_eps, eps=eps,
+                                    add_root=add_root)
         elif aggr in _SOFTMAX:
             out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr, t=self.t, learn_t=self.learn_t,
-                                    relu_eps=relu_eps, eps=eps)
+                                    relu_eps=relu_eps, eps=eps, add_root=add_root)
         elif aggr in _POWER:
             out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr, p=self.p,
-                                    learn_p=isinstance(self.p, torch.nn.Parameter), relu_eps=relu_eps, eps=eps)
+                                    learn_p=isinstance(self.p, torch.nn.Parameter), relu_eps=relu_eps, eps=eps,
+                                    add_root=add_root)
         else:
             raise NotImplementedError("To be implemented")
         if aggr in ("softmax_sum", "power_sum"):
@@ -64,12 +78,13 @@ class GenMessagePassing(torch.nn.Module):
         return out
 
     # -- PyG-flavoured entry points kept for API compatibility ----------------------------
-    def propagate(self, edge_index, size=None, x=None, edge_attr=None):
+    def propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False):
         """``propagate(edge_index, x=x, edge_attr=edge_attr)`` as GENConv.forward calls it
-        (gcn_lib/sparse/torch_vertex.py:68): message + aggregate + update in one kernel."""
+        (gcn_lib/sparse/torch_vertex.py:68): message + aggregate + update in one kernel.  ``add_root`` (extension)
+        returns ``x + aggregate`` from the same kernel when ``fusable_root()``."""
         n = x.size(0) if size is None else (size[1] if isinstance(size, (tuple, list)) else size)
-        return self.update(self._aggregate_fused(x, graph_of(edge_index, n), edge_attr,
-                                                 relu_eps=True, eps=getattr(self, "eps", 1e-7)))
+        return self.update(self._aggregate_fused(x, graph_of(edge_index, n), edge_attr, relu_eps=True,
+                                                 eps=getattr(self, "eps", 1e-7), add_root=add_root))
 
     def aggregate(self, inputs, index, ptr=None, dim_size=None):
         """Aggregate an ALREADY materialised (E, C) message tensor by destination ``index``

@@ -41,6 +41,8 @@ class GENConv(GenMessagePassing):
 
     def forward(self, x, edge_index, edge_attr=None):
         edge_emb = self.edge_encoder(edge_attr) if (self.encode_edge and edge_attr is not None) else edge_attr
+        if self.msg_norm is None and self.fusable_root() and x.dim() == 2:
+            return self.mlp(self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True))   # h = x + m, fused
         m = self.propagate(edge_index, x=x, edge_attr=edge_emb)
         if self.msg_norm is not None:
             m = self.msg_norm(x, m)

@@ -46,7 +46,8 @@ def _rows_f32(x: torch.Tensor) -> torch.Tensor:
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, t_param, p_param, graph: Graph, mode: int, msg: int,
-                eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool, track: bool):
+                eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool, track: bool,
+                add_root: bool = False):
         lib = _lib.load()
         dev = _lib.require_device(x, edge_attr)
         if dev != graph.device:
@@ -70,6 +71,10 @@ class _GenAggregate(torch.autograd.Function):
             if (mode == _lib.AGGR_SOFTMAX and learn_t) or (mode == _lib.AGGR_POWER and learn_p):
                 aux2 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         flags = (_lib.FLAG_LEARN_T if learn_t else 0) | (_lib.FLAG_LEARN_P if learn_p else 0)
+        if add_root:
+            if learn_t or learn_p or graph.n_dst != graph.n_src:
+                raise ValueError("add_root needs a square graph and non-learnable t / p")
+            flags |= _lib.FLAG_ADD_ROOT
         range_flag = None
         if need_grad and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
             range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
@@ -88,6 +93,7 @@ class _GenAggregate(torch.autograd.Function):
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
             ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
             ctx.learn_t, ctx.learn_p = learn_t, learn_p
+            ctx.add_root = add_root
         return out
 
     @staticmethod
@@ -145,25 +151,27 @@ class _GenAggregate(torch.autograd.Function):
                     graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
                     ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
                     gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
-                    _lib.ptr(shift_ok), grad_x.data_ptr(),
+                    _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
                     _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
             _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
             if not ctx.needs_input_grad[0]:
                 grad_x = None
-        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 9
+        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10
 
 
 def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
                   edge_attr: Optional[torch.Tensor] = None, aggr: str = "softmax",
                   t: Union[float, torch.Tensor] = 1.0, p: Union[float, torch.Tensor] = 1.0,
                   learn_t: bool = False, learn_p: bool = False, relu_eps: bool = True,
-                  eps: float = 1e-7, dim_size: Optional[int] = None) -> torch.Tensor:
+                  eps: float = 1e-7, dim_size: Optional[int] = None, add_root: bool = False) -> torch.Tensor:
     """out_i = AGGR_{e: dst(e)=i} m_e with m_e = relu(x[src(e)] (+edge_attr_e)) + eps.
 
     ``aggr`` in {add, mean, max, softmax, softmax_sg, softmax_sum, power, power_sum}; the
     ``*_sum`` degree scaling (torch_message.py:60-63,77-80) is applied by the caller.
     ``t`` / ``p`` may be python floats or 1-element device tensors (learnable parameters are
     read on the device, no host synchronisation).  ``relu_eps=False`` aggregates raw rows.
+    ``add_root`` returns ``x + out`` (the ``h = x + m`` of GENConv.forward) from the same kernel: the root row is
+    added in the epilogue and the upstream gradient in the backward's, saving two elementwise passes per layer.
     """
     if aggr not in _MODES:
         raise NotImplementedError("To be implemented")  # torch_message.py:85
@@ -179,7 +187,7 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
         p_param = p_param.detach()
     msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
     return _GenAggregate.apply(x, edge_attr, t_param, p_param, graph, mode, msg, float(eps),
-                               t_val, p_val, learn_t, learn_p, torch.is_grad_enabled())
+                               t_val, p_val, learn_t, learn_p, torch.is_grad_enabled(), bool(add_root))
 
 
 def selftest(device="cuda:0") -> None:

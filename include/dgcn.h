@@ -49,6 +49,7 @@ extern "C" {
 /* extra behaviour bits for dgcn_gen_aggr_{fwd,bwd}_f32 */
 #define DGCN_FLAG_LEARN_T 1 /* softmax weights are differentiated (torch_message.py:51-52) */
 #define DGCN_FLAG_LEARN_P 2 /* power exponent is differentiated  (torch_message.py:33-34) */
+#define DGCN_FLAG_ADD_ROOT 4 /* forward: out_i += x_i, the h = x + m of GENConv.forward (torch_vertex.py:74) fused in */
 
 /*
  * Graph structure, built once per distinct edge_index and reused by every layer
@@ -139,6 +140,8 @@ int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
  *   aux1    as written by the forward (SOFTMAX: L_i, MAX: arg-max edge ids)
  *   out     forward output (only read for SOFTMAX with DGCN_FLAG_LEARN_T)
  *   gshift, kshift, shift_ok   optional single-gather form for SOFTMAX (see dgcn_softmax_bwd_prep_f32), or NULL
+ *   groot   [n_src, C] contiguous or NULL: added to grad_x (the backward of DGCN_FLAG_ADD_ROOT: pass the raw
+ *           upstream gradient)
  *   grad_x  [n_src, C] contiguous, fully overwritten
  *   grad_edge_attr [E, C] in original edge order or NULL
  */
@@ -149,8 +152,8 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           int32_t msg, int32_t flags, float t, float p, float eps,
                           const float* t_dev, const float* p_dev, const float* gcoef,
                           const void* aux1, const float* out, const float* gshift,
-                          const float* kshift, const int32_t* shift_ok, float* grad_x,
-                          float* grad_edge_attr, void* workspace, size_t workspace_bytes,
+                          const float* kshift, const int32_t* shift_ok, const float* groot,
+                          float* grad_x, float* grad_edge_attr, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /* Node-wise prologue of the single-gather softmax backward:

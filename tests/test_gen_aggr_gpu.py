@@ -261,3 +261,32 @@ def test_strided_inputs_and_non_default_stream():
         out = ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.5)
     s.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.3)), ("power", dict(p=2.0)), ("max", {}), ("mean", {}), ("add", {})])
+@pytest.mark.parametrize("C,with_ea", [(128, False), (16, True), (50, False)])
+def test_add_root_equals_x_plus_aggregate(aggr, kw, C, with_ea):
+    """out = x + AGGR(...) from the kernel epilogue (and grad_x = g + backward) against the two-op composition, on a
+    power-law graph (split hub rows take the merge kernels), float4 / sub-group / scalar layouts."""
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    n = 5000
+    ei = synth.powerlaw_graph(n, 40_000, seed=11, exponent=2.1).to(dev)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, C, generator=g).to(dev)
+    probe = torch.randn(n, C, generator=g).to(dev)
+    ea = torch.randn(ei.size(1), C, generator=g).to(dev) if with_ea else None
+    xa = x.clone().requires_grad_(True)
+    ea_a = ea.clone().requires_grad_(True) if with_ea else None
+    fused = ops.gen_aggregate(xa, ei, ea_a, aggr=aggr, add_root=True, **kw)
+    (fused * probe).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    ea_b = ea.clone().requires_grad_(True) if with_ea else None
+    comp = xb + ops.gen_aggregate(xb, ei, ea_b, aggr=aggr, **kw)
+    (comp * probe).sum().backward()
+    torch.testing.assert_close(fused, comp, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    if with_ea:
+        torch.testing.assert_close(ea_a.grad, ea_b.grad, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.gen_aggregate(xa, ei, aggr="softmax", t=torch.ones(1, device=dev, requires_grad=True), learn_t=True, add_root=True)

@@ -32,9 +32,10 @@ def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None):
+def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False):
     from oracle import sparse_ref
-    return sparse_ref.gen_propagate(x, edge_index, edge_attr, aggr=self.aggr, t=getattr(self, "t", 1.0))
+    m = sparse_ref.gen_propagate(x, edge_index, edge_attr, aggr=self.aggr, t=getattr(self, "t", 1.0))
+    return x + m if add_root else m      # torch_vertex.py:74 (h = x + m), fused into the kernel on the product path
 
 
 def _run(model, case, dev):
