@@ -110,9 +110,10 @@ def main():
     E = ei.size(1)
     for aggr, kw in (("power", dict(p=1.0, learn_p=True)), ("max", {}), ("softmax", dict(t=1.0, learn_t=True))):
         for C in (32, 112):
-            conv = GENConv(C, C, aggr=aggr, norm="layer", mlp_layers=2, encode_edge=True, edge_feat_dim=C * 2, **kw).to(dev)
+            # ogbn-proteins carries 8 raw features per edge; each layer owns a Linear(8 -> C) edge encoder
+            conv = GENConv(C, C, aggr=aggr, norm="layer", mlp_layers=2, encode_edge=True, edge_feat_dim=8, **kw).to(dev)
             xr = torch.randn(s["n"], C, device=dev, requires_grad=True)
-            ea = torch.randn(E, C * 2, device=dev)
+            ea = torch.randn(E, 8, device=dev)
 
             def step_conv():
                 out = conv(xr, ei, ea)

@@ -57,6 +57,9 @@ struct FwdParams {
   float* aux2;
   int32_t* range_flag;  // softmax: set to 1 when some |L_i| >= kShiftSafe (the backward then gathers two rows)
   int add_root;         // out_i += x_i (the GENConv residual h = x + m fused into the epilogue)
+  const float* enc_feat;  // EA == 2: raw edge features [E, kEncF] in original edge order; e_e = enc_w f_e + enc_b
+  const float* enc_w;     // [C, kEncF] (nn.Linear weight)
+  const float* enc_b;     // [C] or null
   float* ws;  // partial slots: [slot][4][C]
 };
 
@@ -78,6 +81,10 @@ struct BwdParams {
   const float* kshift;    // [C] per-channel shift
   const int32_t* shift_ok;  // device flag: 1 = the shifted form is numerically safe for this call
   const float* groot;     // [n_src, C] upstream gradient added to grad_x (backward of add_root) or null
+  const float* enc_feat;  // EA == 2: see FwdParams
+  const float* enc_w;
+  const float* enc_b;
+  float* enc_gpart;       // EA == 2: [gridDim.x][C][kEncF + 1] per-workgroup partial (dW | db)
   float* grad_x;
   float* grad_ea;
   float* ws;  // partial slots: [slot][C]
@@ -360,12 +367,54 @@ __device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][V
   }
 }
 
+// ---- fused edge encoder (EA == 2): e_e = W f_e + b with kEncF raw features per edge -------------------------
+// GENConv(encode_edge=True) builds edge_emb = Linear(edge_feat_dim -> C)(edge_attr), an (E, C) tensor written by
+// a GEMM and read back by the aggregation (gcn_lib/sparse/torch_vertex.py:56-66).  With 8 raw features per edge
+// (ogbn-proteins) the row is cheaper to recompute per edge from 32 bytes than to load as 4C bytes.
+constexpr int kEncF = 8;
+
+template <int VEC>
+struct EncW {
+  float w[VEC][kEncF];
+  float b[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void enc_load(EncW<VEC>& e, const float* __restrict__ W, const float* __restrict__ b,
+                                         int c0, bool act) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    e.b[j] = (act && b) ? b[c0 + j] : 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) e.w[j][f] = act ? W[(c0 + j) * kEncF + f] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void enc_feat_row(float (&fe)[kEncF], const float* __restrict__ feat, int eid) {
+  const float4* p = reinterpret_cast<const float4*>(feat + static_cast<int64_t>(eid) * kEncF);
+  const float4 a = p[0], b = p[1];
+  fe[0] = a.x; fe[1] = a.y; fe[2] = a.z; fe[3] = a.w;
+  fe[4] = b.x; fe[5] = b.y; fe[6] = b.z; fe[7] = b.w;
+}
+
+template <int VEC>
+__device__ __forceinline__ void enc_apply(float (&out)[VEC], const EncW<VEC>& e, const float (&fe)[kEncF]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float a = e.b[j];
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) a = fmaf(e.w[j][f], fe[f], a);
+    out[j] = a;
+  }
+}
+
 // Address of row `src`: a 32x32->64 multiply (one v_mad_u64_u32); the host checks 0 <= stride < 2^31.
 __device__ __forceinline__ const float* row_ptr(const float* base, int src, uint32_t stride) {
   return base + static_cast<uint64_t>(static_cast<uint32_t>(src)) * stride;
 }
 
-template <int MODE, int VEC, int LPR, int SW, bool HAS_EA, bool RELU, bool WITH_D>
+// EA: 0 = no edge features, 1 = dense (E, C) edge features, 2 = encoded on the fly from kEncF raw features
+template <int MODE, int VEC, int LPR, int SW, int EA, bool RELU, bool WITH_D>
 __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
   constexpr int G = SW / LPR;               // edges of one item walked in parallel
   constexpr int R = kWave / SW;             // items walked side by side by one wave
@@ -374,7 +423,7 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
 #else
   constexpr int U = (VEC == 4) ? 4 : 8;     // load batches in flight per lane
 #endif
-  constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
+  constexpr bool NEED_EID = EA != 0 || MODE == DGCN_AGGR_MAX;
 
   const int lane = lane_id();
   const int sl = lane % SW;                 // lane within its sub-group
@@ -412,6 +461,8 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
       const bool act = c0ch < C;
       State<VEC> st;
       state_init<MODE, VEC>(st);
+      EncW<(EA == 2 ? VEC : 1)> enc;
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0ch, act);
 
       int mycol = col0, myeid = eid0;
       for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
@@ -431,9 +482,16 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
               eid[u] = 0;
               if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
               load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
-              if constexpr (HAS_EA) {
+              if constexpr (EA == 1) {
                 float a[VEC];
                 load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+              }
+              if constexpr (EA == 2) {
+                float fe[kEncF], a[VEC];
+                enc_feat_row(fe, P.enc_feat, eid[u]);
+                enc_apply<VEC>(a, enc, fe);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
               }
@@ -451,9 +509,16 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
               for (int j = 0; j < VEC; ++j) v[u][j] = 0.f;
               if (ok[u] && act) {
                 load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
-                if constexpr (HAS_EA) {
+                if constexpr (EA == 1) {
                   float a[VEC];
                   load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+                }
+                if constexpr (EA == 2) {
+                  float fe[kEncF], a[VEC];
+                  enc_feat_row(fe, P.enc_feat, eid[u]);
+                  enc_apply<VEC>(a, enc, fe);
 #pragma unroll
                   for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
                 }
@@ -559,12 +624,12 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
 #else
 #define DGCN_FWD_OCC
 #endif
-template <int MODE, int VEC, int LPR, int SW, bool HAS_EA, bool WITH_D>
+template <int MODE, int VEC, int LPR, int SW, int EA, bool WITH_D>
 __global__ __launch_bounds__(kWgThreads) DGCN_FWD_OCC void gen_aggr_fwd_kernel(const FwdParams P) {
   if (P.msg == DGCN_MSG_RELU_EPS) {
-    gen_aggr_fwd_body<MODE, VEC, LPR, SW, HAS_EA, true, WITH_D>(P);
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, EA, true, WITH_D>(P);
   } else {
-    gen_aggr_fwd_body<MODE, VEC, LPR, SW, HAS_EA, false, WITH_D>(P);
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, EA, false, WITH_D>(P);
   }
 }
 
@@ -639,12 +704,20 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
 // ---------------------------------------------------------------------------------------
 constexpr int kModeSoftmaxShifted = 100;  // internal: softmax backward with ONE gathered row per edge
 
-template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
+template <int MODE, int VEC, int LPR, int SW, int EA>
 __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   constexpr int G = SW / LPR;
   constexpr int R = kWave / SW;
-  constexpr int U = (VEC == 4) ? 4 : 8;
-  constexpr bool NEED_EID = HAS_EA || MODE == DGCN_AGGR_MAX;
+  constexpr int U = (EA == 2) ? 2 : ((VEC == 4) ? 4 : 8);   // EA == 2 keeps U feature rows + 9 VEC sums live
+  constexpr bool NEED_EID = EA != 0 || MODE == DGCN_AGGR_MAX;
+  constexpr int EV = (EA == 2) ? VEC : 1;
+  EncW<EV> enc, genc;       // encoder weights of this lane's channels, and the sums dW | db over this wave's edges
+#pragma unroll
+  for (int j = 0; j < EV; ++j) {
+    genc.b[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) genc.w[j][f] = 0.f;
+  }
 
   const int lane = lane_id();
   const int sl = lane % SW;
@@ -682,6 +755,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
       if constexpr (MODE == kModeSoftmaxShifted) {
         if (act) load_vec<VEC>(ksh, P.kshift + c0);
       }
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0, act);
 
       int mycol = col0, myeid = eid0;
       for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
@@ -689,6 +763,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
         for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
           float gc[U][VEC], a1[U][VEC], oo[U][VEC], ea[U][VEC];
+          float fe[(EA == 2) ? U : 1][kEncF];
           int ai[U][VEC];
           bool ok[U];
           int eid[U];
@@ -717,18 +792,22 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
               if constexpr (MODE == DGCN_AGGR_MAX) {
                 load_vec_i<VEC>(ai[u], static_cast<const int32_t*>(P.aux1) + ro);
               }
-              if constexpr (HAS_EA) {
+              if constexpr (EA == 1) {
                 load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
               }
+              if constexpr (EA == 2) enc_feat_row(fe[u], P.enc_feat, eid[u]);
             }
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
             float dz[VEC];
+            if constexpr (EA == 2) {
+              if (act) enc_apply<VEC>(ea[u], enc, fe[u]);
+            }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-              const float z = HAS_EA ? xs[j] + ea[u][j] : xs[j];
+              const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];
               const float m = msg_apply(z, msg, eps);
               const float r = (msg == DGCN_MSG_RELU_EPS) ? (z > 0.f ? 1.f : 0.f) : 1.f;
               float k;
@@ -751,9 +830,19 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
               dz[j] = r * k;
               acc[j] += dz[j];
             }
-            if constexpr (HAS_EA) {
+            if constexpr (EA == 1) {
               if (act && P.grad_ea) {
                 store_vec<VEC>(P.grad_ea + static_cast<int64_t>(eid[u]) * C + c0, dz);
+              }
+            }
+            if constexpr (EA == 2) {
+              if (act) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                  genc.b[j] += dz[j];
+#pragma unroll
+                  for (int f = 0; f < kEncF; ++f) genc.w[j][f] = fmaf(dz[j], fe[u][f], genc.w[j][f]);
+                }
               }
             }
           }
@@ -783,18 +872,50 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
     col0 = coln;
     eid0 = eidn;
   }
+
+  if constexpr (EA == 2) {
+    // dW | db of this workgroup: lanes with the same channel group (cl) are summed with shuffles, the four waves
+    // through LDS in a fixed order, and the workgroup writes one (C, kEncF + 1) partial; the host sums the partials.
+    constexpr int NV = VEC * (kEncF + 1);
+    __shared__ float red[kWavesPerWg][LPR * NV];
+    float vals[NV];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+      for (int f = 0; f < kEncF; ++f) vals[j * (kEncF + 1) + f] = genc.w[j][f];
+      vals[j * (kEncF + 1) + kEncF] = genc.b[j];
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) vals[q] += __shfl_xor(vals[q], off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane < LPR) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) red[wv][lane * NV + q] = vals[q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LPR * NV; i += kWgThreads) {
+      const int ch = (i / NV) * VEC + (i % NV) / (kEncF + 1);
+      if (ch < C) {
+        const float tsum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        P.enc_gpart[(static_cast<int64_t>(blockIdx.x) * C + ch) * (kEncF + 1) + (i % NV) % (kEncF + 1)] = tsum;
+      }
+    }
+  }
 }
 
-template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
+template <int MODE, int VEC, int LPR, int SW, int EA>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
   if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
     // single-gather form when the caller prepared it and the device-side range check passed
     if (P.gshift != nullptr && !P.learn_t && *P.shift_ok != 0) {
-      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, SW, HAS_EA>(P);
+      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, SW, EA>(P);
       return;
     }
   }
-  gen_aggr_bwd_body<MODE, VEC, LPR, SW, HAS_EA>(P);
+  gen_aggr_bwd_body<MODE, VEC, LPR, SW, EA>(P);
 }
 
 // out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])   (node-wise prologue of the single-gather backward)
@@ -859,24 +980,30 @@ int subgroup_width(int lpr) {
   return sw < kWave ? sw : kWave;
 }
 
-template <int MODE, int VEC, int LPR, int SW, bool HAS_EA>
+template <int MODE, int VEC, int LPR, int SW, int EA>
 void launch_fwd_d(const FwdParams& P, int grid, hipStream_t s) {
   constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
   if constexpr (CAN_D) {
     if (P.aux2) {
-      hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, HAS_EA, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, EA, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
       return;
     }
   }
-  hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, HAS_EA, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+  hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, EA, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
 }
 
 template <int MODE, int VEC, int LPR, int SW>
 void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {   // fused edge encoder: float4 layouts only (the host entry point checks)
+      launch_fwd_d<MODE, VEC, LPR, SW, 2>(P, grid, s);
+      return;
+    }
+  }
   if (P.ea) {
-    launch_fwd_d<MODE, VEC, LPR, SW, true>(P, grid, s);
+    launch_fwd_d<MODE, VEC, LPR, SW, 1>(P, grid, s);
   } else {
-    launch_fwd_d<MODE, VEC, LPR, SW, false>(P, grid, s);
+    launch_fwd_d<MODE, VEC, LPR, SW, 0>(P, grid, s);
   }
 }
 
@@ -902,10 +1029,16 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
 
 template <int MODE, int VEC, int LPR, int SW>
 void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {
+      hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 2>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
   if (P.ea) {
-    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 1>), dim3(grid), dim3(kWgThreads), 0, s, P);
   } else {
-    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 0>), dim3(grid), dim3(kWgThreads), 0, s, P);
   }
 }
 
@@ -960,13 +1093,32 @@ extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t
   return static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float);
 }
 
-extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
-                                     const float* edge_attr, int32_t channels, int32_t mode,
-                                     int32_t msg, int32_t flags, float t, float p, float eps,
-                                     const float* t_dev, const float* p_dev, float* out,
-                                     void* aux1, float* aux2, int32_t* range_flag, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+namespace {
+struct EncArgs {
+  const float* feat;
+  const float* w;
+  const float* b;
+  int n_feat;
+};
+
+constexpr int kEncMaxParts = 1024;   // workgroups (= partial dW|db blocks) of the encoded backward
+
+int enc_check(const EncArgs* enc, int channels) {
+  if (!enc) return DGCN_OK;
+  if (!enc->feat || !enc->w) return DGCN_E_NULL;
+  if (enc->n_feat != dgcn::kEncF || channels % 4 != 0 || channels > 256) return DGCN_E_SHAPE;
+  if (!dgcn::aligned16(enc->feat) || !dgcn::aligned16(enc->w)) return DGCN_E_ALIGN;
+  return DGCN_OK;
+}
+
+int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
+                      const float* edge_attr, const EncArgs* enc, int32_t channels, int32_t mode,
+                      int32_t msg, int32_t flags, float t, float p, float eps,
+                      const float* t_dev, const float* p_dev, float* out,
+                      void* aux1, float* aux2, int32_t* range_flag, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   if (!g || !x || !out) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
   if ((flags & DGCN_FLAG_ADD_ROOT) && g->n_dst > g->n_src) return DGCN_E_SHAPE;   // root rows are x[0 .. n_dst)
   if (g->n_dst < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
   if (x_stride > 0x7fffffffLL) return DGCN_E_SHAPE;   // row addresses use a 32x32->64 multiply
@@ -993,6 +1145,10 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
   P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
+  if (enc && !vec4) return DGCN_E_ALIGN;
 
   const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;   // items walked side by side by one wave
   const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
@@ -1011,16 +1167,51 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
   }
   return launch_status();
 }
+}  // namespace
 
-extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                                      const float* edge_attr, int32_t channels, int32_t mode,
                                      int32_t msg, int32_t flags, float t, float p, float eps,
-                                     const float* t_dev, const float* p_dev, const float* gcoef,
-                                     const void* aux1, const float* out, const float* gshift,
-                                     const float* kshift, const int32_t* shift_ok, const float* groot,
-                                     float* grad_x, float* grad_edge_attr, void* workspace,
+                                     const float* t_dev, const float* p_dev, float* out,
+                                     void* aux1, float* aux2, int32_t* range_flag, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+  return gen_aggr_fwd_impl(g, x, x_stride, edge_attr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev, p_dev,
+                           out, aux1, aux2, range_flag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, float* out, void* aux1, float* aux2,
+                                         int32_t* range_flag, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_fwd_impl(g, x, x_stride, nullptr, &enc, channels, mode, msg, flags, t, p, eps, t_dev, p_dev, out,
+                           aux1, aux2, range_flag, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
+  const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;
+  const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
+  int grid = round_up8(grid_for_waves(n_items));
+  if (enc && grid > kEncMaxParts) grid = kEncMaxParts;
+  return grid;
+}
+
+int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
+                      const float* edge_attr, const EncArgs* enc, float* enc_gpart, int32_t channels, int32_t mode,
+                      int32_t msg, int32_t flags, float t, float p, float eps,
+                      const float* t_dev, const float* p_dev, const float* gcoef,
+                      const void* aux1, const float* out, const float* gshift,
+                      const float* kshift, const int32_t* shift_ok, const float* groot,
+                      float* grad_x, float* grad_edge_attr, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
+  if (enc && !enc_gpart) return DGCN_E_NULL;
   if (g->n_src < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
   if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
   if (msg != DGCN_MSG_IDENTITY && msg != DGCN_MSG_RELU_EPS) return DGCN_E_MODE;
@@ -1050,14 +1241,17 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
   P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr;
   P.groot = groot;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
+  P.enc_gpart = enc_gpart;
+  if (enc && !vec4) return DGCN_E_ALIGN;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
   }
   P.ws = static_cast<float*>(workspace);
 
-  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;
-  const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
-  const int grid = round_up8(grid_for_waves(n_items));
+  const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (mode) {
     case DGCN_AGGR_ADD: launch_bwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;
@@ -1067,4 +1261,38 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
     default: launch_bwd_mode<DGCN_AGGR_POWER>(P, vec, lpr, grid, s); break;
   }
   return launch_status();
+}
+}  // namespace
+
+extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                     const float* edge_attr, int32_t channels, int32_t mode,
+                                     int32_t msg, int32_t flags, float t, float p, float eps,
+                                     const float* t_dev, const float* p_dev, const float* gcoef,
+                                     const void* aux1, const float* out, const float* gshift,
+                                     const float* kshift, const int32_t* shift_ok, const float* groot,
+                                     float* grad_x, float* grad_edge_attr, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return gen_aggr_bwd_impl(g, x, x_stride, edge_attr, nullptr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev,
+                           p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, grad_edge_attr,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels) {
+  if (!g || channels <= 0 || channels % 4 != 0 || g->n_src <= 0) return 0;
+  return bwd_grid(g, channels, true, true);
+}
+
+extern "C" int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, const float* gcoef, const void* aux1,
+                                         const float* out, const float* gshift, const float* kshift,
+                                         const int32_t* shift_ok, const float* groot, float* grad_x,
+                                         float* enc_grad_partials, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, &enc, enc_grad_partials, channels, mode, msg, flags, t, p, eps,
+                           t_dev, p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, nullptr,
+                           workspace, workspace_bytes, stream);
 }

@@ -56,20 +56,21 @@ class GenMessagePassing(torch.nn.Module):
             return False
         return True
 
-    def _aggregate_fused(self, x, graph: Graph, edge_attr=None, relu_eps=True, eps=1e-7, add_root=False):
+    def _aggregate_fused(self, x, graph: Graph, edge_attr=None, relu_eps=True, eps=1e-7, add_root=False,
+                         edge_encoder=None):
         """AGGR_i over relu(x_src + edge_attr) + eps (or the raw rows), then the optional
         degree scaling deg^sigmoid(y) of the ``*_sum`` variants (torch_message.py:60-63,77-80)."""
         aggr = self.aggr
         if aggr is None or aggr in ("add", "mean", "max"):
             out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr or "add", relu_eps=relu_eps, eps=eps,
-                                    add_root=add_root)
+                                    add_root=add_root, edge_encoder=edge_encoder)
         elif aggr in _SOFTMAX:
             out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr, t=self.t, learn_t=self.learn_t,
-                                    relu_eps=relu_eps, eps=eps, add_root=add_root)
+                                    relu_eps=relu_eps, eps=eps, add_root=add_root, edge_encoder=edge_encoder)
         elif aggr in _POWER:
             out = ops.gen_aggregate(x, graph, edge_attr, aggr=aggr, p=self.p,
                                     learn_p=isinstance(self.p, torch.nn.Parameter), relu_eps=relu_eps, eps=eps,
-                                    add_root=add_root)
+                                    add_root=add_root, edge_encoder=edge_encoder)
         else:
             raise NotImplementedError("To be implemented")
         if aggr in ("softmax_sum", "power_sum"):
@@ -78,13 +79,15 @@ class GenMessagePassing(torch.nn.Module):
         return out
 
     # -- PyG-flavoured entry points kept for API compatibility ----------------------------
-    def propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False):
+    def propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False, edge_encoder=None):
         """``propagate(edge_index, x=x, edge_attr=edge_attr)`` as GENConv.forward calls it
         (gcn_lib/sparse/torch_vertex.py:68): message + aggregate + update in one kernel.  ``add_root`` (extension)
-        returns ``x + aggregate`` from the same kernel when ``fusable_root()``."""
+        returns ``x + aggregate`` from the same kernel when ``fusable_root()``; ``edge_encoder=(weight, bias)``
+        (extension) takes ``edge_attr`` as RAW features and applies the Linear edge encoder inside the kernels."""
         n = x.size(0) if size is None else (size[1] if isinstance(size, (tuple, list)) else size)
         return self.update(self._aggregate_fused(x, graph_of(edge_index, n), edge_attr, relu_eps=True,
-                                                 eps=getattr(self, "eps", 1e-7), add_root=add_root))
+                                                 eps=getattr(self, "eps", 1e-7), add_root=add_root,
+                                                 edge_encoder=edge_encoder))
 
     def aggregate(self, inputs, index, ptr=None, dim_size=None):
         """Aggregate an ALREADY materialised (E, C) message tensor by destination ``index``

@@ -40,10 +40,19 @@ class GENConv(GenMessagePassing):
             self.edge_encoder = BondEncoder(emb_dim=in_dim) if bond_encoder else TallLinear(edge_feat_dim, in_dim)
 
     def forward(self, x, edge_index, edge_attr=None):
-        edge_emb = self.edge_encoder(edge_attr) if (self.encode_edge and edge_attr is not None) else edge_attr
-        if self.msg_norm is None and self.fusable_root() and x.dim() == 2:
-            return self.mlp(self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True))   # h = x + m, fused
-        m = self.propagate(edge_index, x=x, edge_attr=edge_emb)
+        root = self.msg_norm is None and self.fusable_root() and x.dim() == 2      # h = x + m inside the kernel
+        enc = None
+        if self.encode_edge and edge_attr is not None:
+            lin = self.edge_encoder
+            if isinstance(lin, nn.Linear) and x.is_cuda and ops.encoder_fusable(x, edge_attr, lin.weight):
+                enc, edge_emb = (lin.weight, lin.bias), edge_attr              # Linear(8 -> C) inside the kernels
+            else:
+                edge_emb = lin(edge_attr)
+        else:
+            edge_emb = edge_attr
+        if root:
+            return self.mlp(self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True, edge_encoder=enc))
+        m = self.propagate(edge_index, x=x, edge_attr=edge_emb, edge_encoder=enc)
         if self.msg_norm is not None:
             m = self.msg_norm(x, m)
         return self.mlp(x + m)

@@ -22,6 +22,7 @@ _MODES = {
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
+ENC_FEATURES = 8                   # raw edge features of the fused edge encoder (kEncF in csrc/gen_aggr.hip)
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr.hip)
 
 
@@ -47,7 +48,7 @@ class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, t_param, p_param, graph: Graph, mode: int, msg: int,
                 eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool, track: bool,
-                add_root: bool = False):
+                add_root: bool = False, enc_feat=None, enc_w=None, enc_b=None):
         lib = _lib.load()
         dev = _lib.require_device(x, edge_attr)
         if dev != graph.device:
@@ -60,7 +61,17 @@ class _GenAggregate(torch.autograd.Function):
             edge_attr = edge_attr.float().contiguous()
             if edge_attr.shape != (graph.n_edges, C):
                 raise ValueError("edge_attr must be (E, C) matching x's channels")
-        need_grad = track and any(ctx.needs_input_grad[:4])  # no_grad/inverse passes skip the saved aux
+        enc = enc_feat is not None
+        if enc:
+            if edge_attr is not None:
+                raise ValueError("pass either edge_attr (E, C) or the raw features + encoder, not both")
+            enc_feat = enc_feat.float().contiguous()
+            enc_w = enc_w.float().contiguous()
+            enc_b = None if enc_b is None else enc_b.float().contiguous()
+            if enc_feat.shape != (graph.n_edges, ENC_FEATURES) or enc_w.shape != (C, ENC_FEATURES):
+                raise ValueError("fused edge encoder: features (E, 8), weight (C, 8)")
+        need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[15:17]))
+        # (no_grad / inverse passes skip the saved aux)
         out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         aux1 = aux2 = None
         if need_grad:
@@ -81,14 +92,22 @@ class _GenAggregate(torch.autograd.Function):
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
         with torch.cuda.device(dev):
-            rc = lib.dgcn_gen_aggr_fwd_f32(
-                graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
-                t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
-                _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
-                _lib.current_stream_handle(dev))
-        _lib.check(rc, "dgcn_gen_aggr_fwd_f32")
+            if enc:
+                rc = lib.dgcn_gen_aggr_enc_fwd_f32(
+                    graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
+                    ENC_FEATURES, C, mode, msg, flags, t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                    out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
+                    _lib.current_stream_handle(dev))
+            else:
+                rc = lib.dgcn_gen_aggr_fwd_f32(
+                    graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
+                    t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
+                    _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
+                    _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32")
         if need_grad:
             ctx.range_flag = range_flag
+            ctx.enc = (enc_feat, enc_w, enc_b) if enc else None
             ctx.save_for_backward(x, edge_attr, t_param, p_param, aux1, aux2, out)
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
             ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
@@ -125,8 +144,9 @@ class _GenAggregate(torch.autograd.Function):
             # d L/d t = sum g * (sum_e w m^2 - out^2)      
             grad_t = (g * (aux2 - out * out)).sum().reshape(t_param.shape)
 
-        grad_x = grad_ea = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        grad_x = grad_ea = grad_w = grad_b = None
+        enc = ctx.enc
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (enc is not None and any(ctx.needs_input_grad[15:17])):
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
             if edge_attr is not None and ctx.needs_input_grad[1]:
@@ -147,23 +167,41 @@ class _GenAggregate(torch.autograd.Function):
                                                        _lib.current_stream_handle(dev))
                 _lib.check(rc, "dgcn_softmax_bwd_prep_f32")
             with torch.cuda.device(dev):
-                rc = lib.dgcn_gen_aggr_bwd_f32(
-                    graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
-                    ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
-                    gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
-                    _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
-                    _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
-            _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
+                if enc is not None:
+                    feat, w_enc, b_enc = enc
+                    nparts = lib.dgcn_gen_aggr_enc_bwd_num_partials(graph.c_struct, C)
+                    gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
+                    rc = lib.dgcn_gen_aggr_enc_bwd_f32(
+                        graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
+                        ENC_FEATURES, C, mode, ctx.msg, ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
+                        _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
+                        _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
+                        grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+                else:
+                    rc = lib.dgcn_gen_aggr_bwd_f32(
+                        graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
+                        ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                        gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
+                        _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
+                        _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+            _lib.check(rc, "dgcn_gen_aggr_enc_bwd_f32" if enc is not None else "dgcn_gen_aggr_bwd_f32")
+            if enc is not None:
+                gsum = gpart.sum(0)                      # fixed-order partials -> (C, 9) = dW | db
+                if ctx.needs_input_grad[15]:
+                    grad_w = gsum[:, :ENC_FEATURES].contiguous()
+                if b_enc is not None and ctx.needs_input_grad[16]:
+                    grad_b = gsum[:, ENC_FEATURES].contiguous()
             if not ctx.needs_input_grad[0]:
                 grad_x = None
-        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10
+        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 11 + (grad_w, grad_b)
 
 
 def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
                   edge_attr: Optional[torch.Tensor] = None, aggr: str = "softmax",
                   t: Union[float, torch.Tensor] = 1.0, p: Union[float, torch.Tensor] = 1.0,
                   learn_t: bool = False, learn_p: bool = False, relu_eps: bool = True,
-                  eps: float = 1e-7, dim_size: Optional[int] = None, add_root: bool = False) -> torch.Tensor:
+                  eps: float = 1e-7, dim_size: Optional[int] = None, add_root: bool = False,
+                  edge_encoder=None) -> torch.Tensor:
     """out_i = AGGR_{e: dst(e)=i} m_e with m_e = relu(x[src(e)] (+edge_attr_e)) + eps.
 
     ``aggr`` in {add, mean, max, softmax, softmax_sg, softmax_sum, power, power_sum}; the
@@ -172,6 +210,8 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
     read on the device, no host synchronisation).  ``relu_eps=False`` aggregates raw rows.
     ``add_root`` returns ``x + out`` (the ``h = x + m`` of GENConv.forward) from the same kernel: the root row is
     added in the epilogue and the upstream gradient in the backward's, saving two elementwise passes per layer.
+    ``edge_encoder=(weight, bias)`` with ``edge_attr`` = the RAW (E, 8) edge features fuses GENConv's
+    ``Linear(edge_feat_dim -> C)`` edge encoder into the kernels (``encoder_fusable``): no (E, C) tensor at all.
     """
     if aggr not in _MODES:
         raise NotImplementedError("To be implemented")  # torch_message.py:85
@@ -186,8 +226,20 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
     if p_param is not None and not learn_p:
         p_param = p_param.detach()
     msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    if edge_encoder is not None:
+        w_enc, b_enc = edge_encoder
+        return _GenAggregate.apply(x, None, t_param, p_param, graph, mode, msg, float(eps), t_val, p_val, learn_t,
+                                   learn_p, torch.is_grad_enabled(), bool(add_root), edge_attr, w_enc, b_enc)
     return _GenAggregate.apply(x, edge_attr, t_param, p_param, graph, mode, msg, float(eps),
                                t_val, p_val, learn_t, learn_p, torch.is_grad_enabled(), bool(add_root))
+
+
+def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels (8 raw features, C % 4 == 0, C <= 256)."""
+    C = x.size(-1)
+    return (edge_feat is not None and edge_feat.dim() == 2 and edge_feat.size(1) == ENC_FEATURES and x.dim() == 2
+            and C % 4 == 0 and C <= 256 and tuple(weight.shape) == (C, ENC_FEATURES)
+            and edge_feat.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
 def selftest(device="cuda:0") -> None:

@@ -156,6 +156,35 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           float* grad_x, float* grad_edge_attr, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/*
+ * The same aggregation with the edge encoder of GENConv(encode_edge=True) fused in
+ * (gcn_lib/sparse/torch_vertex.py:56-66: edge_emb = Linear(edge_feat_dim -> C)(edge_attr), then
+ * message = relu(x_j + edge_emb) + eps): the (E, C) edge embedding is never built; every edge recomputes its row
+ * e_e = enc_weight f_e + enc_bias from n_feat raw features.
+ *   enc_feat    [E, n_feat] fp32 contiguous, ORIGINAL edge order; n_feat must be 8 (ogbn-proteins)
+ *   enc_weight  [channels, n_feat] (nn.Linear.weight), enc_bias [channels] or NULL
+ *   channels % 4 == 0, channels <= 256, 16-byte aligned pointers; anything else returns DGCN_E_SHAPE / _ALIGN and the
+ *   caller materialises the embedding and uses dgcn_gen_aggr_{fwd,bwd}_f32.
+ * Backward: grad_x as above; the encoder gradients come out as per-workgroup partials
+ *   enc_grad_partials [dgcn_gen_aggr_enc_bwd_num_partials(g, channels)][channels][n_feat + 1]
+ * whose sum over the first axis is (d enc_weight | d enc_bias); every block is fully written.
+ */
+int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
+                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
+                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
+                              const float* t_dev, const float* p_dev, float* out, void* aux1, float* aux2,
+                              int32_t* range_flag, void* workspace, size_t workspace_bytes, void* stream);
+
+int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels);
+
+int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
+                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
+                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
+                              const float* t_dev, const float* p_dev, const float* gcoef, const void* aux1,
+                              const float* out, const float* gshift, const float* kshift,
+                              const int32_t* shift_ok, const float* groot, float* grad_x,
+                              float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Node-wise prologue of the single-gather softmax backward:
  *   out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])          (channels % 4 == 0)
  * With it, dL/dm_e = g_i exp(t m_e - L_i) = out_i * exp(t m_e - kshift_c): the edge walk gathers ONE row

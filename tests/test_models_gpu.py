@@ -32,8 +32,10 @@ def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False):
+def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False, edge_encoder=None):
     from oracle import sparse_ref
+    if edge_encoder is not None:        # torch_vertex.py:64-66, fused into the kernels on the product path
+        edge_attr = torch.nn.functional.linear(edge_attr, *edge_encoder)
     m = sparse_ref.gen_propagate(x, edge_index, edge_attr, aggr=self.aggr, t=getattr(self, "t", 1.0))
     return x + m if add_root else m      # torch_vertex.py:74 (h = x + m), fused into the kernel on the product path
 
