@@ -1,0 +1,435 @@
+// Sparse generalized aggregation for gfx950 (MI355X): backward (see gen_aggr_fwd.hip for the execution shape).
+//
+// Walks the CSC (rows = sources) with the same one-wave-per-item scheme and produces grad_x (and grad_edge_attr,
+// or the fused edge encoder's dW | db partials) in one deterministic pass; softmax takes the single-gather form
+// prepared by softmax_bwd_prep_kernel when the forward's range flag allows it.
+
+#include "gen_aggr_common.h"
+
+namespace dgcn {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// backward: walk the CSC (rows = sources).  For CSC position e with destination i and
+// original edge id oe:   dz_e = R(z_e) * K(m_e, i)      
+// ---------------------------------------------------------------------------------------
+constexpr int kModeSoftmaxShifted = 100;  // internal: softmax backward with ONE gathered row per edge
+
+template <int MODE, int VEC, int LPR, int SW, int EA>
+__device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
+  constexpr int G = SW / LPR;
+  constexpr int R = kWave / SW;
+  constexpr int U = (EA == 2) ? 2 : ((VEC == 4) ? 4 : 8);   // EA == 2 keeps U feature rows + 9 VEC sums live
+  constexpr bool NEED_EID = EA != 0 || MODE == DGCN_AGGR_MAX;
+  constexpr int EV = (EA == 2) ? VEC : 1;
+  EncW<EV> enc, genc;       // encoder weights of this lane's channels, and the sums dW | db over this wave's edges
+#pragma unroll
+  for (int j = 0; j < EV; ++j) {
+    genc.b[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) genc.w[j][f] = 0.f;
+  }
+
+  const int lane = lane_id();
+  const int sl = lane % SW;
+  const int sbase = lane - sl;
+  const int g = sl / LPR;
+  const int cl = sl % LPR;
+  const int C = P.C;
+  const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
+  const int total_waves = gridDim.x * kWavesPerWg;
+  const int wave0 = virtual_block() * kWavesPerWg + (threadIdx.x >> 6);
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const int msg = P.msg;
+  const bool learn_t = P.learn_t != 0;
+
+  // same software pipeline over items as in the forward kernel
+  const int stride = total_waves * R;
+  const int sub = lane / SW;
+  Work w = fetch_work<SW>(P.g, wave0 * R + sub, n_items);
+  Work wn = fetch_work<SW>(P.g, wave0 * R + stride + sub, n_items);
+  int col0, eid0;
+  load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+  for (int base = wave0 * R; base < n_items; base += stride) {
+    int coln, eidn;
+    load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
+    const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
+    for (int cb = 0; cb < C; cb += LPR * VEC) {
+      const int c0 = cb + cl * VEC;
+      const bool act = c0 < C;
+      float xs[VEC], acc[VEC], ksh[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; ksh[j] = 0.f; }
+      if (act && w.row >= 0) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
+      if constexpr (MODE == kModeSoftmaxShifted) {
+        if (act) load_vec<VEC>(ksh, P.kshift + c0);
+      }
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0, act);
+
+      int mycol = col0, myeid = eid0;
+      for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
+        const int nb = max(0, min(SW, w.end - blk));
+        if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
+        for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
+          float gc[U][VEC], a1[U][VEC], oo[U][VEC], ea[U][VEC];
+          float fe[(EA == 2) ? U : 1][kEncF];
+          int ai[U][VEC];
+          bool ok[U];
+          int eid[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int ei = s0 + u * G + g;
+            ok[u] = ei < nb;
+            const int dst = __shfl(mycol, sbase + (ei & (SW - 1)));
+            eid[u] = 0;
+            if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              gc[u][j] = 0.f; a1[u][j] = 0.f; oo[u][j] = 0.f; ea[u][j] = 0.f; ai[u][j] = -1;
+            }
+            if (ok[u] && act) {
+              const int64_t ro = static_cast<int64_t>(dst) * C + c0;
+              if constexpr (MODE == kModeSoftmaxShifted) {
+                load_vec<VEC>(gc[u], P.gshift + ro);
+              } else {
+                load_vec<VEC>(gc[u], P.gcoef + ro);
+              }
+              if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+                load_vec<VEC>(a1[u], static_cast<const float*>(P.aux1) + ro);
+                if (learn_t) load_vec<VEC>(oo[u], P.out + ro);
+              }
+              if constexpr (MODE == DGCN_AGGR_MAX) {
+                load_vec_i<VEC>(ai[u], static_cast<const int32_t*>(P.aux1) + ro);
+              }
+              if constexpr (EA == 1) {
+                load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
+              }
+              if constexpr (EA == 2) enc_feat_row(fe[u], P.enc_feat, eid[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            float dz[VEC];
+            if constexpr (EA == 2) {
+              if (act) enc_apply<VEC>(ea[u], enc, fe[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];
+              const float m = msg_apply(z, msg, eps);
+              const float r = (msg == DGCN_MSG_RELU_EPS) ? (z > 0.f ? 1.f : 0.f) : 1.f;
+              float k;
+              if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+                float wgt = fast_exp(t * m - a1[u][j]);
+                if (learn_t) wgt *= 1.f + t * (m - oo[u][j]);
+                k = gc[u][j] * wgt;
+              } else if constexpr (MODE == kModeSoftmaxShifted) {
+                // g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] * exp(t m - K_c): the bracket was gathered
+                k = gc[u][j] * fast_exp(t * m - ksh[j]);
+              } else if constexpr (MODE == DGCN_AGGR_POWER) {
+                const bool in = (m >= kPowLo) && (m <= kPowHi);
+                const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
+                k = in ? gc[u][j] * fast_pow(uu, p - 1.f) : 0.f;
+              } else if constexpr (MODE == DGCN_AGGR_MAX) {
+                k = (ai[u][j] == eid[u]) ? gc[u][j] : 0.f;
+              } else {
+                k = gc[u][j];
+              }
+              dz[j] = r * k;
+              acc[j] += dz[j];
+            }
+            if constexpr (EA == 1) {
+              if (act && P.grad_ea) {
+                store_vec<VEC>(P.grad_ea + static_cast<int64_t>(eid[u]) * C + c0, dz);
+              }
+            }
+            if constexpr (EA == 2) {
+              if (act) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                  genc.b[j] += dz[j];
+#pragma unroll
+                  for (int f = 0; f < kEncF; ++f) genc.w[j][f] = fmaf(dz[j], fe[u][f], genc.w[j][f]);
+                }
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int off = LPR; off < SW; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], off);
+      }
+      if (g == 0 && act && w.row >= 0) {
+        if (w.slot >= 0) {
+          store_vec<VEC>(P.ws + static_cast<int64_t>(w.slot) * C + c0, acc);
+        } else {
+          if (P.groot) {
+            float gr[VEC];
+            load_vec<VEC>(gr, P.groot + static_cast<int64_t>(w.row) * C + c0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += gr[j];
+          }
+          store_vec<VEC>(P.grad_x + static_cast<int64_t>(w.row) * C + c0, acc);
+        }
+      }
+    }
+    w = wn;
+    wn = wnn;
+    col0 = coln;
+    eid0 = eidn;
+  }
+
+  if constexpr (EA == 2) {
+    // dW | db of this workgroup: lanes with the same channel group (cl) are summed with shuffles, the four waves
+    // through LDS in a fixed order, and the workgroup writes one (C, kEncF + 1) partial; the host sums the partials.
+    constexpr int NV = VEC * (kEncF + 1);
+    __shared__ float red[kWavesPerWg][LPR * NV];
+    float vals[NV];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+      for (int f = 0; f < kEncF; ++f) vals[j * (kEncF + 1) + f] = genc.w[j][f];
+      vals[j * (kEncF + 1) + kEncF] = genc.b[j];
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) vals[q] += __shfl_xor(vals[q], off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane < LPR) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) red[wv][lane * NV + q] = vals[q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LPR * NV; i += kWgThreads) {
+      const int ch = (i / NV) * VEC + (i % NV) / (kEncF + 1);
+      if (ch < C) {
+        const float tsum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        P.enc_gpart[(static_cast<int64_t>(blockIdx.x) * C + ch) * (kEncF + 1) + (i % NV) % (kEncF + 1)] = tsum;
+      }
+    }
+  }
+}
+
+template <int MODE, int VEC, int LPR, int SW, int EA>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    // single-gather form when the caller prepared it and the device-side range check passed
+    if (P.gshift != nullptr && !P.learn_t && *P.shift_ok != 0) {
+      gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, SW, EA>(P);
+      return;
+    }
+  }
+  gen_aggr_bwd_body<MODE, VEC, LPR, SW, EA>(P);
+}
+
+// out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])   (node-wise prologue of the single-gather backward)
+__global__ __launch_bounds__(kWgThreads) void softmax_bwd_prep_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ L,
+                                                                      const float* __restrict__ kshift,
+                                                                      float* __restrict__ out, int64_t n_vec4,
+                                                                      int c_vec4) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec4; i += stride) {
+    const int cv = static_cast<int>(i % c_vec4);
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4 lv = reinterpret_cast<const float4*>(L)[i];
+    const float4 kv = reinterpret_cast<const float4*>(kshift)[cv];
+    float4 o;
+    o.x = gv.x * fast_exp(kv.x - lv.x);
+    o.y = gv.y * fast_exp(kv.y - lv.y);
+    o.z = gv.z * fast_exp(kv.z - lv.z);
+    o.w = gv.w * fast_exp(kv.w - lv.w);
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const BwdParams P) {
+  const int lane = lane_id();
+  const int C = P.C;
+  const int n_work = P.g.n_work;
+  const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  if (wave >= P.g.n_split) return;
+  const int i0 = uni(P.g.split_item[wave]);
+  const int row = uni(P.g.work_row[i0]);
+  int i1 = i0;
+  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
+  for (int c = lane; c < C; c += kWave) {
+    float acc = 0.f;
+    for (int i = i0; i < i1; ++i) acc += P.ws[static_cast<int64_t>(P.g.work_slot[i]) * C + c];
+    P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
+  }
+}
+
+template <int MODE, int VEC, int LPR, int SW>
+void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {
+      hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 2>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
+  if (P.ea) {
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 1>), dim3(grid), dim3(kWgThreads), 0, s, P);
+  } else {
+    hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 0>), dim3(grid), dim3(kWgThreads), 0, s, P);
+  }
+}
+
+template <int MODE>
+void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
+  if (vec == 4) {
+    const bool sub = subgroup_width(lpr) < kWave;
+    switch (lpr) {
+      case 4: sub ? launch_bwd_ea<MODE, 4, 4, 16>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s); break;
+      case 8: sub ? launch_bwd_ea<MODE, 4, 8, 32>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s); break;
+      case 16: launch_bwd_ea<MODE, 4, 16, 64>(P, grid, s); break;
+      case 32: launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
+      default: launch_bwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
+    }
+  } else {
+    launch_bwd_ea<MODE, 1, 64, 64>(P, grid, s);
+  }
+  if (P.g.n_work && P.g.n_split > 0) {
+    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
+    hipLaunchKernelGGL(gen_aggr_bwd_merge_kernel, dim3(mg), dim3(kWgThreads), 0, s, P);
+  }
+}
+
+
+int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
+  const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;
+  const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
+  int grid = round_up8(grid_for_waves(n_items));
+  if (enc && grid > kEncMaxParts) grid = kEncMaxParts;
+  return grid;
+}
+
+int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
+                      const float* edge_attr, const EncArgs* enc, float* enc_gpart, int32_t channels, int32_t mode,
+                      int32_t msg, int32_t flags, float t, float p, float eps,
+                      const float* t_dev, const float* p_dev, const float* gcoef,
+                      const void* aux1, const float* out, const float* gshift,
+                      const float* kshift, const int32_t* shift_ok, const float* groot,
+                      float* grad_x, float* grad_edge_attr, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
+  if (enc && !enc_gpart) return DGCN_E_NULL;
+  if (g->n_src < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
+  if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
+  if (msg != DGCN_MSG_IDENTITY && msg != DGCN_MSG_RELU_EPS) return DGCN_E_MODE;
+  if ((mode == DGCN_AGGR_SOFTMAX || mode == DGCN_AGGR_MAX) && !aux1) return DGCN_E_NULL;
+  if (mode == DGCN_AGGR_SOFTMAX && (flags & DGCN_FLAG_LEARN_T) && !out) return DGCN_E_NULL;
+  if (g->n_src == 0) return DGCN_OK;
+  if (!g->t_rowptr || (g->n_edges > 0 && (!g->t_col || !g->t_eperm))) return DGCN_E_NULL;
+  if (g->t_n_work && (!g->t_work_row || !g->t_work_beg || !g->t_work_end || !g->t_work_slot)) return DGCN_E_NULL;
+  if (g->t_n_work && g->t_n_split > 0 && !g->t_split_item) return DGCN_E_NULL;
+  if (workspace_bytes < dgcn_gen_aggr_bwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
+  if (g->t_n_work && g->t_n_slots > 0 && !workspace) return DGCN_E_NULL;
+
+  const bool vec4 = (channels % 4 == 0) && (x_stride % 4 == 0) && aligned16(x) && aligned16(gcoef) &&
+                    aligned16(grad_x) && (!edge_attr || aligned16(edge_attr)) && (!groot || aligned16(groot)) &&
+                    (!aux1 || aligned16(aux1)) && (!out || aligned16(out)) &&
+                    (!grad_edge_attr || aligned16(grad_edge_attr)) &&
+                    (!workspace || aligned16(workspace));
+  const int vec = vec4 ? 4 : 1;
+  const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
+
+  BwdParams P;
+  P.g = WalkGraph{g->n_src, g->t_n_work, g->t_rowptr, g->t_col, g->t_eperm,
+                  g->t_work_row, g->t_work_beg, g->t_work_end, g->t_work_slot, g->t_n_split, g->t_split_item};
+  P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
+  P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
+  P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
+  P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
+  P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr;
+  P.groot = groot;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
+  P.enc_gpart = enc_gpart;
+  if (enc && !vec4) return DGCN_E_ALIGN;
+  if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
+    P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
+  }
+  P.ws = static_cast<float*>(workspace);
+
+  const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (mode) {
+    case DGCN_AGGR_ADD: launch_bwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;
+    case DGCN_AGGR_MEAN: launch_bwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;  // gcoef pre-scaled
+    case DGCN_AGGR_MAX: launch_bwd_mode<DGCN_AGGR_MAX>(P, vec, lpr, grid, s); break;
+    case DGCN_AGGR_SOFTMAX: launch_bwd_mode<DGCN_AGGR_SOFTMAX>(P, vec, lpr, grid, s); break;
+    default: launch_bwd_mode<DGCN_AGGR_POWER>(P, vec, lpr, grid, s); break;
+  }
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshift, float* out,
+                                         int64_t n_rows, int32_t channels, void* stream) {
+  if (!g || !L || !kshift || !out) return DGCN_E_NULL;
+  if (n_rows < 0 || channels <= 0 || channels % 4 != 0) return DGCN_E_SHAPE;
+  if (!aligned16(g) || !aligned16(L) || !aligned16(kshift) || !aligned16(out)) return DGCN_E_ALIGN;
+  if (n_rows == 0) return DGCN_OK;
+  const int64_t n4 = n_rows * (channels / 4);
+  int64_t blocks = (n4 + kWgThreads - 1) / kWgThreads;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_bwd_prep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWgThreads), 0,
+                     static_cast<hipStream_t>(stream), g, L, kshift, out, n4, channels / 4);
+  return launch_status();
+}
+
+
+extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
+  if (!g || g->t_n_work == 0) return 0;
+  return static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float);
+}
+
+
+extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                     const float* edge_attr, int32_t channels, int32_t mode,
+                                     int32_t msg, int32_t flags, float t, float p, float eps,
+                                     const float* t_dev, const float* p_dev, const float* gcoef,
+                                     const void* aux1, const float* out, const float* gshift,
+                                     const float* kshift, const int32_t* shift_ok, const float* groot,
+                                     float* grad_x, float* grad_edge_attr, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return gen_aggr_bwd_impl(g, x, x_stride, edge_attr, nullptr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev,
+                           p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, grad_edge_attr,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels) {
+  if (!g || channels <= 0 || channels % 4 != 0 || g->n_src <= 0) return 0;
+  return bwd_grid(g, channels, true, true);
+}
+
+extern "C" int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, const float* gcoef, const void* aux1,
+                                         const float* out, const float* gshift, const float* kshift,
+                                         const int32_t* shift_ok, const float* groot, float* grad_x,
+                                         float* enc_grad_partials, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, &enc, enc_grad_partials, channels, mode, msg, flags, t, p, eps,
+                           t_dev, p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, nullptr,
+                           workspace, workspace_bytes, stream);
+}
+

@@ -1,0 +1,243 @@
+// Shared pieces of the sparse generalized aggregation kernels (gen_aggr_fwd.hip / gen_aggr_bwd.hip): walk
+// descriptors, the per-item software pipeline helpers, the fused edge encoder and the host-side layout choices.
+// Everything lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+
+#include <stdlib.h>
+
+#include "dgcn_common.h"
+
+namespace dgcn {
+namespace {
+
+constexpr float kShiftSafe = 80.f;  // |L| below this keeps exp(-L) and exp(t*m) inside the fp32 range
+constexpr float kPowLo = 1e-7f;  // torch_message.py:69
+constexpr float kPowHi = 1e1f;
+
+struct WalkGraph {
+  int n_rows;
+  int n_work;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const int32_t* eperm;
+  const int32_t* work_row;
+  const int32_t* work_beg;
+  const int32_t* work_end;
+  const int32_t* work_slot;
+  int n_split;
+  const int32_t* split_item;
+};
+
+struct FwdParams {
+  WalkGraph g;
+  const float* x;
+  int64_t x_stride;
+  const float* ea;
+  int C;
+  int msg;
+  float t, p, eps;
+  const float* t_dev;
+  const float* p_dev;
+  float* out;
+  void* aux1;
+  float* aux2;
+  int32_t* range_flag;  // softmax: set to 1 when some |L_i| >= kShiftSafe (the backward then gathers two rows)
+  int add_root;         // out_i += x_i (the GENConv residual h = x + m fused into the epilogue)
+  const float* enc_feat;  // EA == 2: raw edge features [E, kEncF] in original edge order; e_e = enc_w f_e + enc_b
+  const float* enc_w;     // [C, kEncF] (nn.Linear weight)
+  const float* enc_b;     // [C] or null
+  float* ws;  // partial slots: [slot][4][C]
+};
+
+struct BwdParams {
+  WalkGraph g;      // transposed walk: rows = sources, col = destinations
+  const float* x;
+  int64_t x_stride;
+  const float* ea;
+  int C;
+  int msg;
+  int learn_t;
+  float t, p, eps;
+  const float* t_dev;
+  const float* p_dev;
+  const float* gcoef;
+  const void* aux1;
+  const float* out;
+  const float* gshift;    // [n_dst, C] g_i * exp(kshift_c - L_i)  (single-gather softmax backward) or null
+  const float* kshift;    // [C] per-channel shift
+  const int32_t* shift_ok;  // device flag: 1 = the shifted form is numerically safe for this call
+  const float* groot;     // [n_src, C] upstream gradient added to grad_x (backward of add_root) or null
+  const float* enc_feat;  // EA == 2: see FwdParams
+  const float* enc_w;
+  const float* enc_b;
+  float* enc_gpart;       // EA == 2: [gridDim.x][C][kEncF + 1] per-workgroup partial (dW | db)
+  float* grad_x;
+  float* grad_ea;
+  float* ws;  // partial slots: [slot][C]
+};
+
+struct Work {
+  int row, beg, end, slot;
+};
+
+// SW = lanes that share one work item.  SW == 64: the whole wave, everything wave-uniform (SGPRs).
+// SW < 64 (narrow rows): 64/SW sub-groups walk different items side by side; an out-of-range item is empty.
+template <int SW>
+__device__ __forceinline__ int maybe_uni(int v) {
+  if constexpr (SW == kWave) return uni(v);
+  return v;
+}
+
+template <int SW>
+__device__ __forceinline__ bool any_sub(bool c) {
+  if constexpr (SW == kWave) return c;
+  return __any(c);
+}
+
+template <int SW>
+__device__ __forceinline__ bool all_sub(bool c) {
+  if constexpr (SW == kWave) return c;
+  return __all(c);
+}
+
+template <int SW>
+__device__ __forceinline__ Work fetch_work(const WalkGraph& g, int item, int n_items) {
+  Work w;
+  if (item >= n_items) {   // past the end (sub-group tail, or the look-ahead of the last items): empty
+    w.row = -1; w.beg = 0; w.end = 0; w.slot = -1;
+    return w;
+  }
+  if (g.n_work) {
+    w.row = maybe_uni<SW>(g.work_row[item]);
+    w.beg = maybe_uni<SW>(g.work_beg[item]);
+    w.end = maybe_uni<SW>(g.work_end[item]);
+    w.slot = maybe_uni<SW>(g.work_slot[item]);
+  } else {
+    w.row = item;
+    w.beg = maybe_uni<SW>(g.rowptr[item]);
+    w.end = maybe_uni<SW>(g.rowptr[item + 1]);
+    w.slot = -1;
+  }
+  return w;
+}
+
+// First/next block of <= SW column ids (and original edge ids) of an item, one per lane of the sub-group.
+template <int SW, bool NEED_EID>
+__device__ __forceinline__ void load_cols(const WalkGraph& g, const Work& w, int blk, int sl, int& col, int& eid) {
+  col = 0;
+  eid = 0;
+  if (sl < w.end - blk) {
+    col = g.col[blk + sl];
+    if constexpr (NEED_EID) eid = g.eperm ? g.eperm[blk + sl] : blk + sl;
+  }
+}
+
+// Block b runs on XCD b % 8 (observed dispatch order; used for L2 affinity only).  Remap so
+// that, within one grid-stride sweep, each XCD covers a contiguous range of rows: rows that
+// are adjacent in a locality-ordered graph then share their neighbours' lines in one L2.
+__device__ __forceinline__ int virtual_block() {
+  const int per = gridDim.x / kNumXCD;  // gridDim.x is a multiple of 8
+  return (blockIdx.x % kNumXCD) * per + blockIdx.x / kNumXCD;
+}
+
+__device__ __forceinline__ float msg_apply(float z, int msg, float eps) {
+  return msg == DGCN_MSG_RELU_EPS ? fmaxf(z, 0.f) + eps : z;
+}
+
+__device__ __forceinline__ float fast_pow(float u, float p) {  // u > 0
+  return fast_exp2(p * fast_log2(u));
+}
+
+// ---- fused edge encoder (EA == 2): e_e = W f_e + b with kEncF raw features per edge -------------------------
+// GENConv(encode_edge=True) builds edge_emb = Linear(edge_feat_dim -> C)(edge_attr), an (E, C) tensor written by
+// a GEMM and read back by the aggregation (gcn_lib/sparse/torch_vertex.py:56-66).  With 8 raw features per edge
+// (ogbn-proteins) the row is cheaper to recompute per edge from 32 bytes than to load as 4C bytes.
+constexpr int kEncF = 8;
+
+template <int VEC>
+struct EncW {
+  float w[VEC][kEncF];
+  float b[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void enc_load(EncW<VEC>& e, const float* __restrict__ W, const float* __restrict__ b,
+                                         int c0, bool act) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    e.b[j] = (act && b) ? b[c0 + j] : 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) e.w[j][f] = act ? W[(c0 + j) * kEncF + f] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void enc_feat_row(float (&fe)[kEncF], const float* __restrict__ feat, int eid) {
+  const float4* p = reinterpret_cast<const float4*>(feat + static_cast<int64_t>(eid) * kEncF);
+  const float4 a = p[0], b = p[1];
+  fe[0] = a.x; fe[1] = a.y; fe[2] = a.z; fe[3] = a.w;
+  fe[4] = b.x; fe[5] = b.y; fe[6] = b.z; fe[7] = b.w;
+}
+
+template <int VEC>
+__device__ __forceinline__ void enc_apply(float (&out)[VEC], const EncW<VEC>& e, const float (&fe)[kEncF]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float a = e.b[j];
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) a = fmaf(e.w[j][f], fe[f], a);
+    out[j] = a;
+  }
+}
+
+// Address of row `src`: a 32x32->64 multiply (one v_mad_u64_u32); the host checks 0 <= stride < 2^31.
+__device__ __forceinline__ const float* row_ptr(const float* base, int src, uint32_t stride) {
+  return base + static_cast<uint64_t>(static_cast<uint32_t>(src)) * stride;
+}
+
+// EA: 0 = no edge features, 1 = dense (E, C) edge features, 2 = encoded on the fly from kEncF raw features
+// ---------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------
+int lanes_per_row(int C, int vec) {
+  const int need = (C + vec - 1) / vec;
+  int lpr = 4;
+  while (lpr < need && lpr < kWave) lpr <<= 1;
+  return lpr;
+}
+
+int round_up8(int v) { return (v + 7) / 8 * 8; }
+
+// Sub-group width for narrow rows: 4 edge groups per item (two merge steps instead of four, and the item
+// bookkeeping shared by 64/SW rows).  DGCN_SUBGROUP=64 in the environment forces one item per wave.
+int subgroup_width(int lpr) {
+  static const int forced = [] {
+    const char* e = getenv("DGCN_SUBGROUP");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == kWave) return kWave;
+  const int sw = lpr * 4;
+  return sw < kWave ? sw : kWave;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+
+struct EncArgs {
+  const float* feat;
+  const float* w;
+  const float* b;
+  int n_feat;
+};
+
+constexpr int kEncMaxParts = 1024;   // workgroups (= partial dW|db blocks) of the encoded backward
+
+inline int enc_check(const EncArgs* enc, int channels) {
+  if (!enc) return DGCN_OK;
+  if (!enc->feat || !enc->w) return DGCN_E_NULL;
+  if (enc->n_feat != kEncF || channels % 4 != 0 || channels > 256) return DGCN_E_SHAPE;
+  if (!aligned16(enc->feat) || !aligned16(enc->w)) return DGCN_E_ALIGN;
+  return DGCN_OK;
+}
+
+}  // namespace
+}  // namespace dgcn

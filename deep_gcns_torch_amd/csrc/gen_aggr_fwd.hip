@@ -1,0 +1,653 @@
+// Sparse generalized aggregation for gfx950 (MI355X): forward and backward.
+//
+// Replaces, in ONE pass per direction and without any (E,C) temporary,
+//   GENConv.propagate/message          gcn_lib/sparse/torch_vertex.py:68,78-85
+//   GenMessagePassing.aggregate        gcn_lib/sparse/torch_message.py:44-85
+//   torch_scatter scatter/scatter_softmax/scatter_max underneath them.
+//
+// Execution shape (wave = 64 lanes):
+//   * one wave owns one work item = one destination row (or a <=chunk slice of a hub row);
+//   * a row of C fp32 channels is covered by LPR = C/4 lanes holding a float4 each, so a
+//     wave walks G = 64/LPR edges of the SAME row at once: every global_load_dwordx4 of the
+//     wave fetches G full, 16B-aligned source rows (C=128: 2 rows = 1 KiB per instruction);
+//   * column indices are read 64 at a time with one coalesced load and handed to the edge
+//     groups with ds_bpermute, so the index fetch is off the gather's critical path;
+//   * U batches of loads are issued back to back before any is consumed (memory-level
+//     parallelism), the reduction state lives in registers (online softmax: running
+//     max / denominator / weighted sum per channel), and the G partial states are combined
+//     with wave shuffles at the end.  No atomics anywhere: results are bit-reproducible.
+//
+// The bound is HBM: algorithmic bytes per launch = E*(4C+4) + N*4C + 4(N+1)  (DESIGN.md).
+
+#include "gen_aggr_common.h"
+
+namespace dgcn {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+// Per-channel reduction state.  Meaning by mode:
+//   SOFTMAX: a = running max M' of s' = t*log2(e)*m, b = sum 2^(s'-M'), c = sum 2^(s'-M')*m, d = sum 2^(s'-M')*m^2
+//            (inside the edge loop c, d hold the sums over r = m - eps; see softmax_fold)
+//   POWER  : b = sum u^p, d = sum u^p ln u
+//   ADD/MEAN: b = sum m
+//   MAX    : a = best m, idx = original edge id of the first maximal edge
+template <int VEC>
+struct State {
+  float a[VEC], b[VEC], c[VEC], d[VEC];
+  int idx[VEC];
+};
+
+template <int MODE, int VEC>
+__device__ __forceinline__ void state_init(State<VEC>& s) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    s.a[j] = DGCN_NEG_INF;
+    s.b[j] = 0.f;
+    s.c[j] = 0.f;
+    s.d[j] = 0.f;
+    s.idx[j] = -1;
+  }
+}
+
+// merge `o` (another partial of the same row) into `s`
+template <int MODE, int VEC>
+__device__ __forceinline__ void state_merge(State<VEC>& s, const State<VEC>& o) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+      const float nm = fmaxf(s.a[j], o.a[j]);
+      const float s1 = (s.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp2(s.a[j] - nm);   // a is in the log2 domain
+      const float s2 = (o.a[j] == DGCN_NEG_INF) ? 0.f : fast_exp2(o.a[j] - nm);
+      s.b[j] = s.b[j] * s1 + o.b[j] * s2;
+      s.c[j] = s.c[j] * s1 + o.c[j] * s2;
+      s.d[j] = s.d[j] * s1 + o.d[j] * s2;
+      s.a[j] = nm;
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+      const bool take = (o.a[j] > s.a[j]) ||
+                        (o.a[j] == s.a[j] && o.idx[j] >= 0 && (s.idx[j] < 0 || o.idx[j] < s.idx[j]));
+      if (take) {
+        s.a[j] = o.a[j];
+        s.idx[j] = o.idx[j];
+      }
+    } else {
+      s.b[j] += o.b[j];
+      s.d[j] += o.d[j];
+    }
+  }
+}
+
+template <int MODE, int VEC>
+__device__ __forceinline__ State<VEC> state_shfl_xor(const State<VEC>& s, int off) {
+  State<VEC> o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    o.a[j] = o.b[j] = o.c[j] = o.d[j] = 0.f;
+    o.idx[j] = -1;
+    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+      o.a[j] = __shfl_xor(s.a[j], off);
+      o.b[j] = __shfl_xor(s.b[j], off);
+      o.c[j] = __shfl_xor(s.c[j], off);
+      o.d[j] = __shfl_xor(s.d[j], off);
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+      o.a[j] = __shfl_xor(s.a[j], off);
+      o.idx[j] = __shfl_xor(s.idx[j], off);
+    } else {
+      o.b[j] = __shfl_xor(s.b[j], off);
+      o.d[j] = __shfl_xor(s.d[j], off);
+    }
+  }
+  return o;
+}
+
+// ---- softmax fold, written for VALU economy ------------------------------------------------------------
+// The forward kernel is co-limited by HBM and VALU issue (16 G channel-visits per launch at the products
+// shape), so the per-element work is kept minimal:
+//   * everything in the log2 domain: s' = t*log2(e)*m, weights exp2(s' - max') -> one v_exp_f32 per element, no
+//     extra multiply;
+//   * m = relu(z) + eps is never formed: s' = fma(t2, relu(z), t2*eps), and sum(e*m) = sum(e*relu(z)) + eps*sum(e)
+//     is fixed up once per row;
+//   * channel PAIRS as 2-vectors so mul/add/fma become v_pk_*_f32 (two channels per instruction);
+//   * full batches (all U*G edge slots valid) take a variant without any masking.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vrelu(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));   // one instruction (fmaxf adds a canonicalising max)
+  return r;
+}
+__device__ __forceinline__ f2 vrelu(f2 v) { return f2{vrelu(v.x), vrelu(v.y)}; }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ float vexp2(float a) { return fast_exp2(a); }
+__device__ __forceinline__ f2 vexp2(f2 a) { return f2{fast_exp2(a.x), fast_exp2(a.y)}; }
+__device__ __forceinline__ float vsplat(float, float v) { return v; }
+__device__ __forceinline__ f2 vsplat(f2, float v) { return f2{v, v}; }
+
+// T = float or f2.  (a, D, A, A2) = running max' / sum e / sum e*r / sum e*r^2 with r = relu(z) (or z).
+template <typename T, int U, bool RELU, bool WITH_D, bool FULL>
+__device__ __forceinline__ void softmax_fold(T& a, T& D, T& A, T& A2, const T (&z)[U], const bool (&ok)[U],
+                                             float t2, float c0) {
+  T r[U], s[U];
+  const T vt2 = vsplat(a, t2), vc0 = vsplat(a, c0);
+  T nm = a;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    r[u] = RELU ? vrelu(z[u]) : z[u];
+    s[u] = r[u] * vt2 + vc0;
+    if constexpr (!FULL) {
+      if (u > 0) s[u] = ok[u] ? s[u] : vsplat(a, DGCN_NEG_INF);   // ok[0] holds (caller's guard)
+    }
+    nm = vmax(nm, s[u]);
+  }
+  const T sc = vexp2(a - nm);   // exp2(-inf) = 0 on the first batch
+  D = D * sc;
+  A = A * sc;
+  if constexpr (WITH_D) A2 = A2 * sc;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const T e = vexp2(s[u] - nm);   // 0 for masked edges
+    D = D + e;
+    if constexpr (WITH_D) {
+      const T er = e * r[u];
+      A = A + er;
+      A2 = er * r[u] + A2;
+    } else {
+      A = e * r[u] + A;
+    }
+  }
+  a = nm;
+}
+
+// Fold U gathered rows (this lane's VEC channels of each) into the state.
+template <int MODE, int VEC, int U, bool RELU, bool WITH_D, bool FULL>
+__device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][VEC],
+                                           const bool (&ok)[U], const int (&eid)[U], float eps,
+                                           float t2, float c0, float p) {
+  if constexpr (!FULL) {
+    if (!ok[0]) return;  // ok[] is monotone in u: nothing valid for this edge group
+  }
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    if constexpr (VEC % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; j += 2) {
+        f2 a = {st.a[j], st.a[j + 1]}, D = {st.b[j], st.b[j + 1]}, A = {st.c[j], st.c[j + 1]};
+        f2 A2 = {st.d[j], st.d[j + 1]};
+        f2 z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) z[u] = f2{v[u][j], v[u][j + 1]};
+        softmax_fold<f2, U, RELU, WITH_D, FULL>(a, D, A, A2, z, ok, t2, c0);
+        st.a[j] = a.x; st.a[j + 1] = a.y;
+        st.b[j] = D.x; st.b[j + 1] = D.y;
+        st.c[j] = A.x; st.c[j + 1] = A.y;
+        st.d[j] = A2.x; st.d[j + 1] = A2.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) z[u] = v[u][j];
+        softmax_fold<float, U, RELU, WITH_D, FULL>(st.a[j], st.b[j], st.c[j], st.d[j], z, ok, t2, c0);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if constexpr (MODE == DGCN_AGGR_POWER) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (FULL || ok[u]) {
+          const float m = RELU ? vrelu(v[u][j]) + eps : v[u][j];
+          const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
+          const float l2 = fast_log2(uu);
+          const float up = fast_exp2(p * l2);
+          st.b[j] += up;
+          if constexpr (WITH_D) st.d[j] = fmaf(up, l2 * 0.6931471805599453f, st.d[j]);
+        }
+      }
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (FULL || ok[u]) {
+          const float m = RELU ? vrelu(v[u][j]) + eps : v[u][j];
+          // strict '>' keeps the FIRST maximal edge (edges arrive in increasing id per group)
+          if (m > st.a[j] || st.idx[j] < 0) {
+            st.a[j] = m;
+            st.idx[j] = eid[u];
+          }
+        }
+      }
+    } else {  // ADD / MEAN
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (FULL || ok[u]) st.b[j] += RELU ? vrelu(v[u][j]) + eps : v[u][j];
+      }
+    }
+  }
+}
+
+template <int MODE, int VEC, int LPR, int SW, int EA, bool RELU, bool WITH_D>
+__device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
+  constexpr int G = SW / LPR;               // edges of one item walked in parallel
+  constexpr int R = kWave / SW;             // items walked side by side by one wave
+#ifdef DGCN_FWD_U
+  constexpr int U = DGCN_FWD_U;
+#else
+  constexpr int U = (VEC == 4) ? 4 : 8;     // load batches in flight per lane
+#endif
+  constexpr bool NEED_EID = EA != 0 || MODE == DGCN_AGGR_MAX;
+
+  const int lane = lane_id();
+  const int sl = lane % SW;                 // lane within its sub-group
+  const int sbase = lane - sl;
+  const int g = sl / LPR;
+  const int cl = sl % LPR;
+  const int C = P.C;
+  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
+  const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
+  const int total_waves = gridDim.x * kWavesPerWg;
+  const int wave0 = virtual_block() * kWavesPerWg + (threadIdx.x >> 6);
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const float eps_r = RELU ? eps : 0.f;     // the part of m = relu(z) + eps that the softmax fold leaves out
+  const float t2 = t * 1.4426950408889634f; // log2 domain
+  const float c0 = t2 * eps_r;
+
+  // Software pipeline over the items of this wave: while item i is walked, the column ids of item i+1 and the
+  // row bounds of item i+2 are already in flight, so a row does not start with two dependent memory latencies.
+  const int stride = total_waves * R;
+  const int sub = lane / SW;
+  Work w = fetch_work<SW>(P.g, wave0 * R + sub, n_items);
+  Work wn = fetch_work<SW>(P.g, wave0 * R + stride + sub, n_items);
+  int col0, eid0;
+  load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+  for (int base = wave0 * R; base < n_items; base += stride) {
+#ifndef DGCN_NO_PREFETCH
+    int coln, eidn;
+    load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
+    const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
+#endif
+    for (int cb = 0; cb < C; cb += LPR * VEC) {
+      const int c0ch = cb + cl * VEC;
+      const bool act = c0ch < C;
+      State<VEC> st;
+      state_init<MODE, VEC>(st);
+      EncW<(EA == 2 ? VEC : 1)> enc;
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0ch, act);
+
+      int mycol = col0, myeid = eid0;
+      for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
+        const int nb = max(0, min(SW, w.end - blk));
+        if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
+        for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
+          float v[U][VEC];
+          bool ok[U];
+          int eid[U];
+          const bool full = all_sub<SW>(nb - s0 >= G * U) && (cb + LPR * VEC <= C);   // wave-uniform
+          if (full) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int ei = s0 + u * G + g;
+              ok[u] = true;
+              const int src = __shfl(mycol, sbase + (ei & (SW - 1)));
+              eid[u] = 0;
+              if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
+              load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
+              if constexpr (EA == 1) {
+                float a[VEC];
+                load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+              }
+              if constexpr (EA == 2) {
+                float fe[kEncF], a[VEC];
+                enc_feat_row(fe, P.enc_feat, eid[u]);
+                enc_apply<VEC>(a, enc, fe);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+              }
+            }
+            accumulate<MODE, VEC, U, RELU, WITH_D, true>(st, v, ok, eid, eps, t2, c0, p);
+          } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int ei = s0 + u * G + g;
+              ok[u] = ei < nb;
+              const int src = __shfl(mycol, sbase + (ei & (SW - 1)));
+              eid[u] = 0;
+              if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) v[u][j] = 0.f;
+              if (ok[u] && act) {
+                load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
+                if constexpr (EA == 1) {
+                  float a[VEC];
+                  load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+                }
+                if constexpr (EA == 2) {
+                  float fe[kEncF], a[VEC];
+                  enc_feat_row(fe, P.enc_feat, eid[u]);
+                  enc_apply<VEC>(a, enc, fe);
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+                }
+              }
+            }
+            accumulate<MODE, VEC, U, RELU, WITH_D, false>(st, v, ok, eid, eps, t2, c0, p);
+          }
+        }
+      }
+
+      // combine the G edge groups of each item (all lanes participate)
+#pragma unroll
+      for (int off = LPR; off < SW; off <<= 1) {
+        const State<VEC> o = state_shfl_xor<MODE, VEC>(st, off);
+        state_merge<MODE, VEC>(st, o);
+      }
+
+      if (g == 0 && act && w.row >= 0) {
+        if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+          // back to sums over m = r + eps:  sum e m = A + eps D,  sum e m^2 = A2 + 2 eps A + eps^2 D
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            if constexpr (WITH_D) st.d[j] = fmaf(eps_r, fmaf(eps_r, st.b[j], 2.f * st.c[j]), st.d[j]);
+            st.c[j] = fmaf(eps_r, st.b[j], st.c[j]);
+          }
+        }
+        if (w.slot >= 0) {
+          float* ws = P.ws + (static_cast<int64_t>(w.slot) * 4) * C + c0ch;
+          if constexpr (MODE == DGCN_AGGR_MAX) {
+            float fi[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) fi[j] = __int_as_float(st.idx[j]);
+            store_vec<VEC>(ws, st.a);
+            store_vec<VEC>(ws + C, fi);
+          } else {
+            store_vec<VEC>(ws, st.a);
+            store_vec<VEC>(ws + C, st.b);
+            store_vec<VEC>(ws + 2 * C, st.c);
+            store_vec<VEC>(ws + 3 * C, st.d);
+          }
+        } else {
+          const int64_t o = static_cast<int64_t>(w.row) * C + c0ch;
+          const float deg = static_cast<float>(w.end - w.beg);
+          float res[VEC], x1[VEC], x2[VEC];
+          int xi[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            x1[j] = 0.f; x2[j] = 0.f; xi[j] = -1;
+            if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+              const bool any = st.b[j] > 0.f;
+              const float inv = any ? 1.f / st.b[j] : 0.f;
+              res[j] = st.c[j] * inv;
+              x1[j] = any ? (st.a[j] + fast_log2(st.b[j])) * 0.6931471805599453f : 0.f;
+              x2[j] = st.d[j] * inv;
+              if (P.range_flag && !(fabsf(x1[j]) < kShiftSafe)) atomicOr(P.range_flag, 1);  // rare
+            } else if constexpr (MODE == DGCN_AGGR_POWER) {
+              const float q = st.b[j] / fmaxf(deg, 1.f);
+              const float r = fminf(fmaxf(q, kPowLo), kPowHi);
+              res[j] = fast_pow(r, 1.f / p);
+              x1[j] = q;
+              x2[j] = st.d[j];
+            } else if constexpr (MODE == DGCN_AGGR_MAX) {
+              res[j] = st.idx[j] >= 0 ? st.a[j] : 0.f;
+              xi[j] = st.idx[j];
+            } else if constexpr (MODE == DGCN_AGGR_MEAN) {
+              res[j] = st.b[j] / fmaxf(deg, 1.f);
+            } else {
+              res[j] = st.b[j];
+            }
+          }
+          if (P.add_root) {
+            float xr[VEC];
+            load_vec<VEC>(xr, row_ptr(P.x, w.row, xs32) + c0ch);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) res[j] += xr[j];
+          }
+          store_vec<VEC>(P.out + o, res);
+          if constexpr (MODE == DGCN_AGGR_MAX) {
+            if (P.aux1) store_vec_i<VEC>(static_cast<int32_t*>(P.aux1) + o, xi);
+          } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
+            if (P.aux1) store_vec<VEC>(static_cast<float*>(P.aux1) + o, x1);
+            if (P.aux2) store_vec<VEC>(P.aux2 + o, x2);
+          }
+        }
+      }
+    }
+#ifndef DGCN_NO_PREFETCH
+    w = wn;
+    wn = wnn;
+    col0 = coln;
+    eid0 = eidn;
+#else
+    w = fetch_work<SW>(P.g, base + stride + sub, n_items);
+    load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+#endif
+  }
+}
+
+// WITH_D (second moment for learnable t / p) is a kernel-level parameter: its extra accumulators must not
+// cost the common variant registers.  The message kind is a wave-uniform branch inside (same register budget).
+#ifdef DGCN_FWD_WPE
+#define DGCN_FWD_OCC __attribute__((amdgpu_waves_per_eu(DGCN_FWD_WPE, DGCN_FWD_WPE)))
+#else
+#define DGCN_FWD_OCC
+#endif
+template <int MODE, int VEC, int LPR, int SW, int EA, bool WITH_D>
+__global__ __launch_bounds__(kWgThreads) DGCN_FWD_OCC void gen_aggr_fwd_kernel(const FwdParams P) {
+  if (P.msg == DGCN_MSG_RELU_EPS) {
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, EA, true, WITH_D>(P);
+  } else {
+    gen_aggr_fwd_body<MODE, VEC, LPR, SW, EA, false, WITH_D>(P);
+  }
+}
+
+// Merge the partial slots of split (hub) rows: one wave per split row (its first work item is listed in
+// split_item), lanes over channels, slots folded in work-list order -> deterministic.
+template <int MODE>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const FwdParams P) {
+  const int lane = lane_id();
+  const int C = P.C;
+  const int n_work = P.g.n_work;
+  const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+  if (wave >= P.g.n_split) return;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const int i0 = uni(P.g.split_item[wave]);
+  const int row = uni(P.g.work_row[i0]);
+  const float deg = static_cast<float>(P.g.rowptr[row + 1] - P.g.rowptr[row]);
+  int i1 = i0;
+  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
+  for (int c = lane; c < C; c += kWave) {
+    State<1> st;
+    state_init<MODE, 1>(st);
+    for (int i = i0; i < i1; ++i) {
+      const float* ws = P.ws + (static_cast<int64_t>(P.g.work_slot[i]) * 4) * C + c;
+      State<1> o;
+      state_init<MODE, 1>(o);
+      if constexpr (MODE == DGCN_AGGR_MAX) {
+        o.a[0] = ws[0];
+        o.idx[0] = __float_as_int(ws[C]);
+      } else {
+        o.a[0] = ws[0];
+        o.b[0] = ws[C];
+        o.c[0] = ws[2 * C];
+        o.d[0] = ws[3 * C];
+      }
+      state_merge<MODE, 1>(st, o);
+    }
+    const int64_t o = static_cast<int64_t>(row) * C + c;
+    float res, x1 = 0.f, x2 = 0.f;
+    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+      const bool any = st.b[0] > 0.f;
+      const float inv = any ? 1.f / st.b[0] : 0.f;
+      res = st.c[0] * inv;
+      x1 = any ? (st.a[0] + fast_log2(st.b[0])) * 0.6931471805599453f : 0.f;
+      x2 = st.d[0] * inv;
+      if (P.range_flag && !(fabsf(x1) < kShiftSafe)) atomicOr(P.range_flag, 1);
+    } else if constexpr (MODE == DGCN_AGGR_POWER) {
+      const float q = st.b[0] / fmaxf(deg, 1.f);
+      const float r = fminf(fmaxf(q, kPowLo), kPowHi);
+      res = fast_pow(r, 1.f / p);
+      x1 = q;
+      x2 = st.d[0];
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+      res = st.idx[0] >= 0 ? st.a[0] : 0.f;
+    } else if constexpr (MODE == DGCN_AGGR_MEAN) {
+      res = st.b[0] / fmaxf(deg, 1.f);
+    } else {
+      res = st.b[0];
+    }
+    P.out[o] = P.add_root ? res + P.x[static_cast<int64_t>(row) * P.x_stride + c] : res;
+    if constexpr (MODE == DGCN_AGGR_MAX) {
+      if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = st.idx[0];
+    } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
+      if (P.aux1) static_cast<float*>(P.aux1)[o] = x1;
+      if (P.aux2) P.aux2[o] = x2;
+    }
+  }
+}
+
+template <int MODE, int VEC, int LPR, int SW, int EA>
+void launch_fwd_d(const FwdParams& P, int grid, hipStream_t s) {
+  constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
+  if constexpr (CAN_D) {
+    if (P.aux2) {
+      hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, EA, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gen_aggr_fwd_kernel<MODE, VEC, LPR, SW, EA, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+}
+
+template <int MODE, int VEC, int LPR, int SW>
+void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {   // fused edge encoder: float4 layouts only (the host entry point checks)
+      launch_fwd_d<MODE, VEC, LPR, SW, 2>(P, grid, s);
+      return;
+    }
+  }
+  if (P.ea) {
+    launch_fwd_d<MODE, VEC, LPR, SW, 1>(P, grid, s);
+  } else {
+    launch_fwd_d<MODE, VEC, LPR, SW, 0>(P, grid, s);
+  }
+}
+
+template <int MODE>
+void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
+  if (vec == 4) {
+    const bool sub = subgroup_width(lpr) < kWave;
+    switch (lpr) {
+      case 4: sub ? launch_fwd_ea<MODE, 4, 4, 16>(P, grid, s) : launch_fwd_ea<MODE, 4, 4, 64>(P, grid, s); break;
+      case 8: sub ? launch_fwd_ea<MODE, 4, 8, 32>(P, grid, s) : launch_fwd_ea<MODE, 4, 8, 64>(P, grid, s); break;
+      case 16: launch_fwd_ea<MODE, 4, 16, 64>(P, grid, s); break;
+      case 32: launch_fwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
+      default: launch_fwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
+    }
+  } else {
+    launch_fwd_ea<MODE, 1, 64, 64>(P, grid, s);
+  }
+  if (P.g.n_work && P.g.n_split > 0) {
+    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
+    hipLaunchKernelGGL((gen_aggr_fwd_merge_kernel<MODE>), dim3(mg), dim3(kWgThreads), 0, s, P);
+  }
+}
+
+
+int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
+                      const float* edge_attr, const EncArgs* enc, int32_t channels, int32_t mode,
+                      int32_t msg, int32_t flags, float t, float p, float eps,
+                      const float* t_dev, const float* p_dev, float* out,
+                      void* aux1, float* aux2, int32_t* range_flag, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!g || !x || !out) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
+  if ((flags & DGCN_FLAG_ADD_ROOT) && g->n_dst > g->n_src) return DGCN_E_SHAPE;   // root rows are x[0 .. n_dst)
+  if (g->n_dst < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
+  if (x_stride > 0x7fffffffLL) return DGCN_E_SHAPE;   // row addresses use a 32x32->64 multiply
+  if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
+  if (msg != DGCN_MSG_IDENTITY && msg != DGCN_MSG_RELU_EPS) return DGCN_E_MODE;
+  if (g->n_dst == 0) return DGCN_OK;
+  if (!g->rowptr || (g->n_edges > 0 && !g->col)) return DGCN_E_NULL;
+  if (g->n_work && (!g->work_row || !g->work_beg || !g->work_end || !g->work_slot)) return DGCN_E_NULL;
+  if (g->n_work && g->n_split > 0 && !g->split_item) return DGCN_E_NULL;
+  if (workspace_bytes < dgcn_gen_aggr_fwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
+  if (g->n_work && g->n_slots > 0 && !workspace) return DGCN_E_NULL;
+
+  const bool vec4 = (channels % 4 == 0) && (x_stride % 4 == 0) && aligned16(x) && aligned16(out) &&
+                    (!edge_attr || aligned16(edge_attr)) && (!aux1 || aligned16(aux1)) &&
+                    (!aux2 || aligned16(aux2)) && (!workspace || aligned16(workspace));
+  const int vec = vec4 ? 4 : 1;
+  const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
+
+  FwdParams P;
+  P.g = WalkGraph{g->n_dst, g->n_work, g->rowptr, g->col, g->eperm,
+                  g->work_row, g->work_beg, g->work_end, g->work_slot, g->n_split, g->split_item};
+  P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
+  P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
+  P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
+  P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
+  P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
+  if (enc && !vec4) return DGCN_E_ALIGN;
+
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;   // items walked side by side by one wave
+  const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
+#ifdef DGCN_FWD_WAVES_PER_CU
+  const int grid = round_up8(grid_for_waves(n_items, DGCN_FWD_WAVES_PER_CU));
+#else
+  const int grid = round_up8(grid_for_waves(n_items));
+#endif
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (mode) {
+    case DGCN_AGGR_ADD: launch_fwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;
+    case DGCN_AGGR_MEAN: launch_fwd_mode<DGCN_AGGR_MEAN>(P, vec, lpr, grid, s); break;
+    case DGCN_AGGR_MAX: launch_fwd_mode<DGCN_AGGR_MAX>(P, vec, lpr, grid, s); break;
+    case DGCN_AGGR_SOFTMAX: launch_fwd_mode<DGCN_AGGR_SOFTMAX>(P, vec, lpr, grid, s); break;
+    default: launch_fwd_mode<DGCN_AGGR_POWER>(P, vec, lpr, grid, s); break;
+  }
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace dgcn
+
+using namespace dgcn;
+
+extern "C" size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
+  if (!g || g->n_work == 0) return 0;
+  return static_cast<size_t>(g->n_slots) * 4u * static_cast<size_t>(channels) * sizeof(float);
+}
+
+
+extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                     const float* edge_attr, int32_t channels, int32_t mode,
+                                     int32_t msg, int32_t flags, float t, float p, float eps,
+                                     const float* t_dev, const float* p_dev, float* out,
+                                     void* aux1, float* aux2, int32_t* range_flag, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return gen_aggr_fwd_impl(g, x, x_stride, edge_attr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev, p_dev,
+                           out, aux1, aux2, range_flag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, float* out, void* aux1, float* aux2,
+                                         int32_t* range_flag, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_fwd_impl(g, x, x_stride, nullptr, &enc, channels, mode, msg, flags, t, p, eps, t_dev, p_dev, out,
+                           aux1, aux2, range_flag, workspace, workspace_bytes, stream);
+}
+

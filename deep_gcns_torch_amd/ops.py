@@ -22,8 +22,8 @@ _MODES = {
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
-ENC_FEATURES = 8                   # raw edge features of the fused edge encoder (kEncF in csrc/gen_aggr.hip)
-SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr.hip)
+ENC_FEATURES = 8                   # raw edge features of the fused edge encoder (kEncF in csrc/gen_aggr_common.h)
+SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
 
 
 def _scalar_arg(v):
