@@ -2,8 +2,8 @@
 """Dense point-cloud hot path micro-benchmark (BASELINE.md config 2 shapes: B=8, N=4096, k=16, C=64).
 
 Prints one JSON line per measurement: kNN graph build at dilation 1/14/27, EdgeConv2d (relu, batch-norm)
-forward and forward+backward, a full ResDynBlock2d step, and (optionally) the CPU oracle beside them.
-    python benchmarks/bench_dense.py [--cpu-baseline] [--iters 20]
+forward and forward+backward and a full ResDynBlock2d step (the CPU oracle timed beside them: tests/cpu_baseline_dense.py).
+    python benchmarks/bench_dense.py [--iters 20]
 """
 import argparse
 import json
@@ -36,7 +36,6 @@ def timed(fn, iters, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--C", type=int, default=64)
@@ -96,21 +95,6 @@ def main():
     out.append(dict(op="resdynblock2d_d14_fwd_bwd, HIP-graph replay", ms_avg=avg, ms_min=mn,
                     edges_per_s=edges / (avg * 1e-3)))
 
-    if a.cpu_baseline:
-        from oracle import dense_ref
-        torch.set_num_threads(os.cpu_count())
-        xc = x.cpu()
-        t0 = time.perf_counter(); dense_ref.dense_knn_matrix(xc, k * 14); t_knn = time.perf_counter() - t0
-        nn = torch.nn.Sequential(torch.nn.Conv2d(2 * C, C, 1), torch.nn.ReLU(), torch.nn.BatchNorm2d(C)).train()
-        eic = ei.cpu()
-        xr = xc.clone().requires_grad_(True)
-        t0 = time.perf_counter()
-        y = dense_ref.edgeconv2d(xr, eic, nn)
-        t_f = time.perf_counter() - t0
-        y.backward(go.cpu())
-        t_fb = time.perf_counter() - t0
-        out.append(dict(op="cpu_oracle", cores=os.cpu_count(), knn_K224_ms=t_knn * 1e3, edgeconv_fwd_ms=t_f * 1e3,
-                        edgeconv_fwd_bwd_ms=t_fb * 1e3, edgeconv_fwd_bwd_edges_per_s=edges / t_fb))
     for r in out:
         r.update(B=B, N=N, C=C, k=k)
         print(json.dumps(r), flush=True)
