@@ -285,12 +285,14 @@ void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
 template <int MODE>
 void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
   if (vec == 4) {
-    const bool sub = subgroup_width(lpr) < kWave;
+    // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
+    // chip that way, else one row per wave (more, shorter waves)
+    const bool one = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows) == kWave;
     switch (lpr) {
-      case 4: sub ? launch_bwd_ea<MODE, 4, 4, 16>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s); break;
-      case 8: sub ? launch_bwd_ea<MODE, 4, 8, 32>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s); break;
-      case 16: launch_bwd_ea<MODE, 4, 16, 64>(P, grid, s); break;
-      case 32: launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
+      case 4: one ? launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, kSubWidth(4)>(P, grid, s); break;
+      case 8: one ? launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, kSubWidth(8)>(P, grid, s); break;
+      case 16: one ? launch_bwd_ea<MODE, 4, 16, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 16, kSubWidth(16)>(P, grid, s); break;
+      case 32: one ? launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 32, kSubWidth(32)>(P, grid, s); break;
       default: launch_bwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
     }
   } else {
@@ -305,7 +307,7 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
 
 int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
   const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
-  const int per_wave = vec4 ? kWave / subgroup_width(lpr) : 1;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src)) : 1;
   const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
   int grid = round_up8(grid_for_waves(n_items));
   if (enc && grid > kEncMaxParts) grid = kEncMaxParts;

@@ -207,16 +207,22 @@ int lanes_per_row(int C, int vec) {
 
 int round_up8(int v) { return (v + 7) / 8 * 8; }
 
-// Sub-group width for narrow rows: 4 edge groups per item (two merge steps instead of four, and the item
-// bookkeeping shared by 64/SW rows).  DGCN_SUBGROUP=64 in the environment forces one item per wave.
-int subgroup_width(int lpr) {
-  static const int forced = [] {
-    const char* e = getenv("DGCN_SUBGROUP");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced == kWave) return kWave;
-  const int sw = lpr * 4;
-  return sw < kWave ? sw : kWave;
+// Edge groups per item (G): how many edges of ONE row a wave walks side by side; the remaining 64 / (LPR * G)
+// sub-groups walk other rows.  DGCN_G overrides it at compile time (tuning builds).
+#ifdef DGCN_G
+constexpr int kEdgeGroups(int) { return DGCN_G; }
+#else
+constexpr int kEdgeGroups(int lpr) { return lpr >= 8 ? 2 : 4; }   // measured: products + arxiv shapes, C = 16..128
+#endif
+constexpr int kSubWidth(int lpr) { return lpr * kEdgeGroups(lpr) < kWave ? lpr * kEdgeGroups(lpr) : kWave; }
+
+// Lanes per work item actually used for a walk over n_items rows: the narrow layout (several rows per wave) only
+// when it still leaves >= kMinWaves waves (two per wave slot of the chip); a small graph (ogbn-proteins clusters,
+// PPI) needs every row as its own wave.
+constexpr int kMinWaves = 12288;
+inline int subgroup_width(int lpr, int64_t n_items) {
+  const int sw = kSubWidth(lpr);
+  return (n_items * sw / kWave >= kMinWaves) ? sw : kWave;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
