@@ -98,9 +98,9 @@ __device__ __forceinline__ void bitonic_sort_wave(unsigned long long (&v)[R], in
           const int e = lane * R + r;
           const unsigned long long other = shfl_xor_u64(v[r], lstride);
           const bool up = (e & size) == 0;
-          const unsigned long long mn = v[r] < other ? v[r] : other;
-          const unsigned long long mx = v[r] < other ? other : v[r];
-          v[r] = (up == lower) ? mn : mx;
+          // keep the smaller of the pair iff (ascending block) == (lower position): one compare, one select
+          const bool keep = (v[r] < other) == (up == lower);
+          v[r] = keep ? v[r] : other;
         }
       }
     }
