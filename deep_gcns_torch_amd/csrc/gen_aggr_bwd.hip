@@ -221,7 +221,7 @@ template <int MODE, int VEC, int LPR, int SW, int EA>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParams P) {
   if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
     // single-gather form when the caller prepared it and the device-side range check passed
-    if (P.gshift != nullptr && !P.learn_t && *P.shift_ok != 0) {
+    if (P.gshift != nullptr && !P.learn_t && ((*P.shift_ok != 0) != (P.shift_bad != 0))) {
       gen_aggr_bwd_body<kModeSoftmaxShifted, VEC, LPR, SW, EA>(P);
       return;
     }
@@ -352,7 +352,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
-  P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr;
+  P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr; P.shift_bad = 0;
   P.groot = groot;
   P.enc_feat = enc ? enc->feat : nullptr;
   P.enc_w = enc ? enc->w : nullptr;
@@ -361,6 +361,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   if (enc && !vec4) return DGCN_E_ALIGN;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
+    P.shift_bad = (flags & DGCN_FLAG_SHIFT_FLAG_IS_RANGE) ? 1 : 0;
   }
   P.ws = static_cast<float*>(workspace);
 

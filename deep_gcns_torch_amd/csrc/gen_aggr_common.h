@@ -65,7 +65,8 @@ struct BwdParams {
   const float* out;
   const float* gshift;    // [n_dst, C] g_i * exp(kshift_c - L_i)  (single-gather softmax backward) or null
   const float* kshift;    // [C] per-channel shift
-  const int32_t* shift_ok;  // device flag: 1 = the shifted form is numerically safe for this call
+  const int32_t* shift_ok;  // device flag: the shifted form is numerically safe for this call iff *shift_ok != shift_bad
+  int shift_bad;            // 0: flag means "ok"; 1: flag is the forward's range_flag (nonzero = NOT safe)
   const float* groot;     // [n_src, C] upstream gradient added to grad_x (backward of add_root) or null
   const float* enc_feat;  // EA == 2: see FwdParams
   const float* enc_w;

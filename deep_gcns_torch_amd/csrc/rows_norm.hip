@@ -348,3 +348,269 @@ extern "C" int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_
   }
   return launch_status();
 }
+
+// =====================================================================================================
+// LayerNorm over the channel dimension of (rows, C) features, optional fused ReLU.
+// Replaces nn.LayerNorm from norm_layer('layer', C)  (gcn_lib/sparse/torch_nn.py:23-34; the default norm of the
+// ogbn-proteins / ogbg-ppa / RevGCN configurations) and the Lin -> LayerNorm -> ReLU run of MLP (:50-71).
+// A row lives in the registers of LPR lanes (Q float4 each), 64/LPR rows per wave; mean and variance are two
+// register passes (no E[x^2]-E[x]^2 cancellation), reductions are xor-shuffles inside the row's lanes.
+//   forward : y = [relu]((x - mean) * rstd * gamma + beta); mean, rstd saved per row        (1 read + 1 write)
+//   backward: gh = g' * gamma;  dx = rstd * (gh - mean_c(gh) - xhat * mean_c(gh * xhat))   (2-3 reads + 1 write)
+//             dgamma = sum_rows g' * xhat, dbeta = sum_rows g' as per-workgroup partials [nparts][2][C]
+//             (slot 0 = sum g', slot 1 = sum g' xhat; the caller sums the <= 1024 partials).
+// Stock kernels run at ~1 TB/s on this shape class; these are streaming passes.
+// =====================================================================================================
+namespace dgcn {
+namespace {
+
+constexpr int kLnMaxParts = 1024;
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+struct LnGeom {
+  int lpr;   // lanes per row (power of two, <= 64)
+  int q;     // float4 per lane (1, 2 or 4)
+};
+
+inline LnGeom ln_geom(int C) {
+  const int quads = C / 4;
+  LnGeom g;
+  g.lpr = 4;
+  while (g.lpr < quads && g.lpr < kWave) g.lpr <<= 1;
+  const int need = (quads + g.lpr - 1) / g.lpr;
+  g.q = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
+  return g;
+}
+
+template <int LPR, int Q, bool RELU>
+__global__ __launch_bounds__(kWgThreads) void rows_ln_fwd_kernel(const float* __restrict__ x, int64_t ld,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float* __restrict__ y, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int64_t rows, int C) {
+  constexpr int RPW = kWave / LPR;
+  const int lane = lane_id();
+  const int sub = lane / LPR, li = lane % LPR;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + (threadIdx.x >> 6);
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+  float gm[Q][4], bt[Q][4];
+  bool ok[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int c = (li + k * LPR) * 4;
+    ok[k] = c < C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[k][j] = 1.f; bt[k][j] = 0.f; }
+    if (ok[k] && gamma) load_vec<4>(gm[k], gamma + c);
+    if (ok[k] && beta) load_vec<4>(bt[k], beta + c);
+  }
+  const float inv_c = 1.f / static_cast<float>(C);
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    float v[Q][4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[k][j] = 0.f;
+      if (live && ok[k]) load_vec<4>(v[k], x + r * ld + (li + k * LPR) * 4);
+      s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mean = row_sum<LPR>(s) * inv_c;
+    float q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      if (ok[k]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q2 = fmaf(d, d, q2); }
+      }
+    }
+    const float var = row_sum<LPR>(q2) * inv_c;
+    const float rstd = rsqrtf(var + eps);
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        if (ok[k]) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = fmaf((v[k][j] - mean) * rstd, gm[k][j], bt[k][j]);
+            if (RELU) o[j] = fmaxf(o[j], 0.f);
+          }
+          store_vec<4>(y + r * C + (li + k * LPR) * 4, o);
+        }
+      }
+      if (li == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+    }
+  }
+}
+
+template <int LPR, int Q, bool RELU>
+__global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __restrict__ g,
+                                                                const float* __restrict__ x, int64_t ld,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean_in,
+                                                                const float* __restrict__ rstd_in,
+                                                                float* __restrict__ dx, float* __restrict__ partial,
+                                                                int64_t rows, int C) {
+  constexpr int RPW = kWave / LPR;
+  __shared__ float red[kWavesPerWg][2][LPR * Q * 4];
+  const int lane = lane_id();
+  const int sub = lane / LPR, li = lane % LPR;
+  const int wv = threadIdx.x >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + wv;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+  float gm[Q][4], dg[Q][4], db[Q][4];
+  bool ok[Q];
+#pragma unroll
+  for (int k = 0; k < Q; ++k) {
+    const int c = (li + k * LPR) * 4;
+    ok[k] = c < C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[k][j] = 1.f; dg[k][j] = 0.f; db[k][j] = 0.f; }
+    if (ok[k] && gamma) load_vec<4>(gm[k], gamma + c);
+  }
+  const float inv_c = 1.f / static_cast<float>(C);
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    const float mean = live ? mean_in[r] : 0.f;
+    const float rstd = live ? rstd_in[r] : 0.f;
+    float gp[Q][4], xh[Q][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      float xv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gp[k][j] = 0.f;
+      if (live && ok[k]) {
+        const int c = (li + k * LPR) * 4;
+        load_vec<4>(gp[k], g + r * C + c);
+        load_vec<4>(xv, x + r * ld + c);
+        if (RELU) load_vec<4>(yv, y + r * C + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (RELU && !(yv[j] > 0.f)) gp[k][j] = 0.f;
+        xh[k][j] = (live && ok[k]) ? (xv[j] - mean) * rstd : 0.f;
+        const float gh = gp[k][j] * gm[k][j];
+        s1 += gh;
+        s2 = fmaf(gh, xh[k][j], s2);
+        db[k][j] += gp[k][j];
+        dg[k][j] = fmaf(gp[k][j], xh[k][j], dg[k][j]);
+      }
+    }
+    const float m1 = row_sum<LPR>(s1) * inv_c;
+    const float m2 = row_sum<LPR>(s2) * inv_c;
+    if (live && dx) {
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        if (ok[k]) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = rstd * (gp[k][j] * gm[k][j] - m1 - xh[k][j] * m2);
+          store_vec<4>(dx + r * C + (li + k * LPR) * 4, o);
+        }
+      }
+    }
+  }
+  if (partial) {
+    // lanes with the same channels (the RPW sub-rows of the wave), then the four waves, in a fixed order
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {
+          db[k][j] += __shfl_xor(db[k][j], off);
+          dg[k][j] += __shfl_xor(dg[k][j], off);
+        }
+        if (lane < LPR) {
+          red[wv][0][(k * LPR + li) * 4 + j] = db[k][j];
+          red[wv][1][(k * LPR + li) * 4 + j] = dg[k][j];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LPR * Q * 4; i += kWgThreads) {
+      const int k = i / (LPR * 4), rem = i % (LPR * 4);
+      const int c = ((rem / 4) + k * LPR) * 4 + (rem % 4);
+      if (c < C) {
+        partial[(static_cast<int64_t>(blockIdx.x) * 2) * C + c] = ((red[0][0][i] + red[1][0][i]) + red[2][0][i]) + red[3][0][i];
+        partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = ((red[0][1][i] + red[1][1][i]) + red[2][1][i]) + red[3][1][i];
+      }
+    }
+  }
+}
+
+int ln_grid(int64_t rows, int lpr) {
+  const int rpw = kWave / lpr;
+  int64_t wgs = (rows + static_cast<int64_t>(rpw) * kWavesPerWg - 1) / (static_cast<int64_t>(rpw) * kWavesPerWg);
+  if (wgs > kLnMaxParts) wgs = kLnMaxParts;
+  return static_cast<int>(wgs < 1 ? 1 : wgs);
+}
+
+bool ln_ok(int C, int64_t ld, const void* a, const void* b, const void* c, const void* d, const void* e) {
+  auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return C > 0 && C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ld >= C && al(a) && al(b) && al(c) && al(d) && al(e);
+}
+
+#define DGCN_LN_DISPATCH(KERNEL, RELU_V, ...)                                                                      \
+  do {                                                                                                              \
+    const LnGeom G = ln_geom(C);                                                                                    \
+    const int grid = ln_grid(rows, G.lpr);                                                                          \
+    const dim3 gd(grid), bd(kWgThreads);                                                                            \
+    hipStream_t s = static_cast<hipStream_t>(stream);                                                               \
+    if (G.q == 1) {                                                                                                 \
+      switch (G.lpr) {                                                                                              \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 1, RELU_V>), gd, bd, 0, s, __VA_ARGS__); break;                       \
+        case 8: hipLaunchKernelGGL((KERNEL<8, 1, RELU_V>), gd, bd, 0, s, __VA_ARGS__); break;                       \
+        case 16: hipLaunchKernelGGL((KERNEL<16, 1, RELU_V>), gd, bd, 0, s, __VA_ARGS__); break;                     \
+        case 32: hipLaunchKernelGGL((KERNEL<32, 1, RELU_V>), gd, bd, 0, s, __VA_ARGS__); break;                     \
+        default: hipLaunchKernelGGL((KERNEL<64, 1, RELU_V>), gd, bd, 0, s, __VA_ARGS__); break;                     \
+      }                                                                                                             \
+    } else if (G.q == 2) {                                                                                          \
+      hipLaunchKernelGGL((KERNEL<64, 2, RELU_V>), gd, bd, 0, s, __VA_ARGS__);                                       \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL((KERNEL<64, 4, RELU_V>), gd, bd, 0, s, __VA_ARGS__);                                       \
+    }                                                                                                               \
+  } while (0)
+
+}  // namespace
+}  // namespace dgcn
+
+extern "C" int32_t dgcn_rows_ln_num_partials(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 1024) return 0;
+  return ln_grid(rows, ln_geom(C).lpr);
+}
+
+extern "C" int dgcn_rows_ln_fwd_f32(const float* x, int64_t ld, const float* gamma, const float* beta, float eps,
+                                    int32_t relu, float* y, float* mean, float* rstd, int64_t rows, int32_t C,
+                                    void* stream) {
+  if (!x || !y || !mean || !rstd) return DGCN_E_NULL;
+  if (rows < 0) return DGCN_E_SHAPE;
+  if (!ln_ok(C, ld, x, y, gamma, beta, nullptr)) return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  if (rows == 0) return DGCN_OK;
+  if (relu) DGCN_LN_DISPATCH(rows_ln_fwd_kernel, true, x, ld, gamma, beta, eps, y, mean, rstd, rows, C);
+  else DGCN_LN_DISPATCH(rows_ln_fwd_kernel, false, x, ld, gamma, beta, eps, y, mean, rstd, rows, C);
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, const float* y, const float* gamma,
+                                    const float* mean, const float* rstd, float* dx, float* partial, int64_t rows,
+                                    int32_t C, void* stream) {
+  if (!g || !x || !mean || !rstd || (!dx && !partial)) return DGCN_E_NULL;
+  if (rows <= 0) return DGCN_E_SHAPE;
+  if (!ln_ok(C, ld, x, g, y, gamma, dx)) return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  if (y) DGCN_LN_DISPATCH(rows_ln_bwd_kernel, true, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C);
+  else DGCN_LN_DISPATCH(rows_ln_bwd_kernel, false, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C);
+  return launch_status();
+}

@@ -28,7 +28,7 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
     B, C, N = x3.shape
     ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N) if (N >= 1024 and USE_KNN_FILTER) else 0
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
-    with torch.cuda.device(dev):
+    with _lib.device_ctx(dev):
         rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,
                                     dilation, 1 if exclude_self else 0, nn_out.data_ptr(), _lib.ptr(ctr_out),
                                     _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
@@ -78,7 +78,7 @@ class _VertexGemm(torch.autograd.Function):
         M = Wc.size(1)
         bc = None if bias is None else bias.float().contiguous()
         out = torch.empty(B, N, M, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             rc = lib.dgcn_vertex_gemm_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N,
                                           Wc.data_ptr(), _lib.ptr(bc), M, out.data_ptr(),
                                           _lib.current_stream_handle(dev))
@@ -136,7 +136,7 @@ class _EdgeReduce(torch.autograd.Function):
             stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
         p_ptr = PQ.data_ptr() if has_p else None
         q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             rc = lib.dgcn_dense_edge_reduce_fwd_f32(
                 p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
                 B, N, C, k, act, slope, vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(amax), _lib.ptr(amin),
@@ -177,7 +177,7 @@ class _EdgeReduce(torch.autograd.Function):
         q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
         dp_ptr = dPQ.data_ptr() if has_p else None
         dq_ptr = dPQ.data_ptr() + (C * 4 if has_p else 0)
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             rc = lib.dgcn_dense_edge_reduce_bwd_f32(
                 p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
                 B, N, C, k, act, slope, amax.data_ptr(), _lib.ptr(amin if gmin_c is not None else None),
@@ -256,7 +256,7 @@ class _EdgeConv2dFused(torch.autograd.Function):
         out = torch.empty(B, Cout, N, 1, device=dev, dtype=torch.float32)
         bnbuf = torch.empty(4, Cout, device=dev, dtype=torch.float32) if has_bn else None
         count = float(B) * N * k
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             _lib.check(lib.dgcn_edgeconv_pq_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N,
                                                 W2.data_ptr(), _lib.ptr(bc), Cout, pq.data_ptr(), stream),
                        "dgcn_edgeconv_pq_f32")
@@ -300,7 +300,7 @@ class _EdgeConv2dFused(torch.autograd.Function):
         if parts is None:
             dPQ[..., Cout:].zero_()
         train_stats = bn_mode == BN_TRAIN
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             _lib.check(lib.dgcn_bn_bwd_prep_f32(g3.data_ptr(), g3.stride(0), g3.stride(1), g3.stride(2), vmax.data_ptr(),
                                                 _lib.ptr(vmin), _lib.ptr(bnbuf), gsel.data_ptr(), _lib.ptr(partial),
                                                 B, N, Cout, stream), "dgcn_bn_bwd_prep_f32")

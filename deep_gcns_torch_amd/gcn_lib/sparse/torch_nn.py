@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from ...nn_util import TallLinear
-from ...node_ops import BatchNorm1d
+from ...node_ops import BatchNorm1d, LayerNorm
 from ...utils.data_util import get_atom_feature_dims, get_bond_feature_dims
 
 __all__ = ["act_layer", "norm_layer", "MultiSeq", "MLP", "AtomEncoder", "BondEncoder"]
@@ -33,7 +33,7 @@ def norm_layer(norm_type, nc):
     if kind == "batch":
         return BatchNorm1d(nc, affine=True)          # an nn.BatchNorm1d; (rows, C) inputs run on the HIP kernels
     if kind == "layer":
-        return nn.LayerNorm(nc, elementwise_affine=True)
+        return LayerNorm(nc, elementwise_affine=True)    # an nn.LayerNorm; device rows run on the HIP kernels
     if kind == "instance":
         return nn.InstanceNorm1d(nc, affine=False)
     raise NotImplementedError("normalization layer [%s] is not found" % kind)
@@ -74,12 +74,12 @@ class MLP(nn.Sequential):
         super().__init__(*stages)
 
     def forward(self, x):
-        # same stage order as nn.Sequential; BatchNorm1d directly followed by ReLU runs as one fused kernel pair
+        # same stage order as nn.Sequential; BatchNorm1d / LayerNorm directly followed by ReLU runs with the ReLU fused
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, BatchNorm1d) and i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            if (isinstance(m, (BatchNorm1d, LayerNorm)) and i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
                     and isinstance(x, torch.Tensor) and x.dim() == 2):
                 x = m(x, fuse_relu=True)
                 i += 2

@@ -1,5 +1,8 @@
 """Node-wise ops on (rows, C) feature matrices around the sparse hot path.
 
+``layer_norm_rows`` / ``LayerNorm`` = nn.LayerNorm over the channel dimension (norm_layer('layer', C), the default norm
+of the ogbn-proteins / ogbg-ppa / RevGCN configurations), same kernels file, optional fused ReLU.
+
 ``batch_norm_rows`` = nn.BatchNorm1d forward/backward (training and eval semantics, running statistics) with an
 optional fused ReLU, as HIP streaming kernels (csrc/rows_norm.hip).  ``BatchNorm1d`` is the drop-in module that
 ``gcn_lib.sparse.torch_nn.norm_layer('batch', C)`` returns: an ``nn.BatchNorm1d`` subclass (same parameters,
@@ -28,7 +31,7 @@ class _BatchNormRows(torch.autograd.Function):
         bnbuf = torch.empty(4, C, device=dev, dtype=torch.float32)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             nparts, stats = 0, None
             if use_batch_stats:
                 nparts = lib.dgcn_rows_num_partials(rows, C)
@@ -60,7 +63,7 @@ class _BatchNormRows(torch.autograd.Function):
         partial = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
         coef = torch.empty(4, C, device=dev, dtype=torch.float32)
         dx = torch.empty(rows, C, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             _lib.check(lib.dgcn_rows_bn_bwd_stats_f32(g.data_ptr(), x.data_ptr(), ld, _lib.ptr(y), bnbuf.data_ptr(),
                                                       partial.data_ptr(), rows, C, stream), "dgcn_rows_bn_bwd_stats_f32")
             _lib.check(lib.dgcn_rows_bn_bwd_finalize_f32(partial.data_ptr(), nparts, C, float(rows),
@@ -70,8 +73,8 @@ class _BatchNormRows(torch.autograd.Function):
                 _lib.check(lib.dgcn_rows_bn_bwd_apply_f32(g.data_ptr(), x.data_ptr(), ld, _lib.ptr(y), bnbuf.data_ptr(),
                                                           coef.data_ptr(), dx.data_ptr(), rows, C, stream),
                            "dgcn_rows_bn_bwd_apply_f32")
-        gw = coef[0].clone() if (has_w and ctx.needs_input_grad[1]) else None
-        gb = coef[1].clone() if (has_b and ctx.needs_input_grad[2]) else None
+        gw = coef[0] if (has_w and ctx.needs_input_grad[1]) else None      # rows of a fresh tensor: no copy needed
+        gb = coef[1] if (has_b and ctx.needs_input_grad[2]) else None
         return dx, gw, gb, None, None, None, None, None, None, None, None
 
 
@@ -116,3 +119,78 @@ class BatchNorm1d(nn.BatchNorm1d):
             return torch.relu(y) if fuse_relu else y
         use_batch, momentum, nb, rm, rv = a
         return batch_norm_rows(x, self.weight, self.bias, rm, rv, nb, use_batch, momentum, self.eps, relu=fuse_relu)
+
+
+class _LayerNormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, relu: bool, track: bool):
+        lib = _lib.load()
+        dev = _lib.require_device(x)
+        stream = _lib.current_stream_handle(dev)
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        rows, C = x2.shape
+        ld = x2.stride(0) if rows > 1 else C
+        y = torch.empty(rows, C, device=dev, dtype=torch.float32)
+        mean = torch.empty(rows, device=dev, dtype=torch.float32)
+        rstd = torch.empty(rows, device=dev, dtype=torch.float32)
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        with _lib.device_ctx(dev):
+            _lib.check(lib.dgcn_rows_ln_fwd_f32(x2.data_ptr(), ld, _lib.ptr(w), _lib.ptr(b), float(eps), 1 if relu else 0,
+                                                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, stream),
+                       "dgcn_rows_ln_fwd_f32")
+        if track and any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(x2, w, mean, rstd, y if relu else None)
+            ctx.cfg = (weight is not None, bias is not None, tuple(shape))
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x2, w, mean, rstd, y = ctx.saved_tensors
+        has_w, has_b, shape = ctx.cfg
+        dev = x2.device
+        stream = _lib.current_stream_handle(dev)
+        rows, C = x2.shape
+        ld = x2.stride(0) if rows > 1 else C
+        g2 = g.reshape(rows, C).float().contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        need_p = (has_w and ctx.needs_input_grad[1]) or (has_b and ctx.needs_input_grad[2])
+        dx = torch.empty(rows, C, device=dev, dtype=torch.float32) if need_dx else None
+        partial = psum = None
+        with _lib.device_ctx(dev):
+            if need_p:
+                nparts = lib.dgcn_rows_ln_num_partials(rows, C)
+                partial = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
+            _lib.check(lib.dgcn_rows_ln_bwd_f32(g2.data_ptr(), x2.data_ptr(), ld, _lib.ptr(y), _lib.ptr(w), mean.data_ptr(),
+                                                rstd.data_ptr(), _lib.ptr(dx), _lib.ptr(partial), rows, C, stream),
+                       "dgcn_rows_ln_bwd_f32")
+            if need_p:
+                psum = partial.sum(0)                 # (2, C): sum g' | sum g' xhat over <= 1024 workgroup partials
+        gw = psum[1] if (has_w and ctx.needs_input_grad[1]) else None
+        gb = psum[0] if (has_b and ctx.needs_input_grad[2]) else None
+        return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None
+
+
+def _ln_supported(x: torch.Tensor, C: int) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.size(-1) == C and C % 4 == 0 and C <= 1024
+            and x.numel() > 0 and not torch.is_autocast_enabled())
+
+
+def layer_norm_rows(x, weight, bias, eps: float = 1e-5, relu: bool = False) -> torch.Tensor:
+    """LayerNorm over the last dimension of ``x`` (..., C) [+ ReLU]."""
+    return _LayerNormRows.apply(x, weight, bias, float(eps), bool(relu), torch.is_grad_enabled())
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (normalised over the last dimension only) whose fp32 device inputs run on the HIP row kernels; other
+    shapes / dtypes take the stock implementation.  Same parameters and ``state_dict`` keys."""
+
+    def forward(self, x, fuse_relu: bool = False):
+        if len(self.normalized_shape) == 1 and _ln_supported(x, self.normalized_shape[0]):
+            return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu)
+        y = super().forward(x)
+        return torch.relu(y) if fuse_relu else y

@@ -44,6 +44,18 @@ def _rows_f32(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+_ZEROS = {}
+
+
+def _zeros_cached(dev, n):
+    """A read-only zero vector per (device, length): the per-channel shift of the single-gather softmax backward."""
+    key = (dev.index, n)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(n, device=dev, dtype=torch.float32)
+    return z
+
+
 class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, edge_attr, t_param, p_param, graph: Graph, mode: int, msg: int,
@@ -91,7 +103,7 @@ class _GenAggregate(torch.autograd.Function):
             range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
-        with torch.cuda.device(dev):
+        with _lib.device_ctx(dev):
             if enc:
                 rc = lib.dgcn_gen_aggr_enc_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
@@ -154,33 +166,35 @@ class _GenAggregate(torch.autograd.Function):
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
             gshift = kshift = shift_ok = None
+            bwd_flags = ctx.flags
             if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and ctx.range_flag is not None:
                 # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  K_c = 0
                 # is safe whenever every |L_i| < 80, which the FORWARD kernel checked on the fly (range_flag);
                 # the decision stays on the device (no host sync) and the kernel falls back to two gathers.
-                kshift = torch.zeros(C, device=dev, dtype=torch.float32)
-                shift_ok = (ctx.range_flag == 0).to(torch.int32)
+                kshift = _zeros_cached(dev, C)
+                shift_ok = ctx.range_flag            # the kernel reads the forward's flag directly (0 = safe)
+                bwd_flags |= _lib.FLAG_SHIFT_FLAG_IS_RANGE
                 gshift = torch.empty_like(gcoef)
-                with torch.cuda.device(dev):
+                with _lib.device_ctx(dev):
                     rc = lib.dgcn_softmax_bwd_prep_f32(gcoef.data_ptr(), aux1.data_ptr(), kshift.data_ptr(),
                                                        gshift.data_ptr(), gcoef.size(0), C,
                                                        _lib.current_stream_handle(dev))
                 _lib.check(rc, "dgcn_softmax_bwd_prep_f32")
-            with torch.cuda.device(dev):
+            with _lib.device_ctx(dev):
                 if enc is not None:
                     feat, w_enc, b_enc = enc
                     nparts = lib.dgcn_gen_aggr_enc_bwd_num_partials(graph.c_struct, C)
                     gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
                     rc = lib.dgcn_gen_aggr_enc_bwd_f32(
                         graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
-                        ENC_FEATURES, C, mode, ctx.msg, ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
+                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
                         _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
                 else:
                     rc = lib.dgcn_gen_aggr_bwd_f32(
                         graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,
-                        ctx.flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                        bwd_flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param), _lib.ptr(p_param),
                         gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
                         _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
                         _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
@@ -248,7 +262,7 @@ def selftest(device="cuda:0") -> None:
     dev = torch.device(device)
     x = torch.arange(1000, device=dev, dtype=torch.float32)
     y = torch.ones(1000, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with _lib.device_ctx(dev):
         rc = lib.dgcn_selftest_axpy_f32(2.0, x.data_ptr(), y.data_ptr(), x.numel(),
                                         _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_selftest_axpy_f32")

@@ -49,6 +49,7 @@ extern "C" {
 /* extra behaviour bits for dgcn_gen_aggr_{fwd,bwd}_f32 */
 #define DGCN_FLAG_LEARN_T 1 /* softmax weights are differentiated (torch_message.py:51-52) */
 #define DGCN_FLAG_LEARN_P 2 /* power exponent is differentiated  (torch_message.py:33-34) */
+#define DGCN_FLAG_SHIFT_FLAG_IS_RANGE 8 /* backward: shift_ok points at the forward's range_flag (0 = safe), not at an "ok" flag */
 #define DGCN_FLAG_ADD_ROOT 4 /* forward: out_i += x_i, the h = x + m of GENConv.forward (torch_vertex.py:74) fused in */
 
 /*
@@ -337,6 +338,26 @@ int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t 
 /* dx = scale*(g' - c1 - xhat*c2). */
 int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
                                const float* coef, float* dx, int64_t rows, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the channels of row-major (rows, C) features, optional fused ReLU  (SURVEY.md §8 f1).
+ * Replaces nn.LayerNorm from norm_layer('layer', C) (gcn_lib/sparse/torch_nn.py:23-34: the default norm of the
+ * ogbn-proteins / ogbg-ppa / RevGCN configurations) and the Lin -> LayerNorm -> ReLU run of MLP (:50-71).
+ *   C % 4 == 0, C <= 1024, 16-byte aligned pointers, ld % 4 == 0.  gamma / beta may be NULL (no affine).
+ *   forward : y = [relu]((x - mean_r) * rstd_r * gamma + beta); mean[rows], rstd[rows] are written for the backward
+ *   backward: dx (may be NULL) and, when partial != NULL, per-workgroup partial sums
+ *             partial [dgcn_rows_ln_num_partials][2][C]: slot 0 = sum_rows g', slot 1 = sum_rows g' * xhat
+ *             (g' = g * [y > 0] when y, the forward output, is given); their sum over the first axis is
+ *             (dbeta | dgamma).
+ * ------------------------------------------------------------------------------------ */
+int32_t dgcn_rows_ln_num_partials(int64_t rows, int32_t C);
+
+int dgcn_rows_ln_fwd_f32(const float* x, int64_t ld, const float* gamma, const float* beta, float eps, int32_t relu,
+                         float* y, float* mean, float* rstd, int64_t rows, int32_t C, void* stream);
+
+int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, const float* y, const float* gamma,
+                         const float* mean, const float* rstd, float* dx, float* partial, int64_t rows, int32_t C,
+                         void* stream);
 
 #ifdef __cplusplus
 }

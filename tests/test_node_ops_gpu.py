@@ -111,3 +111,67 @@ def test_mlp_fuses_batchnorm_relu_and_matches_stock_sequential():
     torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-7)
     for (na, pa), (nb, pb) in zip(mlp.named_parameters(), stock.named_parameters()):
         torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6, msg=lambda m: f"{na}: {m}")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 128), (4097, 256), (777, 100), (513, 64), (64, 8), (3, 16), (2000, 512), (300, 1024),
+                                    (169343, 128)])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("affine", [True, False])
+def test_layernorm_rows_matches_torch(rows, C, relu, affine):
+    """HIP LayerNorm [+ReLU] against nn.LayerNorm on the CPU in float64: output, dx, dgamma, dbeta; every lanes-per-row /
+    float4-per-lane layout (C = 8 ... 1024, incl. C/4 not a power of two)."""
+    from deep_gcns_torch_amd.node_ops import LayerNorm
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2.0 + 0.5
+    probe = torch.randn(rows, C, generator=g)
+    ref = nn.LayerNorm(C, elementwise_affine=affine).double()
+    ours = LayerNorm(C, elementwise_affine=affine)
+    if affine:
+        with torch.no_grad():
+            ref.weight.copy_(torch.randn(C, generator=g).double())
+            ref.bias.copy_(torch.randn(C, generator=g).double())
+        ours.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    ours = ours.to(dev)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    (yr * probe.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    y = ours(xd, fuse_relu=True) if relu else ours(xd)
+    (y * probe.to(dev)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=RTOL, atol=1e-5)
+    gs = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5 * gs)
+    if affine:
+        gw = max(1.0, float(ref.weight.grad.abs().max()))
+        torch.testing.assert_close(ours.weight.grad.cpu().double(), ref.weight.grad, rtol=1e-4, atol=1e-5 * gw)
+        torch.testing.assert_close(ours.bias.grad.cpu().double(), ref.bias.grad, rtol=1e-4, atol=1e-5 * gw)
+
+
+def test_layernorm_module_fallbacks_and_mlp_fusion():
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from gcn_lib.sparse.torch_nn import MLP, norm_layer
+    from deep_gcns_torch_amd.node_ops import LayerNorm
+    dev = _dev()
+    ln = norm_layer("layer", 64)
+    assert isinstance(ln, LayerNorm) and isinstance(ln, nn.LayerNorm) and list(ln.state_dict()) == ["weight", "bias"]
+    ln = ln.to(dev)
+    x3 = torch.randn(5, 7, 64, device=dev)                              # leading dims are flattened
+    torch.testing.assert_close(ln(x3), nn.functional.layer_norm(x3, (64,), ln.weight, ln.bias, ln.eps), rtol=1e-5, atol=1e-5)
+    odd = LayerNorm(50).to(dev)                                         # C % 4 != 0: stock path
+    xo = torch.randn(9, 50, device=dev)
+    torch.testing.assert_close(odd(xo), nn.functional.layer_norm(xo, (50,), odd.weight, odd.bias, odd.eps))
+    torch.manual_seed(1)
+    mlp = MLP([64, 128, 64], norm="layer", last_lin=True).to(dev)
+    stock = nn.Sequential(nn.Linear(64, 128), nn.LayerNorm(128), nn.ReLU(), nn.Linear(128, 64)).to(dev)
+    stock.load_state_dict(mlp.state_dict())
+    x = torch.randn(5000, 64, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    mlp(xa).square().mean().backward()
+    stock(xb).square().mean().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-7)
+    for (na, pa), (nb, pb) in zip(mlp.named_parameters(), stock.named_parameters()):
+        torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6, msg=lambda m: f"{na}: {m}")
