@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="profiling aid: skip the backward")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the RCCL multi-rank path even with one rank (sanity check)")
-    ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather"],
+    ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather", "halo"],
                     help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
     ap.add_argument("--node-groups", type=int, default=0, help="transposed scheme: node groups (0 = library default)")
@@ -173,7 +173,7 @@ def main():
         if args.scheme == "auto":
             # the exchange is bound by the xGMI links and RCCL's per-collective efficiency: try the applicable schemes
             # for a few untimed steps and keep the fastest (same choice on every rank: max-over-ranks timings)
-            cands = [("allgather", 1)]
+            cands = [("allgather", 1), ("halo", 1)]
             if world > 1 or args.force_partitioned:
                 if ddist.transposed_supported(C, world, None, 1):
                     cands.append(("transposed", 1))
@@ -284,7 +284,9 @@ def main():
                                 (f"node-partitioned rows x{world}, channel-transposed exchange (RCCL all-to-all in/out; "
                                  f"{part.node_groups} node group(s) x {part.channel_groups} channel group(s): each rank "
                                  f"aggregates {part.n_edges} edges for {C // part.channel_groups} channels)" if transposed else
-                                 f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd")),
+                                 (f"destination-partitioned x{world}, halo rows only (RCCL all-to-all, {part.n_halo} halo rows "
+                                  f"on rank 0)" if isinstance(part, ddist.HaloGraph) else
+                                  f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd"))),
             },
             "roofline": {
                 "kernel": "gen_aggr_fwd_kernel<SOFTMAX> (dgcn_gen_aggr_fwd_f32)"

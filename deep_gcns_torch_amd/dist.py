@@ -452,17 +452,135 @@ def transposed_gen_aggregate(x_local: torch.Tensor, tg: TransposedGraph, aggr: s
     return _TransposedAggregate.apply(x_local, tg, group, local_aggregate, aggr, kw, pipeline_chunks)
 
 
+# ------------------------------------------------------------------------------------------------
+# halo scheme: exchange only the rows a partition actually references
+# ------------------------------------------------------------------------------------------------
+class HaloGraph:
+    """Destination-partitioned graph whose remote sources are the HALO only: at build time every rank tells each
+    owner which of the owner's rows its edges reference (one all-to-all of index lists); per layer the owners send
+    exactly those rows (``all_to_all_single`` with uneven splits) and the local kernel runs on
+    ``[own rows | halo rows]``.  On a graph with locality (METIS-like orderings of real graphs) the halo is a small
+    fraction of N; on a uniform random graph it degenerates to the all-gather volume plus a gather copy."""
+
+    def __init__(self, graph: Graph, bounds, rank, world, send_idx, send_counts, recv_counts, back_graph, n_local_edges):
+        self.graph = graph                  # n_src = n_local + n_halo, n_dst = n_local
+        self.bounds = bounds
+        self.rank, self.world = rank, world
+        self.lo, self.hi = bounds[rank], bounds[rank + 1]
+        self.send_idx = send_idx            # my local row ids requested by the others, grouped by requester
+        self.send_counts = send_counts      # python ints, per requester
+        self.recv_counts = recv_counts      # python ints, per owner
+        self.back_graph = back_graph        # Graph(position in send_idx -> my local row): the backward's scatter-add
+        self.n_local_edges = n_local_edges
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+    @property
+    def n_halo(self) -> int:
+        return sum(self.recv_counts)
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int,
+                        bounds: Optional[List[int]] = None, group=None, need_transpose: bool = True) -> "HaloGraph":
+        src, dst = edge_index[0], edge_index[1]
+        if bounds is None:
+            bounds = balanced_bounds(torch.bincount(dst, minlength=num_nodes), world)
+        assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == num_nodes
+        lo, hi = bounds[rank], bounds[rank + 1]
+        n_local = hi - lo
+        dev = edge_index.device
+        b = torch.tensor(bounds, device=dev, dtype=src.dtype)
+        mine = (dst >= lo) & (dst < hi)
+        lsrc, ldst = src[mine], dst[mine] - lo
+        is_local = (lsrc >= lo) & (lsrc < hi)
+        uniq, inverse = torch.unique(lsrc[~is_local], return_inverse=True)     # ascending: grouped by owner
+        owner = torch.bucketize(uniq, b[1:], right=True)
+        recv_counts_t = torch.bincount(owner, minlength=world).to(torch.int64)
+        send_counts_t = torch.empty_like(recv_counts_t)
+        dist.all_to_all_single(send_counts_t, recv_counts_t, group=group)        # how many of MY rows each rank wants
+        recv_counts = [int(v) for v in recv_counts_t.tolist()]
+        send_counts = [int(v) for v in send_counts_t.tolist()]
+        want = (uniq - b[owner]).to(torch.int64)                                 # owner-local ids of the rows I need
+        send_idx = torch.empty(sum(send_counts), device=dev, dtype=torch.int64)
+        dist.all_to_all_single(send_idx, want, output_split_sizes=send_counts, input_split_sizes=recv_counts, group=group)
+        col = torch.empty_like(lsrc)
+        col[is_local] = lsrc[is_local] - lo
+        col[~is_local] = n_local + inverse
+        g = Graph(col, ldst, n_src=n_local + int(uniq.numel()), n_dst=n_local, need_transpose=need_transpose)
+        back = None
+        if need_transpose and send_idx.numel() > 0:
+            ids = torch.arange(send_idx.numel(), device=dev, dtype=send_idx.dtype)
+            back = Graph(ids, send_idx, n_src=send_idx.numel(), n_dst=n_local, need_transpose=False)
+        return cls(g, list(bounds), rank, world, send_idx, send_counts, recv_counts, back, int(mine.sum()))
+
+
+class _HaloExchange(torch.autograd.Function):
+    """x_local (n_local, C) -> [x_local | halo rows] (n_local + n_halo, C); backward: the halo rows' gradients travel
+    back to their owners and are summed into the owners' rows in a fixed (CSR) order."""
+
+    @staticmethod
+    def forward(ctx, x_local, hg, group, local_add):
+        n_local, C = x_local.shape
+        ext = x_local.new_empty(n_local + hg.n_halo, C)
+        ext[:n_local] = x_local
+        send = x_local.index_select(0, hg.send_idx) if hg.send_idx.numel() else x_local.new_empty(0, C)
+        dist.all_to_all_single(ext[n_local:], send, output_split_sizes=hg.recv_counts, input_split_sizes=hg.send_counts,
+                               group=group)
+        ctx.hg, ctx.group, ctx.local_add = hg, group, local_add
+        return ext
+
+    @staticmethod
+    def backward(ctx, g_ext):
+        hg = ctx.hg
+        n_local = hg.n_local
+        C = g_ext.size(1)
+        g_ext = g_ext.contiguous()
+        back = g_ext.new_empty(hg.send_idx.numel(), C)
+        dist.all_to_all_single(back, g_ext[n_local:].contiguous(), output_split_sizes=hg.send_counts,
+                               input_split_sizes=hg.recv_counts, group=ctx.group)
+        grad = g_ext[:n_local]
+        if back.size(0):
+            grad = grad + ctx.local_add(back, hg)       # deterministic segment sum over the requesters
+        return grad.contiguous(), None, None, None
+
+
+def _halo_back_add_hip(back_rows, hg):
+    from . import ops
+    return ops.gen_aggregate(back_rows, hg.back_graph, aggr="add", relu_eps=False)
+
+
+def _halo_back_add_torch(back_rows, hg):
+    out = back_rows.new_zeros(hg.n_local, back_rows.size(1))
+    return out.index_add_(0, hg.send_idx, back_rows)
+
+
+def halo_gen_aggregate(x_local: torch.Tensor, hg: HaloGraph, aggr: str = "softmax", group=None,
+                       local_aggregate=None, **kw) -> torch.Tensor:
+    """Aggregation of this rank's destination rows with a halo-only exchange (see ``HaloGraph``)."""
+    hip = local_aggregate is None
+    if hip:
+        from . import ops
+        local_aggregate = ops.gen_aggregate
+    x_ext = _HaloExchange.apply(x_local, hg, group, _halo_back_add_hip if hip else _halo_back_add_torch)
+    return local_aggregate(x_ext, hg.graph, aggr=aggr, **kw)
+
+
 def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **kw) -> torch.Tensor:
     """Scheme-agnostic entry: ``part`` is a PartitionedGraph (all-gather scheme) or a TransposedGraph."""
     if isinstance(part, TransposedGraph):
         return transposed_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
+    if isinstance(part, HaloGraph):
+        kw.pop("pipeline_chunks", None)
+        return halo_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
     return partitioned_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
 
 
 def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, rank: int, world: int,
                     scheme: str = "auto", edge_attr=None, need_transpose: bool = True,
                     node_groups: Optional[int] = None):
-    """``scheme``: "transposed", "allgather" or "auto" (transposed whenever it applies: it moves several times
+    """``scheme``: "transposed", "allgather", "halo" or "auto" (transposed whenever it applies: it moves several times
     fewer bytes per rank; graphs whose partitions reference few remote rows are the all-gather scheme's case).
     ``node_groups`` (transposed only): None = ``default_node_groups(channels, world)``."""
     if node_groups is None:
@@ -475,4 +593,6 @@ def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, ran
                                                node_groups=node_groups)
     if scheme == "allgather":
         return PartitionedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
+    if scheme == "halo":
+        return HaloGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
     raise ValueError(f"unknown scheme {scheme!r}")

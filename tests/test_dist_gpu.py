@@ -52,6 +52,15 @@ def test_partitioned_aggregate_on_rccl_single_rank():
             (outt * probe).sum().backward()
             torch.testing.assert_close(outt, ref, rtol=1e-6, atol=1e-7)
             torch.testing.assert_close(xd.grad, xb.grad, rtol=1e-5, atol=1e-6)
+            # halo scheme: with one rank the halo is empty (zero-size all_to_all on RCCL), the local kernel sees its rows
+            from deep_gcns_torch_amd.dist import HaloGraph, halo_gen_aggregate
+            hg = HaloGraph.from_edge_index(ei, 257, 0, 1)
+            assert hg.n_halo == 0 and hg.graph.n_src == 257
+            xe = x.clone().requires_grad_(True)
+            outh = halo_gen_aggregate(xe, hg, aggr=aggr, **kw)
+            (outh * probe).sum().backward()
+            torch.testing.assert_close(outh, ref, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(xe.grad, xb.grad, rtol=1e-5, atol=1e-6)
     finally:
         if created:
             dist.destroy_process_group()
