@@ -337,7 +337,10 @@ __global__ __launch_bounds__(kBwdLdsThreads) void dense_edge_bwd_lds_kernel(cons
   const int C = E.C, N = E.N, k = E.k;
   const int c0 = cs * kBwdSlice + half * 4;
   const bool cok = c0 < C;
-  constexpr int U = 4;
+  #ifndef DGCN_EDGE_BWD_U
+#define DGCN_EDGE_BWD_U 4
+#endif
+  constexpr int U = DGCN_EDGE_BWD_U;   // neighbour rows in flight per thread (8 measured the same: the kernel is LDS-atomic bound)
 
   for (int i = tid; i < N * 2; i += kBwdLdsThreads) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
