@@ -330,11 +330,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
 
   // ---- phase 1: distance strip ----
   constexpr int JJ = 4;
-#ifdef KNN_SKIP_DIST
-  const int n_phase1 = KNN_SKIP_DIST ? 0 : N;
-#else
   const int n_phase1 = N;
-#endif
   if (VEC4) {
     // contiguous, 16B-aligned points: each thread owns 4 CONSECUTIVE columns -> one dwordx4 load per
     // channel (1 KiB per wave instruction) and one ds_write_b128 per row.
@@ -439,9 +435,6 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   __syncthreads();
 
   // ---- phases 2-5: one wave per query row ----
-#ifdef KNN_SKIP_SELECT
-  if (KNN_SKIP_SELECT) continue;
-#endif
   for (int r = wave; r < TM; r += kKnnWaves) {
     const int i = i0 + r;
     if (i >= N) continue;  // wave-uniform
@@ -600,6 +593,10 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
   else sort_and_emit<8>(P, ckey, cidx, lane, K, out_base, i);
 }
 
+// Profiling-only compile-time switches (never defined in the shipped build; results are WRONG with them):
+//   KNNF_STOP_AFTER=1|2  return after the threshold load / after the distance + append pass
+//   KNNF_NO_MFMA, KNNF_NO_APPEND  drop the matrix-core work / the candidate appends
+// They produced the phase decomposition quoted in DESIGN.md section 4.3 (rocprofv3 per-kernel times of variant builds).
 // CAP = per-row candidate list capacity: 512 (64 KB of lists -> two workgroups per CU, their phases overlap)
 // when K leaves enough room below it, else 1024.
 template <int kFCap, int KS>
@@ -686,11 +683,6 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
   float aA[KS], aB[KS];
   float4 bA[KS], bB[KS];
   load_chunk(wave * 64, 0, aA, bA);
-#ifdef KNNF_STAGGER
-  // waves w, w+4, w+8, w+12 share a SIMD: start them a fraction of a block apart so that their load / MFMA /
-  // append phases interleave instead of marching in step
-  for (int d = 0; d < (wave >> 2); ++d) __builtin_amdgcn_s_sleep(KNNF_STAGGER);
-#endif
   for (int col0 = wave * 64; col0 < N; col0 += kColStride) {
     const int cbase = col0 + 4 * li;
     const bool in = cbase < N;  // N % 4 == 0
@@ -702,25 +694,13 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
       // scheduler sinks every load next to its first use (lower register pressure, no overlap at all)
       load_chunk(col0, (ch + 1) * CHUNK, aB, bB);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef KNNF_SETPRIO
-      __builtin_amdgcn_s_setprio(KNNF_SETPRIO);
-#endif
       mfma_chunk(acc, aA, bA);
-#ifdef KNNF_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // next A chunk: this block's, or the first of the next block (clamped past the end: loaded, never used)
       const bool more = ch + 2 < cpb;
       load_chunk(more ? col0 : col0 + kColStride, more ? (ch + 2) * CHUNK : 0, aA, bA);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef KNNF_SETPRIO
-      __builtin_amdgcn_s_setprio(KNNF_SETPRIO);
-#endif
       mfma_chunk(acc, aB, bB);
-#ifdef KNNF_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef KNNF_NO_APPEND
