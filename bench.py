@@ -184,18 +184,31 @@ def main():
         tuned = {}
         best = None
         for sch, wn in cands:
-            cand = make(sch, wn)
-            if len(cands) > 1:
+            if len(cands) == 1:
+                best = (0.0, sch, wn, make(sch, wn))
+                break
+            # a candidate that fails on any rank is dropped on all of them (the flag is agreed on with a MIN-reduce;
+            # a failure in the middle of a collective cannot be recovered from and surfaces as the NCCL timeout)
+            cand, ms, err = None, float("inf"), None
+            try:
+                cand = make(sch, wn)
                 timed(cand[3], cand[1], cand[2], 2)
                 ms = timed(cand[3], cand[1], cand[2], 3)
+            except Exception as exc:   # noqa: BLE001 -- reported below, never silently
+                err = repr(exc)[:200]
+            okf = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                tuned[f"{sch}/node_groups={wn}"] = f"failed: {err or 'on another rank'}"
+                cand = None
+            else:
                 tuned[f"{sch}/node_groups={wn}"] = round(ms, 3)
                 if best is None or ms < best[0]:
                     best = (ms, sch, wn, cand)
-                else:
-                    del cand
-                torch.cuda.empty_cache()
-            else:
-                best = (0.0, sch, wn, cand)
+                cand = None
+            torch.cuda.empty_cache()
+        if best is None:
+            raise SystemExit(f"no exchange scheme ran: {tuned}")
         _, scheme, node_groups, (part, x, g_loc, fwd) = best
         transposed = isinstance(part, ddist.TransposedGraph)
         del ei, x_full, g_full
