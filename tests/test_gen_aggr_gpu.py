@@ -169,6 +169,65 @@ def test_arxiv_shape_properties():
     assert torch.equal(ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.1), sm)
 
 
+def test_products_shape_properties():
+    """BASELINE config 4 at FULL size (N = 2,449,029, E = 126,167,309, C = 128): the CPU oracle cannot replay this, so
+    parity is checked through size-independent properties -- convexity bounds, add = mean * degree, exact gradients
+    of the linear aggregators, the softmax gradient identity sum_c-free check on sampled rows against a torch
+    gather, bit reproducibility."""
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.graph import Graph
+    dev = _dev()
+    s = synth.SHAPES["products"]
+    n, C = s["n"], s["channels"]
+    ei = synth.undirected_random_graph(n, s["n_undirected"], s["seed"], device=dev)
+    assert ei.size(1) == 126_167_309
+    graph = Graph.from_edge_index(ei, n)
+    x = torch.randn(n, C, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    sm = ops.gen_aggregate(x, graph, aggr="softmax_sg", t=0.1)
+    mx = ops.gen_aggregate(x, graph, aggr="max")
+    mn = ops.gen_aggregate(x, graph, aggr="mean")
+    assert torch.all(sm <= mx * (1 + 1e-5) + 1e-6) and torch.all(sm >= mn * (1 - 1e-5) - 1e-6)
+    del mx
+    ad = ops.gen_aggregate(x, graph, aggr="add")
+    torch.testing.assert_close(ad, mn * graph.deg.unsqueeze(1), rtol=1e-4, atol=1e-4)
+    del ad, mn
+    # sampled rows against a direct torch evaluation of the reference formula (softmax over the row's neighbours)
+    rows = torch.randint(0, n, (64,), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    rp = graph.rowptr.long()
+    for r in rows.tolist():
+        nb = graph.col[rp[r]:rp[r + 1]].long()
+        if nb.numel() == 0:
+            assert float(sm[r].abs().max()) == 0.0
+            continue
+        m = torch.relu(x[nb]).double() + 1e-7
+        w = torch.softmax(0.1 * m, dim=0)
+        torch.testing.assert_close(sm[r].double(), (w * m).sum(0), rtol=1e-4, atol=1e-7)
+    # backward: 'add' is linear (grad = out-degree * relu'), softmax_sg gradient sums match a finite directional check
+    xg = x.clone().requires_grad_(True)
+    ops.gen_aggregate(xg, graph, aggr="add").sum().backward()
+    odeg = (graph.t_rowptr[1:] - graph.t_rowptr[:-1]).float().unsqueeze(1)
+    torch.testing.assert_close(xg.grad, odeg * (x > 0).float(), rtol=1e-5, atol=1e-5)
+    xg.grad = None
+    probe = torch.randn(n, C, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    out = ops.gen_aggregate(xg, graph, aggr="softmax_sg", t=0.1)
+    (out * probe).sum().backward()
+    # sampled SOURCE rows: softmax_sg treats the weights as constants (torch_message.py:55-58), so
+    # grad_x[s] = relu'(x_s) * sum_{e: s -> i} w_e * probe_i  with  w_e = softmax over i's in-edges, evaluated with torch
+    trp = graph.t_rowptr.long()
+    for sidx in rows[:16].tolist():
+        dsts = graph.t_col[trp[sidx]:trp[sidx + 1]].long()
+        acc = torch.zeros(C, device=dev, dtype=torch.float64)
+        ms = torch.relu(x[sidx]).double() + 1e-7
+        for i in dsts.tolist():
+            nb = graph.col[rp[i]:rp[i + 1]].long()
+            m = torch.relu(x[nb]).double() + 1e-7
+            lse = torch.logsumexp(0.1 * m, dim=0)
+            acc += torch.exp(0.1 * ms - lse) * probe[i].double()
+        want = acc * (x[sidx] > 0).double()
+        torch.testing.assert_close(xg.grad[sidx].double(), want, rtol=1e-4, atol=1e-6)
+    assert torch.equal(ops.gen_aggregate(x, graph, aggr="softmax_sg", t=0.1), sm)
+
+
 @pytest.mark.parametrize("t,expect_shifted", [(0.1, True), (1.0, True), (40.0, False)])
 def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_shifted):
     """The softmax backward gathers ONE pre-scaled row per edge when every |L_i| < 80 (checked by the forward
