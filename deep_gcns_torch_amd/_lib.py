@@ -111,6 +111,10 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dgcn_rows_ln_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_msgnorm_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                            C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_msgnorm_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

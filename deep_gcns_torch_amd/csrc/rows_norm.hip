@@ -614,3 +614,161 @@ extern "C" int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, 
   else DGCN_LN_DISPATCH(rows_ln_bwd_kernel, false, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C);
   return launch_status();
 }
+
+// =====================================================================================================
+// MsgNorm (gcn_lib/sparse/torch_message.py:88-99) fused with the residual of GENConv.forward (torch_vertex.py:70-74):
+//   y_r = [x_r +] m_r / max(||m_r||_2, 1e-12) * ||x_r||_2 * s          s = msg_scale (device scalar)
+// One pass forward (read x, m; write y), one pass backward (read g, x, m; write dx, dm; per-workgroup partial ds);
+// the stock composition is 7 elementwise / reduction kernels forward and about twice that backward.
+//   u = m / b, b = max(||m||, eps), a = ||x||, q = <u, g>
+//   dm = (a s / b) (g - u q)   (only the g term when ||m|| <= eps: F.normalize clamps the norm, no gradient through it)
+//   dx = [g +] s q x / a       (0 when a = 0)
+//   ds = sum_r a q
+// =====================================================================================================
+namespace dgcn {
+namespace {
+
+constexpr float kMsgNormEps = 1e-12f;   // F.normalize default
+
+template <int LPR, int Q, bool ADD_X>
+__global__ __launch_bounds__(kWgThreads) void rows_msgnorm_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ m,
+                                                                     const float* __restrict__ scale,
+                                                                     float* __restrict__ y, int64_t rows, int C) {
+  constexpr int RPW = kWave / LPR;
+  const int lane = lane_id();
+  const int sub = lane / LPR, li = lane % LPR;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + (threadIdx.x >> 6);
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+  const float s = *scale;
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    float xv[Q][4], mv[Q][4];
+    float sx = 0.f, sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int c = (li + k * LPR) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[k][j] = 0.f; mv[k][j] = 0.f; }
+      if (live && c < C) {
+        load_vec<4>(xv[k], x + r * ldx + c);
+        load_vec<4>(mv[k], m + r * C + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sx = fmaf(xv[k][j], xv[k][j], sx); sm = fmaf(mv[k][j], mv[k][j], sm); }
+    }
+    const float a = sqrtf(row_sum<LPR>(sx));
+    const float b = fmaxf(sqrtf(row_sum<LPR>(sm)), kMsgNormEps);
+    const float f = a * s / b;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const int c = (li + k * LPR) * 4;
+        if (c < C) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ADD_X ? fmaf(mv[k][j], f, xv[k][j]) : mv[k][j] * f;
+          store_vec<4>(y + r * C + c, o);
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, int Q, bool ADD_X>
+__global__ __launch_bounds__(kWgThreads) void rows_msgnorm_bwd_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ m,
+                                                                     const float* __restrict__ scale,
+                                                                     float* __restrict__ dx, float* __restrict__ dm,
+                                                                     float* __restrict__ ds_partial, int64_t rows,
+                                                                     int C) {
+  constexpr int RPW = kWave / LPR;
+  __shared__ float red[kWavesPerWg];
+  const int lane = lane_id();
+  const int sub = lane / LPR, li = lane % LPR;
+  const int wv = threadIdx.x >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + wv;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+  const float s = *scale;
+  float ds = 0.f;
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    float xv[Q][4], mv[Q][4], gv[Q][4];
+    float sx = 0.f, sm = 0.f, mg = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int c = (li + k * LPR) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[k][j] = 0.f; mv[k][j] = 0.f; gv[k][j] = 0.f; }
+      if (live && c < C) {
+        load_vec<4>(xv[k], x + r * ldx + c);
+        load_vec<4>(mv[k], m + r * C + c);
+        load_vec<4>(gv[k], g + r * C + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sx = fmaf(xv[k][j], xv[k][j], sx);
+        sm = fmaf(mv[k][j], mv[k][j], sm);
+        mg = fmaf(mv[k][j], gv[k][j], mg);
+      }
+    }
+    const float a = sqrtf(row_sum<LPR>(sx));
+    const float nm = sqrtf(row_sum<LPR>(sm));
+    const float b = fmaxf(nm, kMsgNormEps);
+    const float q = row_sum<LPR>(mg) / b;            // <u, g>
+    const float f = a * s / b;
+    const float proj = (nm > kMsgNormEps) ? q / b : 0.f;   // u q / b = m q / b^2: zero when the norm was clamped
+    const float cx = (a > 0.f) ? s * q / a : 0.f;
+    if (live) {
+      if (li == 0) ds += a * q;
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const int c = (li + k * LPR) * 4;
+        if (c < C) {
+          float om[4], ox[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            om[j] = f * (gv[k][j] - mv[k][j] * proj);
+            ox[j] = ADD_X ? fmaf(cx, xv[k][j], gv[k][j]) : cx * xv[k][j];
+          }
+          if (dm) store_vec<4>(dm + r * C + c, om);
+          if (dx) store_vec<4>(dx + r * C + c, ox);
+        }
+      }
+    }
+  }
+  // ds: lanes -> wave -> workgroup, fixed order
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) ds += __shfl_xor(ds, off);
+  if (lane == 0) red[wv] = ds;
+  __syncthreads();
+  if (threadIdx.x == 0 && ds_partial) ds_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+}  // namespace
+}  // namespace dgcn
+
+extern "C" int dgcn_rows_msgnorm_fwd_f32(const float* x, int64_t ldx, const float* m, const float* scale,
+                                         int32_t add_x, float* y, int64_t rows, int32_t C, void* stream) {
+  if (!x || !m || !scale || !y) return DGCN_E_NULL;
+  if (rows < 0) return DGCN_E_SHAPE;
+  if (!ln_ok(C, ldx, x, m, y, nullptr, nullptr)) return (C > 0 && C % 4 == 0 && C <= 1024 && ldx >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  if (rows == 0) return DGCN_OK;
+  if (add_x) DGCN_LN_DISPATCH(rows_msgnorm_fwd_kernel, true, x, ldx, m, scale, y, rows, C);
+  else DGCN_LN_DISPATCH(rows_msgnorm_fwd_kernel, false, x, ldx, m, scale, y, rows, C);
+  return launch_status();
+}
+
+extern "C" int dgcn_rows_msgnorm_bwd_f32(const float* g, const float* x, int64_t ldx, const float* m,
+                                         const float* scale, int32_t add_x, float* dx, float* dm, float* ds_partial,
+                                         int64_t rows, int32_t C, void* stream) {
+  if (!g || !x || !m || !scale) return DGCN_E_NULL;
+  if (rows <= 0) return DGCN_E_SHAPE;
+  if (!ln_ok(C, ldx, x, m, g, dx, dm)) return (C > 0 && C % 4 == 0 && C <= 1024 && ldx >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  if (add_x) DGCN_LN_DISPATCH(rows_msgnorm_bwd_kernel, true, g, x, ldx, m, scale, dx, dm, ds_partial, rows, C);
+  else DGCN_LN_DISPATCH(rows_msgnorm_bwd_kernel, false, g, x, ldx, m, scale, dx, dm, ds_partial, rows, C);
+  return launch_status();
+}

@@ -6,7 +6,7 @@ MsgNorm :88-99) without PyG: gather + message + aggregate run as ONE fused HIP k
 import torch
 import torch.nn.functional as F
 
-from ... import ops
+from ... import node_ops, ops
 from ...graph import Graph, graph_of
 
 __all__ = ["GenMessagePassing", "MsgNorm"]
@@ -108,6 +108,10 @@ class MsgNorm(torch.nn.Module):
         super().__init__()
         self.msg_scale = torch.nn.Parameter(torch.Tensor([1.0]), requires_grad=learn_msg_scale)
 
-    def forward(self, x, msg, p=2):
+    def forward(self, x, msg, p=2, add_x=False):
+        """``add_x`` (extension) returns ``x + msg_norm(x, msg)``: GENConv's residual from the same kernel."""
+        if p == 2 and node_ops.msg_norm_supported(x, msg):
+            return node_ops.msg_norm_rows(x, msg, self.msg_scale, add_x=add_x)        # one HIP row kernel
         unit = F.normalize(msg, p=p, dim=1)
-        return unit * x.norm(p=p, dim=1, keepdim=True) * self.msg_scale
+        out = unit * x.norm(p=p, dim=1, keepdim=True) * self.msg_scale
+        return x + out if add_x else out

@@ -54,7 +54,7 @@ class GENConv(GenMessagePassing):
             return self.mlp(self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True, edge_encoder=enc))
         m = self.propagate(edge_index, x=x, edge_attr=edge_emb, edge_encoder=enc)
         if self.msg_norm is not None:
-            m = self.msg_norm(x, m)
+            return self.mlp(self.msg_norm(x, m, add_x=True))        # x + MsgNorm(x, m) in one row kernel
         return self.mlp(x + m)
 
     def message(self, x_j, edge_attr=None):

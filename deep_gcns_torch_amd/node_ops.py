@@ -194,3 +194,58 @@ class LayerNorm(nn.LayerNorm):
             return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu)
         y = super().forward(x)
         return torch.relu(y) if fuse_relu else y
+
+
+class _MsgNormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, msg, scale, add_x: bool, track: bool):
+        lib = _lib.load()
+        dev = _lib.require_device(x, msg, scale)
+        stream = _lib.current_stream_handle(dev)
+        if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+            x = x.contiguous()
+        msg = msg.float().contiguous()
+        sc = scale.detach().float().contiguous()
+        rows, C = x.shape
+        ldx = x.stride(0) if rows > 1 else C
+        y = torch.empty(rows, C, device=dev, dtype=torch.float32)
+        with _lib.device_ctx(dev):
+            _lib.check(lib.dgcn_rows_msgnorm_fwd_f32(x.data_ptr(), ldx, msg.data_ptr(), sc.data_ptr(), 1 if add_x else 0,
+                                                     y.data_ptr(), rows, C, stream), "dgcn_rows_msgnorm_fwd_f32")
+        if track and any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(x, msg, sc)
+            ctx.add_x = add_x
+            ctx.scale_shape = tuple(scale.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, msg, sc = ctx.saved_tensors
+        dev = x.device
+        stream = _lib.current_stream_handle(dev)
+        rows, C = x.shape
+        ldx = x.stride(0) if rows > 1 else C
+        g = g.float().contiguous()
+        dx = torch.empty(rows, C, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dm = torch.empty(rows, C, device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        part = None
+        if ctx.needs_input_grad[2]:
+            part = torch.empty(lib.dgcn_rows_ln_num_partials(rows, C), device=dev, dtype=torch.float32)
+        with _lib.device_ctx(dev):
+            _lib.check(lib.dgcn_rows_msgnorm_bwd_f32(g.data_ptr(), x.data_ptr(), ldx, msg.data_ptr(), sc.data_ptr(),
+                                                     1 if ctx.add_x else 0, _lib.ptr(dx), _lib.ptr(dm), _lib.ptr(part),
+                                                     rows, C, stream), "dgcn_rows_msgnorm_bwd_f32")
+        ds = part.sum().reshape(ctx.scale_shape) if part is not None else None
+        return dx, dm, ds, None, None
+
+
+def msg_norm_rows(x: torch.Tensor, msg: torch.Tensor, scale: torch.Tensor, add_x: bool = False) -> torch.Tensor:
+    """``[x +] normalize(msg) * ||x||_2 * scale`` row by row (MsgNorm, torch_message.py:95-99, p = 2) in one kernel."""
+    return _MsgNormRows.apply(x, msg, scale, bool(add_x), torch.is_grad_enabled())
+
+
+def msg_norm_supported(x: torch.Tensor, msg: torch.Tensor) -> bool:
+    C = x.size(-1)
+    return (x.is_cuda and x.dim() == 2 and msg.shape == x.shape and x.dtype == torch.float32 and msg.dtype == torch.float32
+            and C % 4 == 0 and C <= 1024 and x.size(0) > 0 and not torch.is_autocast_enabled())

@@ -359,6 +359,16 @@ int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, const float
                          const float* mean, const float* rstd, float* dx, float* partial, int64_t rows, int32_t C,
                          void* stream);
 
+/* MsgNorm (gcn_lib/sparse/torch_message.py:88-99) fused with GENConv's residual (torch_vertex.py:70-74):
+ *   y_r = [x_r +] m_r / max(||m_r||_2, 1e-12) * ||x_r||_2 * (*scale)      rows independent, C % 4 == 0, C <= 1024
+ * backward: dx, dm (either may be NULL) and ds_partial [dgcn_rows_ln_num_partials(rows, C)] whose sum is d scale. */
+int dgcn_rows_msgnorm_fwd_f32(const float* x, int64_t ldx, const float* m, const float* scale, int32_t add_x,
+                              float* y, int64_t rows, int32_t C, void* stream);
+
+int dgcn_rows_msgnorm_bwd_f32(const float* g, const float* x, int64_t ldx, const float* m, const float* scale,
+                              int32_t add_x, float* dx, float* dm, float* ds_partial, int64_t rows, int32_t C,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

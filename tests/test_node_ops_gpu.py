@@ -52,7 +52,7 @@ def test_batchnorm_rows_matches_torch(rows, C, training, relu):
     # dx = scale*(g' - mean g' - xhat*mean(g' xhat)) cancels heavily when there are few rows: the error scales with
     # the size of the TERMS (|g| * |gamma| * invstd), not with the (much smaller) result
     var = x.double().var(0, unbiased=False) if training else ref.running_var
-    nat = float(probe.abs().max() * ref.weight.abs().max() * (1.0 / torch.sqrt(var + ref.eps)).max())
+    nat = float(probe.abs().max() * ref.weight.detach().abs().max() * (1.0 / torch.sqrt(var + ref.eps)).max())
     gs = max(1.0, float(gx_ref.abs().max()))
     torch.testing.assert_close(xd.grad.cpu().double(), gx_ref, rtol=RTOL, atol=1e-5 * gs + 2e-6 * nat)
     gw = max(1.0, float(ref.weight.grad.abs().max()))
@@ -175,3 +175,65 @@ def test_layernorm_module_fallbacks_and_mlp_fusion():
     torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-7)
     for (na, pa), (nb, pb) in zip(mlp.named_parameters(), stock.named_parameters()):
         torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6, msg=lambda m: f"{na}: {m}")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 128), (777, 100), (513, 64), (64, 8), (300, 1024), (169343, 128)])
+@pytest.mark.parametrize("add_x", [False, True])
+def test_msgnorm_rows_matches_reference_formula(rows, C, add_x):
+    """MsgNorm (torch_message.py:95-99) [+ residual] against the stock composition in float64: y, dx, dmsg, dscale;
+    includes an all-zero message row (normalize clamps the norm) and an all-zero x row."""
+    import torch.nn.functional as F
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    x = torch.randn(rows, C, generator=g)
+    m = torch.randn(rows, C, generator=g) * 3.0
+    m[3] = 0.0
+    x[5] = 0.0
+    probe = torch.randn(rows, C, generator=g)
+    s0 = torch.tensor([0.7])
+    xr, mr, sr = x.double().requires_grad_(True), m.double().requires_grad_(True), s0.double().requires_grad_(True)
+    yr = F.normalize(mr, p=2, dim=1) * xr.norm(p=2, dim=1, keepdim=True) * sr
+    if add_x:
+        yr = xr + yr
+    (yr * probe.double()).sum().backward()
+    xd, md = x.to(dev).requires_grad_(True), m.to(dev).requires_grad_(True)
+    sd = s0.to(dev).requires_grad_(True)
+    assert node_ops.msg_norm_supported(xd, md)
+    y = node_ops.msg_norm_rows(xd, md, sd, add_x=add_x)
+    (y * probe.to(dev)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=RTOL, atol=1e-5)
+    torch.testing.assert_close(md.grad.cpu().double(), mr.grad, rtol=1e-4, atol=1e-5 * float(mr.grad.abs().max()))
+    gx_ref = xr.grad.clone()
+    gx_ref[5] = torch.nan_to_num(gx_ref[5], nan=0.0) if not add_x else torch.nan_to_num(gx_ref[5], nan=0.0)
+    if add_x:
+        gx_ref[5] = probe[5].double()              # d||x||/dx at 0 is taken as 0 (torch yields nan for the norm term)
+    torch.testing.assert_close(xd.grad.cpu().double(), gx_ref, rtol=1e-4, atol=1e-5 * float(gx_ref.abs().max()))
+    torch.testing.assert_close(sd.grad.cpu().double(), sr.grad, rtol=1e-4, atol=1e-6 * float(sr.grad.abs().max()) + 1e-6)
+
+
+def test_genconv_with_msgnorm_uses_the_fused_residual_and_matches_composition():
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import node_ops, synth
+    from gcn_lib.sparse.torch_vertex import GENConv
+    dev = _dev()
+    torch.manual_seed(3)
+    conv = GENConv(64, 64, aggr="softmax", t=1.0, learn_t=True, msg_norm=True, learn_msg_scale=True, norm="batch").to(dev)
+    ei = synth.undirected_random_graph(3000, 20000, seed=2, device=dev)
+    x = torch.randn(3000, 64, device=dev)
+
+    def run(fused):
+        saved = node_ops.msg_norm_supported
+        if not fused:
+            node_ops.msg_norm_supported = lambda *a: False
+        try:
+            conv.zero_grad()
+            xa = x.clone().requires_grad_(True)
+            conv(xa, ei).square().mean().backward()
+            return xa.grad.clone(), conv.msg_norm.msg_scale.grad.clone(), conv.t.grad.clone()
+        finally:
+            node_ops.msg_norm_supported = saved
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        torch.testing.assert_close(u, v, rtol=1e-3, atol=1e-6 * float(v.abs().max()) + 1e-9)
