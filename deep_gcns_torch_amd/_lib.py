@@ -63,6 +63,8 @@ _SIGNATURES = {
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_power_bwd_prep_f32": (C.c_int, [C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                          C.c_int32, C.c_void_p]),
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_void_p]),
     "dgcn_knn_dense_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -229,6 +229,31 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
   gen_aggr_bwd_body<MODE, VEC, LPR, SW, EA>(P);
 }
 
+// Per-destination coefficient of the power-mean / mean backward, one streaming pass instead
+// of five elementwise torch kernels:  out[i,c] = g[i,c] * r^(1/p - 1) * [lo <= q <= hi] / max(deg_i, 1),
+// r = clamp(q, lo, hi), q = the forward's pre-clamp mean (aux1); q == nullptr gives the MEAN form g / max(deg, 1).
+__global__ __launch_bounds__(kWgThreads) void power_bwd_prep_kernel(const float* __restrict__ g,
+                                                                    const float* __restrict__ q,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const float* __restrict__ p_dev, float p,
+                                                                    float* __restrict__ out, int64_t n_elems, int C) {
+  const float pp = p_dev ? *p_dev : p;
+  const float ex = 1.f / pp - 1.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_elems; i += stride) {
+    const int64_t row = i / C;
+    const float deg = fmaxf(static_cast<float>(rowptr[row + 1] - rowptr[row]), 1.f);
+    float v = g[i] / deg;
+    if (q) {
+      const float qq = q[i];
+      const bool in = (qq >= kPowLo) && (qq <= kPowHi);
+      const float r = fminf(fmaxf(qq, kPowLo), kPowHi);
+      v = in ? v * fast_pow(r, ex) : 0.f;
+    }
+    out[i] = v;
+  }
+}
+
 // out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])   (node-wise prologue of the single-gather backward)
 __global__ __launch_bounds__(kWgThreads) void softmax_bwd_prep_kernel(const float* __restrict__ g,
                                                                       const float* __restrict__ L,
@@ -396,6 +421,19 @@ extern "C" int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const f
   return launch_status();
 }
 
+
+extern "C" int dgcn_power_bwd_prep_f32(const dgcn_graph* g, const float* grad_out, const float* q,
+                                       const float* p_dev, float p, float* out, int32_t channels, void* stream) {
+  if (!g || !grad_out || !out || !g->rowptr) return DGCN_E_NULL;
+  if (g->n_dst < 0 || channels <= 0) return DGCN_E_SHAPE;
+  if (g->n_dst == 0) return DGCN_OK;
+  const int64_t n = static_cast<int64_t>(g->n_dst) * channels;
+  int64_t blocks = (n + kWgThreads - 1) / kWgThreads;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(power_bwd_prep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWgThreads), 0,
+                     static_cast<hipStream_t>(stream), grad_out, q, g->rowptr, p_dev, p, out, n, channels);
+  return launch_status();
+}
 
 extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
   if (!g || g->t_n_work == 0) return 0;

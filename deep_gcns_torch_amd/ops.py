@@ -136,18 +136,22 @@ class _GenAggregate(torch.autograd.Function):
         C = x.size(1)
         g = grad_out.float().contiguous()
         p = p_param if p_param is not None else ctx.p_val
-        deg1 = graph.deg.clamp(min=1.0).unsqueeze(1)
 
         grad_t = grad_p = None
-        if mode == _lib.AGGR_MEAN:
-            gcoef = g / deg1
-        elif mode == _lib.AGGR_POWER:
-            q = aux1
-            r = q.clamp(POW_LO, POW_HI)
-            inr = ((q >= POW_LO) & (q <= POW_HI)).to(g.dtype)
-            gcoef = g * r.pow(1.0 / p - 1.0) * inr / deg1
-            if ctx.learn_p and ctx.needs_input_grad[3]:
+        if mode in (_lib.AGGR_MEAN, _lib.AGGR_POWER):
+            # per-destination coefficient g * r^(1/p-1) * [q in range] / max(deg, 1) (MEAN: g / max(deg, 1)): one pass
+            gcoef = torch.empty_like(g)
+            with _lib.device_ctx(dev):
+                _lib.check(lib.dgcn_power_bwd_prep_f32(
+                    graph.c_struct, g.data_ptr(), aux1.data_ptr() if mode == _lib.AGGR_POWER else None,
+                    _lib.ptr(p_param), ctx.p_val, gcoef.data_ptr(), C, _lib.current_stream_handle(dev)),
+                    "dgcn_power_bwd_prep_f32")
+            if mode == _lib.AGGR_POWER and ctx.learn_p and ctx.needs_input_grad[3]:
                 # d o/d p = o * ( -ln r / p^2 + 1[q in range] * S2 / (p * deg * r) ),  S2 = sum u^p ln u
+                q = aux1
+                deg1 = graph.deg.clamp(min=1.0).unsqueeze(1)
+                r = q.clamp(POW_LO, POW_HI)
+                inr = ((q >= POW_LO) & (q <= POW_HI)).to(g.dtype)
                 dodp = out * (-torch.log(r) / (p * p) + inr * aux2 / (p * deg1 * r))
                 grad_p = (g * dodp).sum().reshape(p_param.shape)
         else:

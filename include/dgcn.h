@@ -186,6 +186,13 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
                               const int32_t* shift_ok, const float* groot, float* grad_x,
                               float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-destination coefficient of the POWER / MEAN backward in one pass (the `gcoef` of dgcn_gen_aggr_bwd_f32):
+ *   out[i,c] = grad_out[i,c] * r^(1/p - 1) * [1e-7 <= q <= 10] / max(deg_i, 1),  r = clamp(q, 1e-7, 10)
+ * q = aux1 of the POWER forward (torch_message.py:68-74); q == NULL gives the MEAN form grad_out / max(deg_i, 1).
+ * p_dev (device scalar) overrides p when given. */
+int dgcn_power_bwd_prep_f32(const dgcn_graph* g, const float* grad_out, const float* q, const float* p_dev, float p,
+                            float* out, int32_t channels, void* stream);
+
 /* Node-wise prologue of the single-gather softmax backward:
  *   out[i,c] = g[i,c] * exp(kshift[c] - L[i,c])          (channels % 4 == 0)
  * With it, dL/dm_e = g_i exp(t m_e - L_i) = out_i * exp(t m_e - kshift_c): the edge walk gathers ONE row
