@@ -78,11 +78,13 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
           int ai[U][VEC];
           bool ok[U];
           int eid[U];
+          int dsts[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int ei = s0 + u * G + g;
             ok[u] = ei < nb;
             const int dst = __shfl(mycol, sbase + (ei & (SW - 1)));
+            dsts[u] = dst;
             eid[u] = 0;
             if constexpr (NEED_EID) eid[u] = __shfl(myeid, sbase + (ei & (SW - 1)));
 #pragma unroll
@@ -93,7 +95,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
               const int64_t ro = static_cast<int64_t>(dst) * C + c0;
               if constexpr (MODE == kModeSoftmaxShifted) {
                 load_vec<VEC>(gc[u], P.gshift + ro);
-              } else {
+              } else if constexpr (MODE != DGCN_AGGR_MAX) {   // MAX: g is fetched below, only where an arg-max matches
                 load_vec<VEC>(gc[u], P.gcoef + ro);
               }
               if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
@@ -107,6 +109,17 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
                 load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
               }
               if constexpr (EA == 2) enc_feat_row(fe[u], P.enc_feat, eid[u]);
+            }
+          }
+          if constexpr (MODE == DGCN_AGGR_MAX) {
+            // An edge receives gradient only in the channels whose arg-max it is (about 1/deg of them): read the
+            // arg-max ids for every edge, but g only for the lanes with a hit -- half the gathered bytes.
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              bool hit = false;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) hit = hit || (ai[u][j] == eid[u]);
+              if (ok[u] && act && hit) load_vec<VEC>(gc[u], P.gcoef + static_cast<int64_t>(dsts[u]) * C + c0);
             }
           }
 #pragma unroll
