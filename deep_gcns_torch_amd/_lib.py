@@ -96,6 +96,11 @@ _SIGNATURES = {
                                        C.c_void_p]),
     "dgcn_bn_bwd_finalize_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dgcn_dense_edge_reduce_bwd_inv_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "dgcn_dense_edge_reduce_bwd_inv_f32": (C.c_int, [
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
     "dgcn_rows_num_partials": (C.c_int32, [C.c_int64, C.c_int32]),

@@ -137,6 +137,10 @@ struct EdgeParams {
                           // and to the arg-min slot where scale < 0 (gmin is then ignored)
   float* dP;          // [B,N,C] or null
   float* dQ;          // [B,N,C], pre-zeroed, accumulated with hardware fp32 atomics
+  float* dz;          // [B,N,k,C] or null: backward writes every edge's dz row here INSTEAD of accumulating dQ (the
+                      // inverse-list gather kernel sums them per neighbour afterwards)
+  int32_t* inv_cnt;   // with dz: [B,N] zeroed in-degree counters; the edge's arrival rank in its neighbour's list
+  int32_t* inv_rank;  //          = atomicAdd(inv_cnt, 1) is stored per edge [B,N,k] (counting sort, first pass)
 };
 
 __device__ __forceinline__ float act_apply(float z, int act, float slope) {
@@ -255,9 +259,17 @@ __global__ __launch_bounds__(kWgThreads) void dense_edge_kernel(const EdgeParams
             }
           }
           if constexpr (BWD) {
-            float* dq = E.dQ + (static_cast<int64_t>(b) * E.N + nb[u]) * E.ldq + c0;
+            if (E.dz) {
+              store_vec<4>(E.dz + ((static_cast<int64_t>(b) * E.N + n) * k + l) * C + c0, dz);
+              if (cl == 0 && cb == 0) {
+                E.inv_rank[(static_cast<int64_t>(b) * E.N + n) * k + l] =
+                    atomicAdd(&E.inv_cnt[static_cast<int64_t>(b) * E.N + nb[u]], 1);
+              }
+            } else {
+              float* dq = E.dQ + (static_cast<int64_t>(b) * E.N + nb[u]) * E.ldq + c0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dq + j, dz[j]);
+              for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dq + j, dz[j]);
+            }
           }
         }
       }
@@ -427,6 +439,121 @@ __global__ __launch_bounds__(kBwdLdsThreads) void dense_edge_bwd_lds_kernel(cons
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Backward through inverse neighbour lists (default when the caller provides the workspace).
+//   dQ[b,j,:] = sum over the edges (n,l) with idx[b,n,l] = j of dz[b,n,l,:]
+// Instead of 33.5 M LDS float atomics per ResGCN layer (the LDS-privatised kernel above runs at ~1 lane/clk/CU),
+// the edge kernel writes the dz rows once (B*N*k*C floats, L2/MALL resident) and takes each edge's rank in its
+// neighbour's list with one integer L2 atomic; a scan and an atomic-free fill finish the counting sort, and a
+// gather kernel sums each neighbour's rows:
+// one 16-byte-per-lane row read per incoming edge, no float atomics.  The order inside a list follows the fill
+// order, so sums are reproducible only up to fp32 rounding (as with the LDS atomics before).
+// ---------------------------------------------------------------------------------------
+// ptr[b][0..N] = exclusive scan of cnt[b][0..N) ; one workgroup per sample
+__global__ __launch_bounds__(kBwdLdsThreads) void inv_scan_kernel(const int32_t* __restrict__ cnt, int N,
+                                                                 int32_t* __restrict__ ptr) {
+  __shared__ int32_t wsum[kBwdLdsThreads / kWave];
+  __shared__ int32_t carry;
+  const int b = blockIdx.x;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += kBwdLdsThreads) {
+    const int j = base + threadIdx.x;
+    const int v = j < N ? cnt[static_cast<int64_t>(b) * N + j] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == kWave - 1) wsum[wv] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    const int excl = before + incl - v;
+    if (j < N) ptr[static_cast<int64_t>(b) * (N + 1) + j] = excl;
+    __syncthreads();
+    if (threadIdx.x == kBwdLdsThreads - 1) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[static_cast<int64_t>(b) * (N + 1) + N] = carry;
+}
+
+__global__ __launch_bounds__(kWgThreads) void inv_fill_kernel(const int64_t* __restrict__ idx, int64_t ib, int64_t in_,
+                                                             int64_t ik, int B, int N, int k,
+                                                             const int32_t* __restrict__ ptr,
+                                                             const int32_t* __restrict__ rank,
+                                                             int32_t* __restrict__ inv) {
+  const int64_t per_b = static_cast<int64_t>(N) * k;
+  const int64_t total = static_cast<int64_t>(B) * per_b;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < total;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int l = static_cast<int>(e % k);
+    const int n = static_cast<int>((e / k) % N);
+    const int b = static_cast<int>(e / per_b);
+    const int j = static_cast<int>(idx[b * ib + n * in_ + l * ik]);
+    inv[b * per_b + ptr[static_cast<int64_t>(b) * (N + 1) + j] + rank[e]] = n * k + l;   // edge id inside the sample
+  }
+}
+
+// One WAVE per neighbour row: LPR lanes x float4 cover the C channels, the G = 64/LPR lane groups walk G edges of
+// the SAME list side by side (kNN in-degrees are heavy-tailed: a hub with hundreds of in-edges must not be summed by
+// one lane group), U loads in flight each, partial sums combined with shuffles.
+template <int LPR>
+__global__ __launch_bounds__(kWgThreads) void inv_gather_kernel(const float* __restrict__ dz,
+                                                               const int32_t* __restrict__ ptr,
+                                                               const int32_t* __restrict__ inv, int B, int N, int C,
+                                                               int k, float* __restrict__ dQ, int64_t ldq) {
+  constexpr int G = kWave / LPR;
+  constexpr int U = 4;
+  const int lane = lane_id();
+  const int g = lane / LPR, cl = lane % LPR;
+  const int64_t total = static_cast<int64_t>(B) * N;
+  const int64_t per_b = static_cast<int64_t>(N) * k;
+  const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
+  for (int cb = 0; cb < C; cb += LPR * 4) {
+    const int c0 = cb + cl * 4;
+    const bool act = c0 < C;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + (threadIdx.x >> 6); t < total; t += wave_stride) {
+      const int b = static_cast<int>(t / N);
+      const int j = static_cast<int>(t % N);
+      const int beg = uni(ptr[static_cast<int64_t>(b) * (N + 1) + j]);
+      const int end = uni(ptr[static_cast<int64_t>(b) * (N + 1) + j + 1]);
+      const float* dzb = dz + b * per_b * C + c0;
+      const int32_t* invb = inv + b * per_b;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int blk = beg; blk < end; blk += kWave) {
+        const int nb = min(kWave, end - blk);
+        const int mye = (lane < nb) ? invb[blk + lane] : 0;      // 64 edge ids with one coalesced load
+        for (int s0 = 0; s0 < nb; s0 += G * U) {
+          float v[U][4];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int ei = s0 + u * G + g;
+            const int e = __shfl(mye, ei & (kWave - 1));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = 0.f;
+            if (ei < nb && act) load_vec<4>(v[u], dzb + static_cast<int64_t>(e) * C);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += v[u][q];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
+      }
+      if (g == 0 && act) store_vec<4>(dQ + (static_cast<int64_t>(b) * N + j) * ldq + c0, acc);
+    }
+  }
+}
+
 int bwd_nsplit(int B, int N, int C) {
   if (static_cast<size_t>(N) * kBwdSlice * 4 > 158u * 1024u) return 0;  // slice does not fit LDS: atomic path
   // one 128 KB workgroup per CU: aim for exactly one round of <= 256 workgroups
@@ -573,3 +700,81 @@ extern "C" int dgcn_dense_edge_reduce_bwd_f32(const float* P, int64_t ldp, const
   launch_edge<true>(E, lpr, edge_grid(static_cast<int64_t>(B) * N, lpr), static_cast<hipStream_t>(stream));
   return launch_status();
 }
+
+namespace {
+struct InvWs {
+  float* dz;
+  int32_t *cnt, *ptr, *rank, *inv;
+  size_t bytes;
+};
+
+InvWs inv_layout(void* base, int64_t B, int64_t N, int64_t C, int64_t k) {
+  auto up = [](size_t v) { return (v + 15u) / 16u * 16u; };
+  InvWs w;
+  size_t off = 0;
+  unsigned char* p = static_cast<unsigned char*>(base);
+  w.dz = reinterpret_cast<float*>(p + off); off += up(static_cast<size_t>(B * N * k * C) * 4u);
+  w.cnt = reinterpret_cast<int32_t*>(p + off); off += up(static_cast<size_t>(B * N) * 4u);
+  w.ptr = reinterpret_cast<int32_t*>(p + off); off += up(static_cast<size_t>(B * (N + 1)) * 4u);
+  w.rank = reinterpret_cast<int32_t*>(p + off); off += up(static_cast<size_t>(B * N * k) * 4u);
+  w.inv = reinterpret_cast<int32_t*>(p + off); off += up(static_cast<size_t>(B * N * k) * 4u);
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dgcn_dense_edge_reduce_bwd_inv_workspace_bytes(int32_t B, int32_t N, int32_t C, int32_t k) {
+  if (B <= 0 || N <= 0 || C <= 0 || k <= 0) return 0;
+  return inv_layout(nullptr, B, N, C, k).bytes;
+}
+
+// Same contract as dgcn_dense_edge_reduce_bwd_f32, with dQ produced through inverse neighbour lists: dP and dQ are
+// fully overwritten (no pre-zeroing), workspace >= dgcn_dense_edge_reduce_bwd_inv_workspace_bytes.
+extern "C" int dgcn_dense_edge_reduce_bwd_inv_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq,
+                                                  const int64_t* idx, int64_t idx_sb, int64_t idx_sn, int64_t idx_sk,
+                                                  int32_t B, int32_t N, int32_t C, int32_t k, int32_t act,
+                                                  float slope, const uint8_t* amax, const uint8_t* amin,
+                                                  const float* gmax, const float* gmin, const float* gsum,
+                                                  const float* gsq, const float* sel_scale, float* dP, float* dQ,
+                                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!Q || !idx || !amax || !gmax || !dQ || !workspace) return DGCN_E_NULL;
+  if (gmin && !amin) return DGCN_E_NULL;
+  if (B < 0 || N <= 0 || C <= 0 || k <= 0 || k > 255) return DGCN_E_SHAPE;
+  if (C % 4 != 0 || ldq < C || ldq % 4 != 0 || (P && (ldp < C || ldp % 4 != 0))) return DGCN_E_SHAPE;
+  if (act < ACT_NONE || act > ACT_LEAKY) return DGCN_E_MODE;
+  if (!al16(Q) || (P && !al16(P)) || !al16(gmax) || (gmin && !al16(gmin)) || (gsum && !al16(gsum)) ||
+      (gsq && !al16(gsq)) || (dP && !al16(dP)) || !al16(dQ) || !al16(workspace) || (sel_scale && !al16(sel_scale)))
+    return DGCN_E_ALIGN;
+  if (workspace_bytes < dgcn_dense_edge_reduce_bwd_inv_workspace_bytes(B, N, C, k)) return DGCN_E_WORKSPACE;
+  if (B == 0) return DGCN_OK;
+  const InvWs W = inv_layout(workspace, B, N, C, k);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(W.cnt, 0, static_cast<size_t>(B) * N * sizeof(int32_t), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  EdgeParams E{};
+  E.P = P; E.Q = Q; E.ldp = ldp; E.ldq = ldq; E.idx = idx; E.ib = idx_sb; E.in_ = idx_sn; E.ik = idx_sk;
+  E.B = B; E.N = N; E.C = C; E.k = k; E.act = act; E.slope = slope;
+  E.amax = const_cast<uint8_t*>(amax); E.amin = const_cast<uint8_t*>(amin);
+  E.gmax = gmax; E.gmin = gmin; E.gsum = gsum; E.gsq = gsq; E.selscale = sel_scale; E.dP = dP; E.dQ = nullptr;
+  E.dz = W.dz; E.inv_cnt = W.cnt; E.inv_rank = W.rank;
+  const int lpr = edge_lpr(C);
+  launch_edge<true>(E, lpr, edge_grid(static_cast<int64_t>(B) * N, lpr), s);
+  const int64_t edges = static_cast<int64_t>(B) * N * k;
+  int64_t eg = (edges + kWgThreads - 1) / kWgThreads;
+  if (eg > 4096) eg = 4096;
+  hipLaunchKernelGGL(inv_scan_kernel, dim3(B), dim3(kBwdLdsThreads), 0, s, W.cnt, N, W.ptr);
+  hipLaunchKernelGGL(inv_fill_kernel, dim3(static_cast<unsigned>(eg)), dim3(kWgThreads), 0, s, idx, idx_sb, idx_sn,
+                     idx_sk, B, N, k, W.ptr, W.rank, W.inv);
+  int64_t gw = (static_cast<int64_t>(B) * N + kWavesPerWg - 1) / kWavesPerWg;   // one wave per neighbour row
+  if (gw > 8192) gw = 8192;
+  const int grid = static_cast<int>(gw);
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL(inv_gather_kernel<4>, dim3(grid), dim3(kWgThreads), 0, s, W.dz, W.ptr, W.inv, B, N, C, k, dQ, ldq); break;
+    case 8: hipLaunchKernelGGL(inv_gather_kernel<8>, dim3(grid), dim3(kWgThreads), 0, s, W.dz, W.ptr, W.inv, B, N, C, k, dQ, ldq); break;
+    case 16: hipLaunchKernelGGL(inv_gather_kernel<16>, dim3(grid), dim3(kWgThreads), 0, s, W.dz, W.ptr, W.inv, B, N, C, k, dQ, ldq); break;
+    case 32: hipLaunchKernelGGL(inv_gather_kernel<32>, dim3(grid), dim3(kWgThreads), 0, s, W.dz, W.ptr, W.inv, B, N, C, k, dQ, ldq); break;
+    default: hipLaunchKernelGGL(inv_gather_kernel<64>, dim3(grid), dim3(kWgThreads), 0, s, W.dz, W.ptr, W.inv, B, N, C, k, dQ, ldq); break;
+  }
+  return launch_status();
+}
+

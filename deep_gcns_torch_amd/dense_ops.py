@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+USE_INVERSE_LISTS = True      # dense edge backward: dQ through inverse neighbour lists (False: LDS-privatised atomics)
 USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fallback inside the library)
 
 
@@ -166,6 +167,21 @@ class _EdgeReduce(torch.autograd.Function):
         gmin_c = gmin.float().contiguous() if (need_min and gmin is not None) else None
         gs = gs1.float().contiguous() if (need_stats and gs1 is not None) else None
         gq = gs2.float().contiguous() if (need_stats and gs2 is not None) else None
+        p_ptr = PQ.data_ptr() if has_p else None
+        q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
+        if USE_INVERSE_LISTS:                           # dQ through inverse neighbour lists (no float atomics)
+            dPQ = torch.empty_like(PQ)
+            ws_bytes = lib.dgcn_dense_edge_reduce_bwd_inv_workspace_bytes(B, N, C, k)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            with _lib.device_ctx(dev):
+                rc = lib.dgcn_dense_edge_reduce_bwd_inv_f32(
+                    p_ptr, W, q_ptr, W, idx.data_ptr(), idx.stride(0), idx.stride(1), idx.stride(2),
+                    B, N, C, k, act, slope, amax.data_ptr(), _lib.ptr(amin if gmin_c is not None else None),
+                    gmax.data_ptr(), _lib.ptr(gmin_c), _lib.ptr(gs), _lib.ptr(gq), None,
+                    dPQ.data_ptr() if has_p else None, dPQ.data_ptr() + (C * 4 if has_p else 0),
+                    ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+            _lib.check(rc, "dgcn_dense_edge_reduce_bwd_inv_f32")
+            return dPQ, None, None, None, None, None, None, None
         nsplit = lib.dgcn_dense_edge_reduce_bwd_nsplit(B, N, C)
         parts = None
         if nsplit > 0:                                  # LDS-accumulated dQ partials, no global atomics
@@ -173,8 +189,6 @@ class _EdgeReduce(torch.autograd.Function):
             dPQ = torch.empty_like(PQ)
         else:
             dPQ = torch.zeros_like(PQ)                  # dQ half is accumulated with global atomics
-        p_ptr = PQ.data_ptr() if has_p else None
-        q_ptr = PQ.data_ptr() + (C * 4 if has_p else 0)
         dp_ptr = dPQ.data_ptr() if has_p else None
         dq_ptr = dPQ.data_ptr() + (C * 4 if has_p else 0)
         with _lib.device_ctx(dev):
@@ -295,10 +309,16 @@ class _EdgeConv2dFused(torch.autograd.Function):
         partial = torch.empty(nparts, 2, Cout, device=dev, dtype=torch.float32) if has_bn else None
         coef = torch.empty(4, Cout, device=dev, dtype=torch.float32) if has_bn else None
         dPQ = torch.empty(B, N, 2 * Cout, device=dev, dtype=torch.float32)
-        nsplit = lib.dgcn_dense_edge_reduce_bwd_nsplit(B, N, Cout)
-        parts = torch.empty(nsplit, B, N, Cout, device=dev, dtype=torch.float32) if nsplit > 0 else None
-        if parts is None:
-            dPQ[..., Cout:].zero_()
+        inv_ws = None
+        nsplit, parts = 0, None
+        if USE_INVERSE_LISTS:
+            inv_bytes = lib.dgcn_dense_edge_reduce_bwd_inv_workspace_bytes(B, N, Cout, k)
+            inv_ws = torch.empty(inv_bytes, device=dev, dtype=torch.uint8)
+        else:
+            nsplit = lib.dgcn_dense_edge_reduce_bwd_nsplit(B, N, Cout)
+            parts = torch.empty(nsplit, B, N, Cout, device=dev, dtype=torch.float32) if nsplit > 0 else None
+            if parts is None:
+                dPQ[..., Cout:].zero_()
         train_stats = bn_mode == BN_TRAIN
         with _lib.device_ctx(dev):
             _lib.check(lib.dgcn_bn_bwd_prep_f32(g3.data_ptr(), g3.stride(0), g3.stride(1), g3.stride(2), vmax.data_ptr(),
@@ -310,12 +330,20 @@ class _EdgeConv2dFused(torch.autograd.Function):
                                                         stream), "dgcn_bn_bwd_finalize_f32")
             gs_ptr = coef[2].data_ptr() if train_stats else None
             gq_ptr = coef[3].data_ptr() if train_stats else None
-            _lib.check(lib.dgcn_dense_edge_reduce_bwd_f32(
-                pq.data_ptr(), 2 * Cout, pq.data_ptr() + 4 * Cout, 2 * Cout, idx.data_ptr(), idx.stride(0),
-                idx.stride(1), idx.stride(2), B, N, Cout, k, act, slope, amax.data_ptr(), _lib.ptr(amin),
-                gsel.data_ptr(), None, gs_ptr, gq_ptr, bnbuf.data_ptr() if has_bn else None,
-                dPQ.data_ptr(), dPQ.data_ptr() + 4 * Cout, _lib.ptr(parts), nsplit, stream),
-                "dgcn_dense_edge_reduce_bwd_f32")
+            if inv_ws is not None:
+                _lib.check(lib.dgcn_dense_edge_reduce_bwd_inv_f32(
+                    pq.data_ptr(), 2 * Cout, pq.data_ptr() + 4 * Cout, 2 * Cout, idx.data_ptr(), idx.stride(0),
+                    idx.stride(1), idx.stride(2), B, N, Cout, k, act, slope, amax.data_ptr(), _lib.ptr(amin),
+                    gsel.data_ptr(), None, gs_ptr, gq_ptr, bnbuf.data_ptr() if has_bn else None,
+                    dPQ.data_ptr(), dPQ.data_ptr() + 4 * Cout, inv_ws.data_ptr(), inv_bytes, stream),
+                    "dgcn_dense_edge_reduce_bwd_inv_f32")
+            else:
+                _lib.check(lib.dgcn_dense_edge_reduce_bwd_f32(
+                    pq.data_ptr(), 2 * Cout, pq.data_ptr() + 4 * Cout, 2 * Cout, idx.data_ptr(), idx.stride(0),
+                    idx.stride(1), idx.stride(2), B, N, Cout, k, act, slope, amax.data_ptr(), _lib.ptr(amin),
+                    gsel.data_ptr(), None, gs_ptr, gq_ptr, bnbuf.data_ptr() if has_bn else None,
+                    dPQ.data_ptr(), dPQ.data_ptr() + 4 * Cout, _lib.ptr(parts), nsplit, stream),
+                    "dgcn_dense_edge_reduce_bwd_f32")
             if parts is not None:
                 _lib.check(lib.dgcn_reduce_parts_f32(parts.data_ptr(), nsplit, B * N, Cout,
                                                      dPQ.data_ptr() + 4 * Cout, 2 * Cout, stream),

@@ -310,6 +310,18 @@ int dgcn_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, do
                              const float* gamma, const float* bnbuf, int32_t training, float* coef,
                              void* stream);
 
+/* The same backward with dQ produced through INVERSE NEIGHBOUR LISTS instead of atomics: the edge kernel writes each
+ * edge's dz row once, a counting sort groups the edge ids by neighbour, a gather kernel sums every neighbour's rows.
+ * dP and dQ are fully overwritten (no pre-zeroing); workspace >= dgcn_dense_edge_reduce_bwd_inv_workspace_bytes
+ * (B*N*k*C floats + ~2*B*N + 2*B*N*k ints).  Sums follow the fill order: reproducible up to fp32 rounding. */
+size_t dgcn_dense_edge_reduce_bwd_inv_workspace_bytes(int32_t B, int32_t N, int32_t C, int32_t k);
+int dgcn_dense_edge_reduce_bwd_inv_f32(const float* P, int64_t ldp, const float* Q, int64_t ldq, const int64_t* idx,
+                                       int64_t idx_sb, int64_t idx_sn, int64_t idx_sk, int32_t B, int32_t N,
+                                       int32_t C, int32_t k, int32_t act, float slope, const uint8_t* amax,
+                                       const uint8_t* amin, const float* gmax, const float* gmin, const float* gsum,
+                                       const float* gsq, const float* sel_scale, float* dP, float* dQ,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* dst[row*ld + c] = sum_s parts[s][row][c]  (fixed order; C % 4 == 0): combines the dq_parts of the
  * atomic-free edge backward into the Q half of the vertex-GEMM gradient. */
 int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int32_t C, float* dst, int64_t ld,
