@@ -15,6 +15,28 @@ from deep_gcns_torch_amd.dist import (HaloGraph, PartitionedGraph, TransposedGra
                                       transposed_gen_aggregate, transposed_supported)
 
 
+def _retry_rendezvous(times=3):
+    """Multi-process tests rendezvous on a freshly picked local port; on a busy host that can lose a race (port
+    taken between probing and binding, slow spawn).  Re-run with a new port before reporting a failure."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*a, **kw):
+            last = None
+            for _ in range(times):
+                try:
+                    return fn(*a, **kw)
+                except Exception as exc:      # noqa: BLE001 -- re-raised below if it persists
+                    last = exc
+                    for child in mp.active_children():      # ranks of the failed attempt must not linger
+                        child.terminate()
+                        child.join(timeout=10)
+            raise last
+        return wrapper
+    return deco
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -54,6 +76,7 @@ def _worker(rank, world, port, aggr, kw, q, chunks=1):
 
 @pytest.mark.parametrize("aggr,kw,chunks", [("softmax", dict(t=0.7), 1), ("power", dict(p=2.0), 1), ("mean", {}, 1),
                                             ("softmax", dict(t=0.7), 4), ("max", {}, 3)])
+@_retry_rendezvous()
 def test_partitioned_aggregate_world2_matches_single_process(aggr, kw, chunks):
     from oracle import sparse_ref
     world = 2
@@ -136,6 +159,7 @@ def _worker_transposed(rank, world, port, aggr, kw, q, chunks, node_groups=1):
 
 @pytest.mark.parametrize("aggr,kw,chunks", [("softmax", dict(t=0.7), 1), ("softmax", dict(t=0.7), 2),
                                             ("power", dict(p=2.0), 2), ("max", {}, 1), ("mean", {}, 2)])
+@_retry_rendezvous()
 def test_channel_transposed_aggregate_world2_matches_single_process(aggr, kw, chunks):
     """all_to_all (rows -> channel block) -> aggregation of ALL edges on 8 of the 16 channels -> all_to_all back;
     uneven row ranges (128 / 129 rows) exercise the padded layout."""
@@ -184,6 +208,7 @@ def test_transposed_graph_padded_ids_round_trip():
 
 @pytest.mark.parametrize("world,node_groups,aggr,kw,chunks", [(4, 2, "softmax", dict(t=0.7), 1), (4, 2, "max", {}, 2),
                                                              (2, 2, "power", dict(p=2.0), 1), (4, 4, "mean", {}, 1)])
+@_retry_rendezvous()
 def test_two_dimensional_transposed_aggregate_matches_single_process(world, node_groups, aggr, kw, chunks):
     """node groups x channel groups: replicated input all-to-all, group-local output all-to-all (uneven splits),
     and in the backward the sum over node groups.  (4,4) and (2,2) degenerate to pure node partitioning."""
@@ -245,6 +270,7 @@ def _worker_halo(rank, world, port, aggr, kw, q):
 
 
 @pytest.mark.parametrize("world,aggr,kw", [(2, "softmax", dict(t=0.7)), (3, "max", {}), (4, "power", dict(p=2.0))])
+@_retry_rendezvous()
 def test_halo_exchange_matches_single_process(world, aggr, kw):
     """Only referenced remote rows travel (uneven all-to-all), gradients of halo rows return to their owners."""
     from oracle import sparse_ref
