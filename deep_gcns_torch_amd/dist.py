@@ -35,6 +35,13 @@ load-balances any degree distribution exactly.  It needs edge-feature-free aggre
 destination rows of node group a only.  Gathered rows stay >= 128 bytes when C/W would fall below 32 channels
 (C = 128 on 8 ranks: 4 channel groups x 2 node groups), at the price of a Wn-fold replicated input exchange and a
 sum over node groups in the backward exchange (both still all-to-all, no reduction collective).
+
+Halo scheme (``HaloGraph``, ``halo_gen_aggregate``): the destination partition of the first scheme, but only the
+remote rows a partition actually references travel (index lists exchanged once at build time, uneven all-to-all per
+layer; gradients of halo rows return the same way and are summed into their owners' rows by a CSR add kernel).
+This is the scheme for graphs with locality; on a uniform random graph it degenerates to the all-gather volume.
+
+``build_partition(..., scheme=...)`` + ``aggregate(x_local, part, ...)`` are the scheme-agnostic entry points.
 """
 from __future__ import annotations
 
