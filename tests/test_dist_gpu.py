@@ -66,6 +66,38 @@ def test_partitioned_aggregate_on_rccl_single_rank():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world,rank,node_groups", [(4, 2, 1), (4, 1, 2), (8, 5, 2), (8, 7, 1)])
+def test_rank_local_rectangular_graphs_of_a_multi_rank_job(world, rank, node_groups):
+    """The local graphs a rank of a W > 1 job hands to the HIP kernels (built without any collective): the
+    destination-partitioned one (n_dst = local rows, n_src = W * max_rows padded) and the transposed one (whole graph or
+    one node group, padded ids).  Forward and backward against the CPU oracle on the same rectangular graph."""
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.dist import PartitionedGraph, TransposedGraph
+    from oracle import sparse_ref
+    dev = torch.device("cuda:0")
+    n, C = 3001, 32
+    ei = synth.powerlaw_graph(n, 20_000, seed=21, exponent=2.2)
+    parts = [PartitionedGraph.from_edge_index(ei.to(dev), n, rank, world),
+             TransposedGraph.from_edge_index(ei.to(dev), n, rank, world, node_groups=node_groups)]
+    for part in parts:
+        g = part.graph
+        gen = torch.Generator().manual_seed(world * 10 + rank)
+        x = torch.randn(g.n_src, C, generator=gen)
+        probe = torch.randn(g.n_dst, C, generator=gen)
+        deg = (g.rowptr[1:] - g.rowptr[:-1]).long().cpu()
+        eic = torch.stack([g.col.long().cpu(), torch.repeat_interleave(torch.arange(g.n_dst), deg)])
+        for aggr, kw in (("softmax_sg", dict(t=0.5)), ("max", {}), ("power", dict(p=2.0))):
+            xr = x.double().requires_grad_(True)
+            ref = sparse_ref.gen_propagate(xr, eic, aggr=aggr, dim_size=g.n_dst, **kw)
+            (ref * probe.double()).sum().backward()
+            xd = x.to(dev).requires_grad_(True)
+            out = ops.gen_aggregate(xd, g, aggr=aggr, **kw)
+            (out * probe.to(dev)).sum().backward()
+            torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-6)
+            gs = max(1.0, float(xr.grad.abs().max()))
+            torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-6 * gs)
+
+
 def test_dense_layer_is_hip_graph_capturable():
     """No hidden host synchronisation or allocation outside torch's allocator: a whole ResDynBlock2d
     forward+backward (kNN, MFMA GEMM, edge kernels, BatchNorm kernels) captures into a HIP graph and replays."""
