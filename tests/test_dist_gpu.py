@@ -98,6 +98,82 @@ def test_rank_local_rectangular_graphs_of_a_multi_rank_job(world, rank, node_gro
             torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-6 * gs)
 
 
+def _hip_local(x_full, graph, aggr="softmax", **kw):
+    """local_aggregate for a gloo (CPU tensor) job whose per-rank compute runs on the GPU's HIP kernels."""
+    from deep_gcns_torch_amd import ops
+    from deep_gcns_torch_amd.graph import Graph
+    dev = torch.device("cuda:0")
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+    gd = Graph(graph.col.long().to(dev), dst.to(dev), n_src=graph.n_src, n_dst=graph.n_dst)
+    return ops.gen_aggregate(x_full.float().to(dev), gd, aggr=aggr, **kw).cpu().to(x_full.dtype)
+
+
+def _worker_hybrid(rank, world, port, q):
+    import torch.distributed as dist
+    from deep_gcns_torch_amd import dist as ddist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, C = 2000, 32
+        ei = synth.powerlaw_graph(n, 15_000, seed=31, exponent=2.2)
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(n, C, generator=g)
+        probe = torch.randn(n, C, generator=g)
+        res = {}
+        for name, build in (("allgather", lambda: ddist.PartitionedGraph.from_edge_index(ei, n, rank, world)),
+                            ("transposed2d", lambda: ddist.TransposedGraph.from_edge_index(ei, n, rank, world, node_groups=2)),
+                            ("halo", lambda: ddist.HaloGraph.from_edge_index(ei, n, rank, world))):
+            part = build()
+            xl = x[part.lo:part.hi].clone().requires_grad_(True)
+            out = ddist.aggregate(xl, part, aggr="softmax_sg", t=0.5, local_aggregate=_hip_local)
+            (out * probe[part.lo:part.hi]).sum().backward()
+            res[name] = (part.lo, out.detach().numpy().copy(), xl.grad.detach().numpy().copy())   # plain arrays: no fd passing
+        q.put((rank, res))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_four_rank_job_with_hip_local_kernels_matches_single_gpu():
+    """End to end with W = 4: four processes exchange over gloo (CPU tensors) while every rank's local aggregation runs
+    on the GPU's HIP kernels (all ranks share cuda:0) -- all-gather (channel-pipelined), 2-D transposed and halo schemes
+    against the single-process HIP result."""
+    import socket
+    import torch.multiprocessing as mp
+    from deep_gcns_torch_amd import ops, synth
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_hybrid, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.terminate()
+    dev = torch.device("cuda:0")
+    n, C = 2000, 32
+    ei = synth.powerlaw_graph(n, 15_000, seed=31, exponent=2.2).to(dev)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, C, generator=g).to(dev).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g).to(dev)
+    ref = ops.gen_aggregate(x, ei, aggr="softmax_sg", t=0.5)
+    (ref * probe).sum().backward()
+    for name in ("allgather", "transposed2d", "halo"):
+        order = sorted(got, key=lambda r: r[1][name][0])
+        out = torch.cat([torch.from_numpy(r[1][name][1]) for r in order])
+        grad = torch.cat([torch.from_numpy(r[1][name][2]) for r in order])
+        torch.testing.assert_close(out, ref.detach().cpu(), rtol=1e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+        gs = float(x.grad.abs().max())
+        torch.testing.assert_close(grad, x.grad.cpu(), rtol=1e-4, atol=1e-5 * gs, msg=lambda m: f"{name}: {m}")
+
+
 def test_dense_layer_is_hip_graph_capturable():
     """No hidden host synchronisation or allocation outside torch's allocator: a whole ResDynBlock2d
     forward+backward (kNN, MFMA GEMM, edge kernels, BatchNorm kernels) captures into a HIP graph and replays."""
