@@ -53,9 +53,11 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   int col0, eid0;
   load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
   for (int base = wave0 * R; base < n_items; base += stride) {
+#ifndef DGCN_NO_PREFETCH_BWD
     int coln, eidn;
     load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
     const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
+#endif
     for (int cb = 0; cb < C; cb += LPR * VEC) {
       const int c0 = cb + cl * VEC;
       const bool act = c0 < C;
@@ -191,10 +193,15 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         }
       }
     }
+#ifndef DGCN_NO_PREFETCH_BWD
     w = wn;
     wn = wnn;
     col0 = coln;
     eid0 = eidn;
+#else
+    w = fetch_work<SW>(P.g, base + stride + sub, n_items);
+    load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+#endif
   }
 
   if constexpr (EA == 2) {

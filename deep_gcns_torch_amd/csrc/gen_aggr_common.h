@@ -2,8 +2,8 @@
 // descriptors, the per-item software pipeline helpers, the fused edge encoder and the host-side layout choices.
 // Everything lives in an anonymous namespace: each translation unit gets its own copy.
 // Tuning-build switches (compile-time, not defined in the shipped build): DGCN_G (edge groups per row), DGCN_FWD_U
-// (load batches in flight), DGCN_FWD_WPE / DGCN_FWD_WAVES_PER_CU (occupancy / grid), DGCN_NO_PREFETCH (item look-ahead
-// off).  The defaults are the measured optimum on the products and arxiv shapes.
+// (load batches in flight), DGCN_FWD_WPE / DGCN_FWD_WAVES_PER_CU (occupancy / grid), DGCN_NO_PREFETCH / DGCN_NO_PREFETCH_BWD (item
+// look-ahead off; measured neutral on the products shape).  The defaults are the measured optimum on the products and arxiv shapes.
 #pragma once
 
 #include <stdlib.h>
