@@ -22,11 +22,20 @@ USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fa
 # ----------------------------------------------------------------------------------------
 # kNN
 # ----------------------------------------------------------------------------------------
+KNN_MAX_POINTS = 4096        # one sample's distance strip lives in LDS (csrc/knn_dense.hip)
+KNN_MAX_NEIGHBOURS = 512     # k * dilation; sem_seg_dense's deepest block needs 16 * 27 = 432
+
+
 def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, ctr_out, exclude_self: bool = False):
     """x3: (B, C, N) fp32 view (any strides)."""
     lib = _lib.load()
     dev = _lib.require_device(x3)
     B, C, N = x3.shape
+    if N > KNN_MAX_POINTS or K > KNN_MAX_NEIGHBOURS or K > N - (1 if exclude_self else 0):
+        raise NotImplementedError(
+            f"dgcn_knn_dense_f32 serves clouds of at most {KNN_MAX_POINTS} points and k*dilation <= "
+            f"{KNN_MAX_NEIGHBOURS} (<= points available); got N={N}, k*dilation={K}. Larger or ragged clouds are "
+            f"not implemented (INTEGRATION.md, 'Limits').")
     ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N) if (N >= 1024 and USE_KNN_FILTER) else 0
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     with _lib.device_ctx(dev):
@@ -49,7 +58,45 @@ def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1, exclude_self: boo
         kout = (K + dilation - 1) // dilation
         ei = torch.empty(2, B, N, kout, dtype=torch.int64, device=x.device)
         _knn_launch(x3, K, dilation, ei[0], ei[1], exclude_self)
+    _CENTRES_OK.add(ei.untyped_storage().data_ptr())     # written by the kernel: edge_index[1][b, n, :] == n
     return ei
+
+
+# ---- centre-id contract of the dense convolutions ------------------------------------------------------------
+# The reference gathers x_i = batched_index_select(x, edge_index[1]) (gcn_lib/dense/torch_vertex.py:17,32); every
+# graph builder of the library writes edge_index[1][b, n, :] = n, which is what the fused kernels assume (row n of
+# the neighbour list belongs to point n).  Edge lists built here are known to satisfy it (their storage is
+# registered, views such as edge_index[..., ::d] share it); a caller-supplied edge_index is verified ONCE per
+# storage (one device reduction + host read) and rejected loudly if its centres differ.
+class _StorageSet:
+    def __init__(self, cap=256):
+        self._d, self._cap = {}, cap
+
+    def add(self, key):
+        if len(self._d) >= self._cap:
+            self._d.pop(next(iter(self._d)))
+        self._d[key] = True
+
+    def __contains__(self, key):
+        return key in self._d
+
+
+_CENTRES_OK = _StorageSet()
+
+
+def check_centres(edge_index: torch.Tensor) -> None:
+    key = edge_index.untyped_storage().data_ptr()
+    if key in _CENTRES_OK:
+        return
+    centre = edge_index[1]
+    n = centre.size(-2)
+    want = torch.arange(n, device=centre.device, dtype=centre.dtype).view(1, n, 1)
+    if not bool((centre == want).all()):
+        raise NotImplementedError(
+            "dense EdgeConv2d / MRConv2d: edge_index[1][b, n, :] must equal n (the centre of neighbour row n is "
+            "point n, as every gcn_lib.dense graph builder produces); general centre ids are not supported by the "
+            "fused kernels")
+    _CENTRES_OK.add(key)
 
 
 def knn_indices(pts: torch.Tensor, k: int, dilation: int = 1, exclude_self: bool = False) -> torch.Tensor:

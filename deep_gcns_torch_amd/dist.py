@@ -99,7 +99,9 @@ class PartitionedGraph:
         owner = torch.bucketize(lsrc, b[1:], right=True)          # rank owning each source node
         padded_src = owner * max_rows + (lsrc - b[owner])
         g = Graph(padded_src, ldst, n_src=world * max_rows, n_dst=hi - lo, need_transpose=need_transpose)
-        return cls(g, list(bounds), rank, world, max_rows, int(mine.sum()))
+        part = cls(g, list(bounds), rank, world, max_rows, int(mine.sum()))
+        part.edge_mask = mine         # rows of a global (E, C) edge_attr that belong to this rank: edge_attr[part.edge_mask]
+        return part
 
 
 def _supports_tensor_collectives(group) -> bool:
@@ -231,6 +233,19 @@ class _PipelinedPartitionedAggregate(torch.autograd.Function):
         return grad, None, None, None, None, None, None
 
 
+def _pipelinable(kw: dict) -> bool:
+    """The channel-pipelined Function differentiates w.r.t. the gathered feature blocks ONLY (its backward calls
+    ``autograd.grad(out, leaf)``), and hands every block the keyword arguments unchanged.  Anything else that
+    needs a gradient (learnable ``t`` / ``p``: 1-element Parameters whose per-rank gradients the caller must
+    SUM-all-reduce like any replicated parameter) or that is per-channel data (``edge_attr`` (E, C), a fused
+    ``edge_encoder``) takes the plain all-gather -> aggregate composition, where autograd sees everything."""
+    if kw.get("learn_t") or kw.get("learn_p"):
+        return False
+    if kw.get("edge_attr") is not None or kw.get("edge_encoder") is not None:
+        return False
+    return not any(isinstance(v, torch.Tensor) and v.requires_grad for v in kw.values())
+
+
 def partitioned_gen_aggregate(x_local: torch.Tensor, part: PartitionedGraph, aggr: str = "softmax", group=None,
                               local_aggregate=None, pipeline_chunks: Optional[int] = None, **kw) -> torch.Tensor:
     """Aggregation of this rank's destination rows; ``x_local`` = this rank's feature rows.
@@ -247,7 +262,8 @@ def partitioned_gen_aggregate(x_local: torch.Tensor, part: PartitionedGraph, agg
         # measured on one MI355X (products shape, C=128): 2 blocks cost +7 % kernel time, 4 blocks +28 % (narrower
         # row gathers); the more ranks, the more the exchange dominates and the more overlap is worth
         pipeline_chunks = 2 if dist.get_world_size(group) <= 2 else 4
-    if pipeline_chunks > 1 and dist.get_world_size(group) > 1 and C >= 8 and C % 4 == 0:
+    if (pipeline_chunks > 1 and dist.get_world_size(group) > 1 and C >= 8 and C % 4 == 0
+            and _pipelinable(kw)):
         return _PipelinedPartitionedAggregate.apply(x_local, part, group, local_aggregate, aggr, kw, pipeline_chunks)
     x_full = all_gather_rows(x_local, part, group)
     return local_aggregate(x_full, part.graph, aggr=aggr, **kw)

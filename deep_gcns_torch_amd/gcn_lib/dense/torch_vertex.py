@@ -40,6 +40,7 @@ class MRConv2d(nn.Module):
     def forward(self, x, edge_index):
         # x_i is constant over the neighbourhood and fl(a - b) is monotone in a:
         # max_j (x_j - x_i) == (max_j x_j) - x_i bit for bit -> one gather-max over point-major rows.
+        dense_ops.check_centres(edge_index)
         rows = x.squeeze(-1).transpose(1, 2).contiguous()                       # (B,N,C)
         vmax, _, _, _ = dense_ops.edge_reduce(rows, edge_index[0], has_p=False)
         rel = _to_bcn1(vmax - rows)
@@ -61,6 +62,7 @@ class EdgeConv2d(nn.Module):
         _act_code(self.nn)
 
     def forward(self, x, edge_index):
+        dense_ops.check_centres(edge_index)
         conv = self.nn[0]
         act, slope = _act_code(self.nn)
         bn = next((m for m in self.nn if isinstance(m, nn.BatchNorm2d)), None)

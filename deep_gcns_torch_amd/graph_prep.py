@@ -63,11 +63,12 @@ def induced_subgraph(edge_index: torch.Tensor, parts: torch.Tensor, cluster: int
 
 def generate_sub_graphs(edge_index: torch.Tensor, parts: torch.Tensor, num_nodes: int, cluster_number: int = 10,
                         batch_size: int = 1) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-    """Device-side equivalent of utils/data_util.generate_sub_graphs: one induced sub-graph per group of
-    ``batch_size`` clusters.  Edge lists are sorted by (row, col) like the scipy CSR -> COO conversion."""
+    """Device-side equivalent of utils/data_util.generate_sub_graphs (reference utils/data_util.py:48-61): batch
+    ``c`` = the sub-graph induced by ``parts == c`` for c in range(cluster_number // batch_size), exactly the
+    reference's selection.  Edge lists are sorted by (row, col) like the scipy CSR -> COO conversion."""
     sg_nodes, sg_edges = [], []
-    for b in range(cluster_number // batch_size):
-        group = (parts >= b * batch_size) & (parts < (b + 1) * batch_size)
+    for c in range(cluster_number // batch_size):
+        group = parts == c
         nodes = torch.nonzero(group).flatten()
         new_id = torch.full((num_nodes,), -1, dtype=edge_index.dtype, device=edge_index.device)
         new_id[nodes] = torch.arange(nodes.numel(), device=edge_index.device, dtype=edge_index.dtype)

@@ -23,8 +23,8 @@ class _BatchNormRows(torch.autograd.Function):
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
-        if x.stride(1) != 1:
-            x = x.contiguous()
+        if x.stride(1) != 1 or x.data_ptr() % 16 != 0 or (x.size(0) > 1 and x.stride(0) % 4 != 0):
+            x = x.contiguous()     # the float4 row layout needs 16-byte aligned rows (a sliced view may not be)
         rows, C = x.shape
         ld = x.stride(0) if rows > 1 else C
         y = torch.empty(rows, C, device=dev, dtype=torch.float32)

@@ -44,6 +44,12 @@ def _rows_f32(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _scalar_f32(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if v is None or (v.dtype == torch.float32 and v.is_contiguous()):
+        return v
+    return v.detach().float().contiguous()
+
+
 _ZEROS = {}
 
 
@@ -62,7 +68,13 @@ class _GenAggregate(torch.autograd.Function):
                 eps: float, t_val: float, p_val: float, learn_t: bool, learn_p: bool, track: bool,
                 add_root: bool = False, enc_feat=None, enc_w=None, enc_b=None):
         lib = _lib.load()
-        dev = _lib.require_device(x, edge_attr)
+        dev = _lib.require_device(x, edge_attr, t_param, p_param, enc_feat, enc_w, enc_b)
+        # the kernels read t / p as fp32 scalars through raw pointers: a model cast with .half() / .bfloat16()
+        # keeps its Parameter dtype, the kernels get an fp32 copy
+        t_dtype = None if t_param is None else t_param.dtype
+        p_dtype = None if p_param is None else p_param.dtype
+        t_param = _scalar_f32(t_param)
+        p_param = _scalar_f32(p_param)
         if dev != graph.device:
             raise RuntimeError("graph and features live on different devices")
         x = _rows_f32(x)
@@ -124,6 +136,7 @@ class _GenAggregate(torch.autograd.Function):
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
             ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
             ctx.learn_t, ctx.learn_p = learn_t, learn_p
+            ctx.t_dtype, ctx.p_dtype = t_dtype, p_dtype
             ctx.add_root = add_root
         return out
 
@@ -153,12 +166,12 @@ class _GenAggregate(torch.autograd.Function):
                 r = q.clamp(POW_LO, POW_HI)
                 inr = ((q >= POW_LO) & (q <= POW_HI)).to(g.dtype)
                 dodp = out * (-torch.log(r) / (p * p) + inr * aux2 / (p * deg1 * r))
-                grad_p = (g * dodp).sum().reshape(p_param.shape)
+                grad_p = (g * dodp).sum().reshape(p_param.shape).to(ctx.p_dtype)
         else:
             gcoef = g
         if mode == _lib.AGGR_SOFTMAX and ctx.learn_t and ctx.needs_input_grad[2]:
             # d L/d t = sum g * (sum_e w m^2 - out^2)      
-            grad_t = (g * (aux2 - out * out)).sum().reshape(t_param.shape)
+            grad_t = (g * (aux2 - out * out)).sum().reshape(t_param.shape).to(ctx.t_dtype)
 
         grad_x = grad_ea = grad_w = grad_b = None
         enc = ctx.enc

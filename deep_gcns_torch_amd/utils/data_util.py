@@ -34,16 +34,22 @@ def random_partition_graph(num_nodes, cluster_number=10):
 
 
 def generate_sub_graphs(adj, parts, cluster_number=10, batch_size=1):
-    """Induced sub-graphs of a scipy CSR adjacency for groups of `batch_size` clusters
-    (utils/data_util.py:48-61): returns (node id lists, COO edge_index tensors)."""
+    """Induced sub-graph of every cluster (utils/data_util.py:48-61): returns (node id arrays, COO edge_index
+    tensors).  ``adj`` is what the reference's callers pass, a ``torch_sparse.SparseTensor`` (anything with
+    ``to_scipy(layout='csr')``), or directly a scipy sparse matrix.  As in the reference, batch ``c`` holds the
+    nodes with ``parts == c`` for c in range(cluster_number // batch_size) -- ``batch_size`` only changes how
+    many batches are produced.  Edge order = scipy's ``tocoo()`` of the sliced CSR (row-major), which is what
+    ``torch_geometric.utils.from_scipy_sparse_matrix`` returns.  For the device-side equivalent on an
+    ``edge_index`` see ``deep_gcns_torch_amd.graph_prep.induced_subgraphs``."""
+    if hasattr(adj, "to_scipy"):
+        adj = adj.to_scipy(layout='csr')
+    else:
+        adj = adj.tocsr()
     num_batches = cluster_number // batch_size
     sg_nodes, sg_edges = [], []
-    for b in range(num_batches):
-        nodes = np.where(parts == batch_size * b)[0]
-        for k in range(1, batch_size):
-            nodes = np.concatenate((nodes, np.where(parts == batch_size * b + k)[0]), axis=0)
-        sub = adj[nodes, :][:, nodes]
-        coo = sub.tocoo()
+    for cluster in range(num_batches):
+        nodes = np.where(parts == cluster)[0]
+        coo = adj[nodes, :][:, nodes].tocoo()
         sg_nodes.append(nodes)
         sg_edges.append(torch.from_numpy(np.vstack((coo.row, coo.col))).long())
     return sg_nodes, sg_edges

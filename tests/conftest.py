@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# Tests that load the reference's example files by path (build container only) must never drop __pycache__ into
+# the read-only reference tree.
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

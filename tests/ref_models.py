@@ -9,6 +9,8 @@ import types
 
 import torch
 
+sys.dont_write_bytecode = True   # the reference tree stays free of __pycache__ (it is read-only input)
+
 REF = "/root/reference"
 
 

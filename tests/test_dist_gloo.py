@@ -50,6 +50,8 @@ def _oracle_local(x_full, graph, aggr="softmax", **kw):
     deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
     dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
     ei = torch.stack([graph.col.long(), dst])
+    if kw.get("edge_attr") is not None and graph.eperm is not None:      # CSR position -> original local edge
+        kw = dict(kw, edge_attr=kw["edge_attr"].index_select(0, graph.eperm.long()))
     return sparse_ref.gen_propagate(x_full, ei, aggr=aggr, dim_size=graph.n_dst, **kw)
 
 
@@ -103,6 +105,75 @@ def test_partitioned_aggregate_world2_matches_single_process(aggr, kw, chunks):
     assert sum(r[4] for r in res) == ei.size(1)
     torch.testing.assert_close(out, ref.detach(), rtol=1e-10, atol=1e-12)
     torch.testing.assert_close(grad, x.grad, rtol=1e-10, atol=1e-12)
+
+
+def _worker_params(rank, world, port, case, q, chunks):
+    """learnable t / edge features through partitioned_gen_aggregate with pipeline_chunks > 1 (the
+    channel-pipelined Function used to drop their gradients; such calls now take the plain composition)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        n, C = 257, 16
+        ei = synth.tricky_graph()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(n, C, generator=g, dtype=torch.float64)
+        probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+        ea = torch.randn(ei.size(1), C, generator=g, dtype=torch.float64)
+        part = PartitionedGraph.from_edge_index(ei, n, rank, world)
+        xl = x[part.lo:part.hi].clone().requires_grad_(case != "t_only")
+        t = torch.tensor([0.7], dtype=torch.float64, requires_grad=True)
+        kw = dict(t=t, learn_t=True)
+        ea_l = None
+        if case == "edge_attr":
+            ea_l = ea[part.edge_mask].clone().requires_grad_(True)
+            kw["edge_attr"] = ea_l
+        out = partitioned_gen_aggregate(xl, part, aggr="softmax", local_aggregate=_oracle_local,
+                                        pipeline_chunks=chunks, **kw)
+        (out * probe[part.lo:part.hi]).sum().backward()
+        gt = t.grad.clone()
+        dist.all_reduce(gt)                     # replicated parameter: per-rank gradients are summed by the caller
+        q.put((rank, out.detach(), None if xl.grad is None else xl.grad.detach(), gt,
+               None if ea_l is None else (part.edge_mask.nonzero().flatten(), ea_l.grad.detach())))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["learn_t", "t_only", "edge_attr"])
+@_retry_rendezvous()
+def test_partitioned_aggregate_keeps_parameter_and_edge_gradients(case):
+    from oracle import sparse_ref
+    world, chunks = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_params, args=(r, world, port, case, q, chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    ea = torch.randn(ei.size(1), C, generator=g, dtype=torch.float64).requires_grad_(True)
+    t = torch.tensor([0.7], dtype=torch.float64, requires_grad=True)
+    ref = sparse_ref.gen_propagate(x, ei, ea if case == "edge_attr" else None, aggr="softmax", t=t, learn_t=True)
+    (ref * probe).sum().backward()
+    torch.testing.assert_close(torch.cat([r[1] for r in res]), ref.detach(), rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(res[0][3], t.grad, rtol=1e-9, atol=1e-12)
+    if case != "t_only":
+        torch.testing.assert_close(torch.cat([r[2] for r in res]), x.grad, rtol=1e-10, atol=1e-12)
+    if case == "edge_attr":
+        gea = torch.zeros_like(ea)
+        for r in res:
+            gea[r[4][0]] = r[4][1]
+        torch.testing.assert_close(gea, ea.grad, rtol=1e-10, atol=1e-12)
 
 
 def test_balanced_bounds_and_padded_remap():

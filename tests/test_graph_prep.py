@@ -36,13 +36,17 @@ def test_induced_subgraphs_match_scipy_slicing():
     ref_nodes, ref_edges = data_util.generate_sub_graphs(adj, parts_np, clusters, batch_size=2)
     nodes, edges = gp.generate_sub_graphs(ei, torch.from_numpy(parts_np), n, clusters, batch_size=2)
     assert len(nodes) == len(ref_nodes) == 3
-    for a, b, ea, eb in zip(nodes, ref_nodes, edges, ref_edges):
-        assert np.array_equal(a.numpy(), np.sort(b))               # scipy keeps np.where order (ascending per cluster)
-        # same node set may be ordered differently by the reference (concatenation of clusters): compare edge sets
-        relabel = {int(v): i for i, v in enumerate(b)}
-        mine = {(int(a[u]), int(a[v])) for u, v in ea.t().tolist()}
-        ref = {(int(b[u]), int(b[v])) for u, v in eb.t().tolist()}
-        assert mine == ref
+    for c, (a, b, ea, eb) in enumerate(zip(nodes, ref_nodes, edges, ref_edges)):
+        assert np.array_equal(b, np.where(parts_np == c)[0])        # the reference's selection: parts == c
+        assert np.array_equal(a.numpy(), b)
+        assert torch.equal(ea, eb)                                  # same relabelling, same (row, col) order
+
+    class _SparseTensorLike:                                        # what the reference's callers pass (torch_sparse)
+        def to_scipy(self, layout="csr"):
+            assert layout == "csr"
+            return adj
+    n2, e2 = data_util.generate_sub_graphs(_SparseTensorLike(), parts_np, clusters, batch_size=1)
+    assert len(n2) == clusters and all(torch.equal(x, y) for x, y in zip(e2[:3], ref_edges))
     nd, sub, attr, eids = gp.induced_subgraph(ei, torch.from_numpy(parts_np), 4, n, edge_attr=torch.arange(ei.size(1)).float())
     assert torch.equal(attr, eids.float()) and bool((sub >= 0).all()) and int(sub.max()) < nd.numel()
     assert torch.equal(nd[sub], ei[:, eids])
