@@ -295,9 +295,66 @@ def full_model_cases():
     return cases
 
 
+def revgcn_cases():
+    """BASELINE config 5 as the reference runs it: the REAL examples/ogb_eff/ogbn_proteins/model_rev.RevGCN on the
+    REAL eff_gcn_modules/rev/{gcn_revop,memgcn,rev_layer}.py and the reference gcn_lib.sparse (third-party
+    primitives from oracle/thirdparty.py).  One model-level Linear(8 -> hidden) edge embedding, repeated per group,
+    every GENConv owning a Linear(hidden -> hidden/group) edge encoder (model_rev.py:45-55,98-107).
+    Recorded: inputs, the shared dropout mask (drawn by the model from the seeded CPU RNG, re-drawn here with the
+    same seed), the output of last_norm (the last deterministic tensor: F.dropout follows) and the gradients of
+    L = sum(last_norm_out * probe) w.r.t. every parameter."""
+    import io
+    import tempfile
+    from contextlib import redirect_stdout
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_models
+    cases = []
+
+    def run(name, graph, n, num_layers, hidden, aggr, seed, **over):
+        with redirect_stdout(io.StringIO()), tempfile.TemporaryDirectory() as tmp:
+            torch.manual_seed(seed)
+            m = ref_models.proteins_revgcn(tmp, num_layers=num_layers, hidden=hidden, aggr=aggr, n_table=n, **over)
+        m.train()
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.rand(n, 8, generator=g)
+        node_index = torch.randperm(n, generator=g)
+        edge_attr = torch.rand(graph.size(1), 8, generator=g)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        keep = {}
+        hook = m.last_norm.register_forward_hook(lambda mod, i, o: keep.__setitem__("hn", o))
+        torch.manual_seed(seed + 2)
+        pred = m(x, node_index, graph, edge_attr)
+        hook.remove()
+        torch.manual_seed(seed + 2)          # first RNG consumer of forward() is the shared mask (model_rev.py:101)
+        mask = torch.zeros(n, hidden).bernoulli_(1 - m.dropout) / (1 - m.dropout)
+        hn = keep["hn"]
+        probe = _probe(hn.shape, 6)
+        (hn * probe).sum().backward()
+        grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        cases.append(dict(name=name, ctor=dict(num_layers=num_layers, hidden=hidden, aggr=aggr, dropout=m.dropout,
+                                               learn_p=m.learn_p, **{k: v for k, v in over.items() if k in ("p", "t", "learn_t")}),
+                          n=n, edge_index=graph, x=x, node_index=node_index, edge_attr=edge_attr, mask=mask,
+                          node_table=m.node_features.clone(), state_dict_before=sd0, probe=probe, hn=hn.detach(),
+                          pred_shape=tuple(pred.shape), grads=grads))
+
+    tricky = synth.tricky_graph()
+    small = synth.tricky_graph(n=64, e=700, hub_deg=300, seed=7)
+    run("revgcn3_h64_max", tricky, 257, 3, 64, "max", 41)
+    run("revgcn3_h64_power", tricky, 257, 3, 64, "power", 42, learn_p=True, p=2.0)
+    run("revgcn1_h224_max", small, 64, 1, 224, "max", 43)                  # RevGNN-Wide width: C = 112 per group
+    run("revgcn2_h224_power", small, 64, 2, 224, "power", 44, learn_p=True)
+    run("revgcn2_h64_softmax", small, 64, 2, 64, "softmax", 45, learn_t=True, t=0.5)
+    return cases
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     dense, sparse = refshim.import_reference()
+    if "--only-rev" in sys.argv:
+        torch.set_num_threads(8)
+        torch.save(revgcn_cases(), os.path.join(GOLD, "revgcn.pt"))
+        print("revgcn.pt", os.path.getsize(os.path.join(GOLD, "revgcn.pt")) // 1024, "KiB")
+        return
     torch.save(model_key_tables(), os.path.join(GOLD, "model_keys.pt"))
     torch.save(full_model_cases(), os.path.join(GOLD, "models.pt"))
     torch.set_num_threads(8)
@@ -307,7 +364,8 @@ def main():
     torch.save(mods, os.path.join(GOLD, "sparse_modules.pt"))
     dn = dense_cases(dense)
     torch.save(dn, os.path.join(GOLD, "dense.pt"))
-    for f in ("sparse_aggregate.pt", "sparse_modules.pt", "dense.pt"):
+    torch.save(revgcn_cases(), os.path.join(GOLD, "revgcn.pt"))
+    for f in ("sparse_aggregate.pt", "sparse_modules.pt", "dense.pt", "revgcn.pt"):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KiB")
 
 

@@ -61,7 +61,7 @@ def ppi_deepgcn(conv="mr", n_blocks=3, **over):
     return arch.DeepGCN(opt)
 
 
-def proteins_revgcn(tmpdir, num_layers=4, hidden=64, aggr="power", **over):
+def proteins_revgcn(tmpdir, num_layers=4, hidden=64, aggr="power", n_table=50, **over):
     # rev_layer.py wraps its imports in one try-block that starts with torch_geometric: give it a stub
     if "torch_geometric" not in sys.modules:
         tgnn = types.ModuleType("torch_geometric.nn")
@@ -73,7 +73,7 @@ def proteins_revgcn(tmpdir, num_layers=4, hidden=64, aggr="power", **over):
     if REF not in sys.path:
         sys.path.append(REF)
     nf = os.path.join(tmpdir, "nf.pt")
-    torch.save(torch.rand(50, 8), nf)
+    torch.save(torch.rand(n_table, 8), nf)
     m = _load(os.path.join(REF, "examples/ogb_eff/ogbn_proteins/model_rev.py"), "ref_proteins_model_rev")
     args = argparse.Namespace(num_layers=num_layers, dropout=0.2, group=2, hidden_channels=hidden, num_tasks=112,
                               gcn_aggr=aggr, t=1.0, learn_t=False, p=1.0, learn_p=True, y=0.0, learn_y=False,

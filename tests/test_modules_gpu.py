@@ -297,7 +297,7 @@ def test_dense_limits_are_reported_not_silently_wrong():
     from deep_gcns_torch_amd import dense_ops
     dev = _dev()
     x = torch.randn(1, 3, 5000, 1, device=dev)
-    with pytest.raises(RuntimeError, match="shape"):
+    with pytest.raises(NotImplementedError, match="at most 4096 points"):
         dense_ops.knn_edge_index(x, 4, 1)                      # N > 4096
-    with pytest.raises(RuntimeError, match="shape"):
+    with pytest.raises(NotImplementedError, match="k\\*dilation <= 512"):
         dense_ops.knn_edge_index(x[:, :, :1024], 600, 1)       # K > 512
