@@ -16,7 +16,7 @@ _LIB_PATH = Path(os.environ.get("DGCN_LIB_PATH") or (Path(__file__).resolve().pa
 # aggregation modes / flags (include/dgcn.h)
 AGGR_ADD, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4
 MSG_IDENTITY, MSG_RELU_EPS = 0, 1
-FLAG_LEARN_T, FLAG_LEARN_P, FLAG_ADD_ROOT, FLAG_SHIFT_FLAG_IS_RANGE = 1, 2, 4, 8
+FLAG_LEARN_T, FLAG_LEARN_P, FLAG_ADD_ROOT, FLAG_SHIFT_FLAG_IS_RANGE, FLAG_EA_IS_Z = 1, 2, 4, 8, 16
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -63,6 +63,12 @@ _SIGNATURES = {
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_gen_aggr_egemm_supported": (C.c_int32, [C.c_int32, C.c_int32]),
+    "dgcn_gen_aggr_egemm_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "dgcn_gen_aggr_egemm_fwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_power_bwd_prep_f32": (C.c_int, [C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                           C.c_int32, C.c_void_p]),
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

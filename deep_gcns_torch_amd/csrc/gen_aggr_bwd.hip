@@ -44,6 +44,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   const float eps = P.eps;
   const int msg = P.msg;
   const bool learn_t = P.learn_t != 0;
+  const bool ea_is_z = (EA == 1) && P.ea_is_z != 0;
 
   // same software pipeline over items as in the forward kernel
   const int stride = total_waves * R;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
       float xs[VEC], acc[VEC], ksh[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; ksh[j] = 0.f; }
-      if (act && w.row >= 0) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
+      if (act && w.row >= 0 && !ea_is_z) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
       if constexpr (MODE == kModeSoftmaxShifted) {
         if (act) load_vec<VEC>(ksh, P.kshift + c0);
       }
@@ -133,7 +134,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-              const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];
+              const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];   // xs == 0 when the edge rows are z itself
               const float m = msg_apply(z, msg, eps);
               const float r = (msg == DGCN_MSG_RELU_EPS) ? (z > 0.f ? 1.f : 0.f) : 1.f;
               float k;
@@ -367,6 +368,9 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                       const float* kshift, const int32_t* shift_ok, const float* groot,
                       float* grad_x, float* grad_edge_attr, void* workspace,
                       size_t workspace_bytes, void* stream) {
+  const bool ea_is_z = (flags & DGCN_FLAG_EA_IS_Z) != 0;
+  if (ea_is_z && (!edge_attr || enc)) return DGCN_E_MODE;
+  if (ea_is_z && !x) { x = edge_attr; x_stride = channels; }    // never read: the rows of edge_attr are z_e itself
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
   if (const int rc = enc_check(enc, channels)) return rc;
   if (enc && !enc_gpart) return DGCN_E_NULL;
@@ -395,6 +399,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                   g->t_work_row, g->t_work_beg, g->t_work_end, g->t_work_slot, g->t_n_split, g->t_split_item};
   P.x = x; P.x_stride = x_stride; P.ea = edge_attr; P.C = channels; P.msg = msg;
   P.learn_t = (flags & DGCN_FLAG_LEARN_T) ? 1 : 0;
+  P.ea_is_z = ea_is_z ? 1 : 0;
   P.t = t; P.p = p; P.eps = eps; P.t_dev = t_dev; P.p_dev = p_dev;
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
   P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr; P.shift_bad = 0;

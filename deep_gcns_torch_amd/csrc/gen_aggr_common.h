@@ -60,6 +60,7 @@ struct BwdParams {
   int C;
   int msg;
   int learn_t;
+  int ea_is_z;      // EA == 1: the edge rows ARE z_e (saved by the fused edge-GEMM forward), x is not added
   float t, p, eps;
   const float* t_dev;
   const float* p_dev;

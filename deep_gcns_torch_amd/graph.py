@@ -128,6 +128,17 @@ class Graph:
         return g
 
     @property
+    def erow(self) -> torch.Tensor:
+        """Destination row of every CSR position (int32 [E]) = the sorted ``edge_index[1]``; built on first use
+        (the fused edge-GEMM kernel cuts its work items by edge count and reads the row of each edge from here)."""
+        t = getattr(self, "_erow", None)
+        if t is None:
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            rows = torch.arange(self.n_dst, device=self.device, dtype=torch.int32)
+            t = self._erow = torch.repeat_interleave(rows, counts).contiguous()
+        return t
+
+    @property
     def c_struct(self):
         return C.byref(self._c)
 

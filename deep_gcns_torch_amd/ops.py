@@ -24,6 +24,8 @@ POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
 ENC_FEATURES = 8                   # raw edge features of the fused edge encoder (kEncF in csrc/gen_aggr_common.h)
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
+FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
+                                   # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
 
 
 def _scalar_arg(v):
@@ -48,6 +50,32 @@ def _scalar_f32(v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if v is None or (v.dtype == torch.float32 and v.is_contiguous()):
         return v
     return v.detach().float().contiguous()
+
+
+def _feat_rows(f: torch.Tensor) -> torch.Tensor:
+    """Edge-feature rows for the fused edge GEMM: fp32, unit column stride, 16-byte aligned rows.  A torch.chunk view
+    of the model-level embedding ((E, hidden) inside (E, hidden * group), model_rev.py:98-99) is consumed in place."""
+    if f.dtype != torch.float32:
+        f = f.float()
+    if f.stride(1) != 1 or f.stride(0) % 4 != 0 or f.data_ptr() % 16 != 0 or f.stride(0) < f.size(1):
+        f = f.contiguous()
+    return f
+
+
+def _splitk_tn(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """g2^T @ x2 for (R, M), (R, K) with R >> M, K as a batched split-K product + fixed-order sum (the un-split
+    GEMM runs on a handful of CUs); row-strided operands are used in place (no (R, K) copy)."""
+    R = g2.size(0)
+    S = 1
+    while S < 128 and R // (S * 2) >= 1024:
+        S *= 2
+    if S == 1:
+        return g2.t() @ x2
+    Rp = (R // S) * S
+    part = torch.bmm(g2[:Rp].unflatten(0, (S, Rp // S)).transpose(1, 2), x2[:Rp].unflatten(0, (S, Rp // S))).sum(0)
+    if Rp != R:
+        part = part + g2[Rp:].t() @ x2[Rp:]
+    return part
 
 
 _ZEROS = {}
@@ -86,15 +114,23 @@ class _GenAggregate(torch.autograd.Function):
             if edge_attr.shape != (graph.n_edges, C):
                 raise ValueError("edge_attr must be (E, C) matching x's channels")
         enc = enc_feat is not None
+        egemm = False
         if enc:
             if edge_attr is not None:
                 raise ValueError("pass either edge_attr (E, C) or the raw features + encoder, not both")
-            enc_feat = enc_feat.float().contiguous()
+            n_feat = enc_feat.size(1)
             enc_w = enc_w.float().contiguous()
             enc_b = None if enc_b is None else enc_b.float().contiguous()
-            if enc_feat.shape != (graph.n_edges, ENC_FEATURES) or enc_w.shape != (C, ENC_FEATURES):
-                raise ValueError("fused edge encoder: features (E, 8), weight (C, 8)")
-        need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[15:17]))
+            if enc_feat.dim() != 2 or enc_feat.size(0) != graph.n_edges or enc_w.shape != (C, n_feat):
+                raise ValueError("fused edge encoder: features (E, F), weight (C, F)")
+            if n_feat == ENC_FEATURES:
+                enc_feat = enc_feat.float().contiguous()
+            elif graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
+                egemm = True
+                enc_feat = _feat_rows(enc_feat)
+            else:
+                raise ValueError(f"fused edge encoder: unsupported shape F={n_feat}, C={C} (see encoder_fusable)")
+        need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[14:17]))
         # (no_grad / inverse passes skip the saved aux)
         out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         aux1 = aux2 = None
@@ -115,8 +151,20 @@ class _GenAggregate(torch.autograd.Function):
             range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+        z_save = None
+        if egemm:
+            if need_grad:
+                z_save = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)   # z_e, original edge order
+            ws_bytes = lib.dgcn_gen_aggr_egemm_fwd_workspace_bytes(graph.n_edges, C)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with _lib.device_ctx(dev):
-            if enc:
+            if egemm:
+                rc = lib.dgcn_gen_aggr_egemm_fwd_f32(
+                    graph.c_struct, graph.erow.data_ptr(), x.data_ptr(), x.stride(0), enc_feat.data_ptr(),
+                    enc_feat.stride(0), enc_w.data_ptr(), _lib.ptr(enc_b), n_feat, C, mode, msg, flags, t_val, p_val,
+                    eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2),
+                    _lib.ptr(range_flag), _lib.ptr(z_save), ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+            elif enc:
                 rc = lib.dgcn_gen_aggr_enc_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
                     ENC_FEATURES, C, mode, msg, flags, t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
@@ -128,11 +176,14 @@ class _GenAggregate(torch.autograd.Function):
                     t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
                     _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
-        _lib.check(rc, "dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32")
+        _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
+                   ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
         if need_grad:
             ctx.range_flag = range_flag
             ctx.enc = (enc_feat, enc_w, enc_b) if enc else None
-            ctx.save_for_backward(x, edge_attr, t_param, p_param, aux1, aux2, out)
+            ctx.egemm = egemm
+            # fused edge GEMM: the backward reads the saved pre-activations z_e instead of x[src] + edge rows
+            ctx.save_for_backward(x, z_save if egemm else edge_attr, t_param, p_param, aux1, aux2, out)
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
             ctx.t_val, ctx.p_val, ctx.flags = t_val, p_val, flags
             ctx.learn_t, ctx.learn_p = learn_t, learn_p
@@ -173,17 +224,20 @@ class _GenAggregate(torch.autograd.Function):
             # d L/d t = sum g * (sum_e w m^2 - out^2)      
             grad_t = (g * (aux2 - out * out)).sum().reshape(t_param.shape).to(ctx.t_dtype)
 
-        grad_x = grad_ea = grad_w = grad_b = None
-        enc = ctx.enc
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (enc is not None and any(ctx.needs_input_grad[15:17])):
+        grad_x = grad_ea = grad_w = grad_b = grad_feat = None
+        egemm = ctx.egemm
+        enc = None if egemm else ctx.enc
+        need_dz = egemm and any(ctx.needs_input_grad[14:17])
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
+                (enc is not None and any(ctx.needs_input_grad[15:17])):
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
-            if edge_attr is not None and ctx.needs_input_grad[1]:
+            if edge_attr is not None and (ctx.needs_input_grad[1] or need_dz):
                 grad_ea = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
             gshift = kshift = shift_ok = None
-            bwd_flags = ctx.flags
+            bwd_flags = ctx.flags | (_lib.FLAG_EA_IS_Z if egemm else 0)
             if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and ctx.range_flag is not None:
                 # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  K_c = 0
                 # is safe whenever every |L_i| < 80, which the FORWARD kernel checked on the fly (range_flag);
@@ -222,9 +276,20 @@ class _GenAggregate(torch.autograd.Function):
                     grad_w = gsum[:, :ENC_FEATURES].contiguous()
                 if b_enc is not None and ctx.needs_input_grad[16]:
                     grad_b = gsum[:, ENC_FEATURES].contiguous()
+            if egemm:
+                # dz = dL/dz_e (E, C), original edge order = the gradient of the never-materialised edge embedding
+                feat, w_enc, b_enc = ctx.enc
+                dz, grad_ea = grad_ea, None
+                if dz is not None:
+                    if ctx.needs_input_grad[14]:
+                        grad_feat = dz @ w_enc
+                    if ctx.needs_input_grad[15]:
+                        grad_w = _splitk_tn(dz, feat)
+                    if b_enc is not None and ctx.needs_input_grad[16]:
+                        grad_b = dz.sum(0)
             if not ctx.needs_input_grad[0]:
                 grad_x = None
-        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 11 + (grad_w, grad_b)
+        return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10 + (grad_feat, grad_w, grad_b)
 
 
 def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
@@ -266,11 +331,20 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
 
 
 def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels (8 raw features, C % 4 == 0, C <= 256)."""
-    C = x.size(-1)
-    return (edge_feat is not None and edge_feat.dim() == 2 and edge_feat.size(1) == ENC_FEATURES and x.dim() == 2
-            and C % 4 == 0 and C <= 256 and tuple(weight.shape) == (C, ENC_FEATURES)
-            and edge_feat.dtype == torch.float32 and not torch.is_autocast_enabled())
+    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels:
+    * 8 raw features per edge (C % 4 == 0, C <= 256): every edge recomputes its row in registers;
+    * wide features, F % 16 == 0, F <= 256, C % 4 == 0, C <= 128 (``Linear(hidden -> C)`` of the reference's
+      ogbn-proteins / ogbg-ppa / RevGCN models): E x F x C GEMM on the fp32 matrix cores inside the aggregation."""
+    if edge_feat is None or edge_feat.dim() != 2 or x.dim() != 2 or not edge_feat.is_floating_point():
+        return False
+    C, F = x.size(-1), edge_feat.size(1)
+    if tuple(weight.shape) != (C, F) or torch.is_autocast_enabled():
+        return False
+    if F == ENC_FEATURES:
+        return C % 4 == 0 and C <= 256 and edge_feat.dtype == torch.float32
+    if not FUSED_EDGE_GEMM or edge_feat.size(0) == 0:
+        return False
+    return bool(_lib.load().dgcn_gen_aggr_egemm_supported(F, C))
 
 
 def selftest(device="cuda:0") -> None:

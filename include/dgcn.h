@@ -51,6 +51,8 @@ extern "C" {
 #define DGCN_FLAG_LEARN_P 2 /* power exponent is differentiated  (torch_message.py:33-34) */
 #define DGCN_FLAG_SHIFT_FLAG_IS_RANGE 8 /* backward: shift_ok points at the forward's range_flag (0 = safe), not at an "ok" flag */
 #define DGCN_FLAG_ADD_ROOT 4 /* forward: out_i += x_i, the h = x + m of GENConv.forward (torch_vertex.py:74) fused in */
+#define DGCN_FLAG_EA_IS_Z 16 /* backward: the rows of edge_attr are the pre-activations z_e themselves (saved by
+                                dgcn_gen_aggr_egemm_fwd_f32), x is not gathered (may be NULL) */
 
 /*
  * Graph structure, built once per distinct edge_index and reused by every layer
@@ -185,6 +187,34 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
                               const float* out, const float* gshift, const float* kshift,
                               const int32_t* shift_ok, const float* groot, float* grad_x,
                               float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE
+ * (E, hidden) edge embedding and every GENConv owns edge_encoder = Linear(edge_feat_dim = hidden -> C)
+ * (gcn_lib/sparse/torch_vertex.py:56-66; examples/ogb_eff/ogbn_proteins/model_rev.py:45-55,98-107;
+ * eff_gcn_modules/rev/rev_layer.py:53-75; examples/ogb/ogbn_proteins/model.py:74-107; ogbg_ppa/model.py:60).
+ * dgcn_gen_aggr_egemm_fwd_f32 runs that E x n_feat x C GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an
+ * exact fp32 fma chain), adds the gathered x[src] and folds the tile straight into the aggregation: the (E, C)
+ * edge embedding of the reference is never written.
+ *   erow        [E] int32: destination row of every CSR position (= sorted edge_index[1])
+ *   edge_feat   [E, n_feat] fp32, ORIGINAL edge order, row stride feat_stride floats (a torch.chunk view of the
+ *               model-level embedding is consumed in place), 16-byte aligned rows
+ *   enc_weight  [channels, n_feat] contiguous (nn.Linear.weight), enc_bias [channels] or NULL
+ *   z_save      [E, channels] or NULL: receives z_e = x[src] + W f_e + b in ORIGINAL edge order; the backward is
+ *               then dgcn_gen_aggr_bwd_f32(edge_attr = z_save, flags | DGCN_FLAG_EA_IS_Z), whose grad_edge_attr is
+ *               dL/dz_e = the gradient of the (never materialised) edge embedding
+ *   workspace   dgcn_gen_aggr_egemm_fwd_workspace_bytes(E, channels) bytes, 16-byte aligned
+ * Supported (dgcn_gen_aggr_egemm_supported): channels % 4 == 0, channels <= 128, n_feat % 16 == 0, n_feat <= 256,
+ * weight tile + two wave tiles within the 160 KiB LDS; E >= 1.  Everything else as dgcn_gen_aggr_fwd_f32.
+ */
+int32_t dgcn_gen_aggr_egemm_supported(int32_t n_feat, int32_t channels);
+size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t channels);
+int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* erow, const float* x, int64_t x_stride,
+                                const float* edge_feat, int64_t feat_stride, const float* enc_weight,
+                                const float* enc_bias, int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                int32_t flags, float t, float p, float eps, const float* t_dev, const float* p_dev,
+                                float* out, void* aux1, float* aux2, int32_t* range_flag, float* z_save,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Per-destination coefficient of the POWER / MEAN backward in one pass (the `gcoef` of dgcn_gen_aggr_bwd_f32):
  *   out[i,c] = grad_out[i,c] * r^(1/p - 1) * [1e-7 <= q <= 10] / max(deg_i, 1),  r = clamp(q, 1e-7, 10)
