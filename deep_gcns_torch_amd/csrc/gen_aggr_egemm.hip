@@ -8,7 +8,8 @@
 // i.e. an E x K x C GEMM (39.7 GFLOP at E = 791 k, K = 224, C = 112) whose (E, C) result is written, re-read by the
 // gather/scatter chain and thrown away.  Here the GEMM tile never leaves the chip:
 //
-//   * a work item = 64 consecutive CSR positions (edges sorted by destination), one wave per item, 16 edges per
+//   * a work item = item_len consecutive CSR positions (edges sorted by destination; one item per wave slot of the
+//     chip, equally long: exact static balance for any degree distribution), one wave per item, 16 edges per
 //     batch.  Lane (m, kb) holds the feature row of edge m as the A operand of v_mfma_f32_16x16x4_f32 (exact fp32,
 //     an fma chain) and streams it 128 bytes (one cache line per edge) at a time; the encoder weight lives in LDS
 //     for the lifetime of the workgroup and is read with conflict-free ds_read_b128 (k indices permuted so that a
@@ -35,7 +36,10 @@ namespace {
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kEgM = 16;        // edges per MFMA batch (M of the 16x16x4 tile)
-constexpr int kEgItem = 64;     // consecutive CSR positions per work item
+constexpr int kEgMinItem = 64;  // a work item = item_len consecutive CSR positions (a multiple of 16, >= 64): the edge
+                                // list is cut into at most one item per wave slot of the chip (256 CUs x 8 waves), all
+                                // items equally long -> static, exact load balance for any degree distribution, and
+                                // only two partial row states per WAVE leave the registers
 constexpr int kEgChunk = 32;    // feature floats per k-chunk = one 128-byte line per edge
 constexpr int kEgWPad = 8;      // LDS row stride of W = Kpad + 8 floats: (stride/4) % 4 == 2 makes the B-operand
                                 // ds_read_b128 of the four fixed lane groups conflict-free
@@ -44,7 +48,7 @@ constexpr int kEgLdsBytes = 160 * 1024;
 constexpr int kEgInfo = 4;      // int32 per item: head_row, tail_row, head_continues, unused
 
 struct EgParams {
-  int n_rows, n_edges, n_items;
+  int n_rows, n_edges, n_items, item_len;
   const int32_t* rowptr;
   const int32_t* col;
   const int32_t* eperm;
@@ -68,6 +72,7 @@ struct EgParams {
   float* z_save;            // [E][C] original edge order, or null
   float* part;              // [n_items][2][4][C]
   int32_t* info;            // [n_items][kEgInfo]
+  int dbg;                  // profiling builds only (DGCN_EG_DEBUG): 1 skip the walk, 2 skip the MFMA chain, 4 skip feature loads
 };
 
 // ---- state -> result ------------------------------------------------------------------------------------------
@@ -197,8 +202,34 @@ __device__ __forceinline__ void eg_empty_rows(const EgParams& P, int r0, int r1,
 template <int MODE, bool RELU, bool WITH_D>
 __device__ __forceinline__ void eg_walk_batch(const EgParams& P, EgWalk& wk, int item, State<4>& st,
                                               const float* __restrict__ zt, int nb, int rowv, int eidv, int cl,
-                                              bool act, float eps, float eps_r, float t2, float c0s, float p) {
+                                              bool act, float eps, float eps_r, float t2, float c0s, float p,
+                                              const f4v& bias4) {
   const int c0 = cl * 4;
+  // Common case (average degree >> 16): the whole batch continues the current row -> two edges per fold, their LDS
+  // rows requested together, no per-edge row bookkeeping.
+  if (nb == kEgM && __builtin_amdgcn_readlane(rowv, 0) == wk.cur_row &&
+      __builtin_amdgcn_readlane(rowv, kEgM - 1) == wk.cur_row) {
+#pragma unroll 2
+    for (int e0 = 0; e0 < kEgM; e0 += 2) {
+      float v[2][4];
+      bool ok[2] = {true, true};
+      int eids[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        eids[u] = __builtin_amdgcn_readlane(eidv, e0 + u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[u][j] = 0.f;
+        if (act) {
+          const f4v zz = *reinterpret_cast<const f4v*>(zt + (e0 + u) * P.ZS + c0) + bias4;
+          v[u][0] = zz.x; v[u][1] = zz.y; v[u][2] = zz.z; v[u][3] = zz.w;
+          if (P.z_save) *reinterpret_cast<f4v*>(P.z_save + static_cast<int64_t>(eids[u]) * P.C + c0) = zz;
+        }
+      }
+      accumulate<MODE, 4, 2, RELU, WITH_D, true>(st, v, ok, eids, eps, t2, c0s, p);
+    }
+    wk.cnt += kEgM;
+    return;
+  }
 #pragma unroll 2
   for (int e = 0; e < kEgM; ++e) {
     if (e < nb) {   // wave-uniform
@@ -217,7 +248,7 @@ __device__ __forceinline__ void eg_walk_batch(const EgParams& P, EgWalk& wk, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[0][j] = 0.f;
       if (act) {
-        const f4v zz = *reinterpret_cast<const f4v*>(zt + e * P.ZS + c0);
+        const f4v zz = *reinterpret_cast<const f4v*>(zt + e * P.ZS + c0) + bias4;
         v[0][0] = zz.x; v[0][1] = zz.y; v[0][2] = zz.z; v[0][3] = zz.w;
         if (P.z_save) {
           *reinterpret_cast<f4v*>(P.z_save + static_cast<int64_t>(eid) * P.C + c0) = zz;
@@ -232,26 +263,27 @@ __device__ __forceinline__ void eg_walk_batch(const EgParams& P, EgWalk& wk, int
 template <int MODE>
 __device__ __forceinline__ void eg_walk_dispatch(const EgParams& P, EgWalk& wk, int item, State<4>& st,
                                                  const float* __restrict__ zt, int nb, int rowv, int eidv, int cl,
-                                                 bool act, float eps, float eps_r, float t2, float c0s, float p) {
+                                                 bool act, float eps, float eps_r, float t2, float c0s, float p,
+                                                 const f4v& bias4) {
   const bool relu = P.msg == DGCN_MSG_RELU_EPS;
   constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
   if constexpr (CAN_D) {
     if (P.with_d) {
-      if (relu) eg_walk_batch<MODE, true, true>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p);
-      else eg_walk_batch<MODE, false, true>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p);
+      if (relu) eg_walk_batch<MODE, true, true>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, bias4);
+      else eg_walk_batch<MODE, false, true>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, bias4);
       return;
     }
   }
-  if (relu) eg_walk_batch<MODE, true, false>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p);
-  else eg_walk_batch<MODE, false, false>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p);
+  if (relu) eg_walk_batch<MODE, true, false>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, bias4);
+  else eg_walk_batch<MODE, false, false>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, bias4);
 }
 
 // End of an item: the row in the registers either ends here (complete, or a head partial that ends) or continues
 // into the next item (tail partial; a row covering the whole item stays a head partial that "continues").
 template <int MODE>
-__device__ __forceinline__ void eg_finish_item(const EgParams& P, EgWalk& wk, int item, int ie, State<4>& st, int c0,
-                                               bool act, float eps_r, float p) {
-  const int next_row = (ie < P.n_edges) ? uni(P.erow[ie]) : P.n_rows;   // n_rows: "no more edges"
+__device__ __forceinline__ void eg_finish_item(const EgParams& P, EgWalk& wk, int item, int ie, int next_row,
+                                               State<4>& st, int c0, bool act, float eps_r, float p) {
+  // next_row = row of CSR position ie, or n_rows when there are no more edges
   const bool continues = next_row == wk.cur_row;
   if (continues && !wk.head) {
     eg_fix_eps<MODE, 4>(st, eps_r, P.with_d != 0);
@@ -307,10 +339,11 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_kernel(const Eg
   float bias[NT];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
+  const f4v kZero4 = {0.f, 0.f, 0.f, 0.f};           // the accumulators of this variant already contain the bias
 
   for (int item = blockIdx.x * nwaves + wave; item < P.n_items; item += gridDim.x * nwaves) {
-    const int ib = item * kEgItem;
-    const int ie = min(ib + kEgItem, E);
+    const int ib = item * P.item_len;
+    const int ie = min(ib + P.item_len, E);
     EgWalk wk;
     wk.head_row = -1; wk.tail_row = -1; wk.head_cont = 0; wk.cnt = 0;
     {
@@ -427,26 +460,27 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_kernel(const Eg
       // ---- fold the tile edge by edge into the state of the current destination row ----
       switch (P.mode) {
         case DGCN_AGGR_ADD:
-          eg_walk_dispatch<DGCN_AGGR_ADD>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p); break;
+          eg_walk_dispatch<DGCN_AGGR_ADD>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, kZero4); break;
         case DGCN_AGGR_MEAN:
-          eg_walk_dispatch<DGCN_AGGR_MEAN>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p); break;
+          eg_walk_dispatch<DGCN_AGGR_MEAN>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, kZero4); break;
         case DGCN_AGGR_MAX:
-          eg_walk_dispatch<DGCN_AGGR_MAX>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p); break;
+          eg_walk_dispatch<DGCN_AGGR_MAX>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, kZero4); break;
         case DGCN_AGGR_SOFTMAX:
-          eg_walk_dispatch<DGCN_AGGR_SOFTMAX>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p); break;
+          eg_walk_dispatch<DGCN_AGGR_SOFTMAX>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, kZero4); break;
         default:
-          eg_walk_dispatch<DGCN_AGGR_POWER>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p); break;
+          eg_walk_dispatch<DGCN_AGGR_POWER>(P, wk, item, st, zt, nb, rowv, eidv, cl, act, eps, eps_r, t2, c0s, p, kZero4); break;
       }
       __builtin_amdgcn_wave_barrier();
       srcv = srcn; eidv = eidn; rowv = rown;
     }
 
+    const int next_row = (ie < E) ? uni(P.erow[ie]) : P.n_rows;
     switch (P.mode) {
-      case DGCN_AGGR_ADD: eg_finish_item<DGCN_AGGR_ADD>(P, wk, item, ie, st, cl * 4, act, eps_r, p); break;
-      case DGCN_AGGR_MEAN: eg_finish_item<DGCN_AGGR_MEAN>(P, wk, item, ie, st, cl * 4, act, eps_r, p); break;
-      case DGCN_AGGR_MAX: eg_finish_item<DGCN_AGGR_MAX>(P, wk, item, ie, st, cl * 4, act, eps_r, p); break;
-      case DGCN_AGGR_SOFTMAX: eg_finish_item<DGCN_AGGR_SOFTMAX>(P, wk, item, ie, st, cl * 4, act, eps_r, p); break;
-      default: eg_finish_item<DGCN_AGGR_POWER>(P, wk, item, ie, st, cl * 4, act, eps_r, p); break;
+      case DGCN_AGGR_ADD: eg_finish_item<DGCN_AGGR_ADD>(P, wk, item, ie, next_row, st, cl * 4, act, eps_r, p); break;
+      case DGCN_AGGR_MEAN: eg_finish_item<DGCN_AGGR_MEAN>(P, wk, item, ie, next_row, st, cl * 4, act, eps_r, p); break;
+      case DGCN_AGGR_MAX: eg_finish_item<DGCN_AGGR_MAX>(P, wk, item, ie, next_row, st, cl * 4, act, eps_r, p); break;
+      case DGCN_AGGR_SOFTMAX: eg_finish_item<DGCN_AGGR_SOFTMAX>(P, wk, item, ie, next_row, st, cl * 4, act, eps_r, p); break;
+      default: eg_finish_item<DGCN_AGGR_POWER>(P, wk, item, ie, next_row, st, cl * 4, act, eps_r, p); break;
     }
     if (lane == 0) {
       int32_t* info = P.info + static_cast<int64_t>(item) * kEgInfo;
@@ -458,8 +492,683 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_kernel(const Eg
   }
 }
 
-// Rows that straddle item boundaries: the item where such a row STARTS (its tail partial) owns the merge; the
-// following items' head partials are folded in item order until one does not continue.  One wave per item.
+// ---- software-pipelined, tile-free variant for compile-time feature widths -----------------------------------------
+// Measured on the kernel above (K = 224, C = 112, E = 791 k; DGCN_EG_DEBUG phase switches): MFMA chain 0.31 ms,
+// tile walk 0.12 ms, feature-load stalls 0.07 ms, and they ADD UP -- two waves per SIMD, s_setprio and staggering
+// change nothing, because v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate on the vector ALU: while one wave
+// streams fp32 MFMAs the other wave's VALU work does not issue.  So every instruction counts:
+//   * the B fragments of the NT channel tiles are read in two groups; a group's reads are issued before the other
+//     group's MFMAs and consumed after them, and inside a group the MFMAs go tile by tile for each k (consecutive
+//     MFMAs never touch the same accumulator): no LDS wait, no dependent-accumulator bubble in the chain;
+//   * the feature row streams through a register ring kEgAhead 16-float halves ahead, across batch boundaries;
+//     the gathered x rows of the next batch are requested into the (just drained) accumulators before the current
+//     tile is folded, the index metadata two batches ahead; item bookkeeping comes from the same metadata loads;
+//   * the tile is folded where it is: in the MFMA D layout lane (n, q) holds z[edge 4 q + j][channel 16 ct + n],
+//     i.e. four CONSECUTIVE edges of NT channels.  A batch that continues the current row (the common case) is
+//     folded four edges at a time per lane, all 64 lanes busy (the LDS-tile walk above uses C/4 of the 64 lanes), the
+//     running state stays split over the four lane groups and is merged with two xor-shuffles only when the row
+//     ends.  No LDS tile, no ds_write / ds_read / barrier per batch, and the LDS holds nothing but the weights.
+constexpr int kEgAhead = 4;
+
+struct EgCoord {
+  int item, b, ie;
+};
+
+struct EgMeta {
+  int src, eid;   // of CSR position b + (lane & 15), clamped to the item: source row, original edge id
+  int row;        // lanes 0..15: destination row of that position; lanes 16..31: row of position b - 1 (the edge
+                  // before the batch); lanes 32..63: row of position ie (the edge after the item)
+};
+constexpr int kEgLanePrev = 16, kEgLaneNext = 32;
+
+__device__ __forceinline__ EgMeta eg_load_meta(const EgParams& P, const EgCoord& c, int lane) {
+  const int pos = min(c.b + (lane & 15), c.ie - 1);
+  EgMeta m;
+  m.src = P.col[pos];
+  m.eid = P.eperm ? P.eperm[pos] : pos;
+  int rpos = pos;
+  if (lane >= kEgLaneNext) rpos = min(c.ie, P.n_edges - 1);
+  else if (lane >= kEgLanePrev) rpos = max(c.b - 1, 0);
+  m.row = P.erow[rpos];
+  return m;
+}
+
+// -- D-layout row output: after the merge every lane holds the full state of channels 16 ct + n; lanes 0..15 write --
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_write_row(const EgParams& P, int row, int n, bool writer, const State<NT>& st,
+                                              float deg, float p) {
+  float res[NT], x1[NT], x2[NT];
+  int xi[NT];
+  bool oor;
+  eg_finalize<MODE, NT>(st, deg, p, res, x1, x2, xi, oor);
+  if (!writer) return;
+  bool flag = false;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int ch = ct * 16 + n;
+    if (ch < P.C) {
+      const int64_t o = static_cast<int64_t>(row) * P.C + ch;
+      float r = res[ct];
+      if (P.add_root) r += P.x[static_cast<int64_t>(row) * P.x_stride + ch];
+      P.out[o] = r;
+      if constexpr (MODE == DGCN_AGGR_MAX) {
+        if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = xi[ct];
+      } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
+        if (P.aux1) static_cast<float*>(P.aux1)[o] = x1[ct];
+        if (P.aux2) P.aux2[o] = x2[ct];
+        if constexpr (MODE == DGCN_AGGR_SOFTMAX) flag = flag || !(fabsf(x1[ct]) < kShiftSafe);
+      }
+    }
+  }
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    if (P.range_flag && flag) atomicOr(P.range_flag, 1);   // rare
+  }
+}
+
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_store_partial(const EgParams& P, int item, int which, int n, bool writer,
+                                                  const State<NT>& st) {
+  if (!writer) return;
+  float* ws = P.part + (static_cast<int64_t>(item) * 2 + which) * 4 * P.C;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int ch = ct * 16 + n;
+    if (ch < P.C) {
+      ws[ch] = st.a[ct];
+      if constexpr (MODE == DGCN_AGGR_MAX) {
+        ws[P.C + ch] = __int_as_float(st.idx[ct]);
+      } else {
+        ws[P.C + ch] = st.b[ct];
+        ws[2 * P.C + ch] = st.c[ct];
+        ws[3 * P.C + ch] = st.d[ct];
+      }
+    }
+  }
+}
+
+// merge the four lane groups' partial states of the current row (every lane ends up with the full state)
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_merge_groups(State<NT>& st) {
+#pragma unroll
+  for (int off = 16; off < kWave; off <<= 1) {
+    const State<NT> o = state_shfl_xor<MODE, NT>(st, off);
+    state_merge<MODE, NT>(st, o);
+  }
+}
+
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_flush(const EgParams& P, EgWalk& wk, int item, State<NT>& st, int n, bool writer,
+                                          float eps_r, float p) {
+  egd_merge_groups<MODE, NT>(st);
+  eg_fix_eps<MODE, NT>(st, eps_r, P.with_d != 0);
+  if (wk.head) {
+    egd_store_partial<MODE, NT>(P, item, 0, n, writer, st);
+    wk.head_row = wk.cur_row;
+    wk.head = 0;
+  } else {
+    egd_write_row<MODE, NT>(P, wk.cur_row, n, writer, st, static_cast<float>(wk.cnt), p);
+  }
+}
+
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_empty_rows(const EgParams& P, int r0, int r1, int n, bool writer, float p) {
+  State<NT> e;
+  state_init<MODE, NT>(e);
+  for (int r = r0; r < r1; ++r) egd_write_row<MODE, NT>(P, r, n, writer, e, 0.f, p);
+}
+
+// Fold one batch held in the D layout (acc[ct][j] = z of edge 4 q + j, channel 16 ct + n) into the running state.
+template <int MODE, int NT, bool WITH_D>
+__device__ __forceinline__ void egd_walk_batch(const EgParams& P, EgWalk& wk, int item, State<NT>& st,
+                                               const f4v (&acc)[NT], int nb, int rowv, int eidv, int n, int q,
+                                               bool writer, float eps, float eps_r, float t2, float c0s, float p) {
+  constexpr bool NEED_EID = MODE == DGCN_AGGR_MAX;
+  int eidq[4] = {0, 0, 0, 0};
+  if (NEED_EID || P.z_save) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) eidq[j] = __shfl(eidv, 4 * q + j);
+  }
+  if (P.z_save) {      // pre-activations for the backward, original edge order (64-byte segments per 16 lanes)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (4 * q + j < nb) {
+        float* zr = P.z_save + static_cast<int64_t>(eidq[j]) * P.C + n;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          if (ct * 16 + n < P.C) zr[ct * 16] = acc[ct][j];
+        }
+      }
+    }
+  }
+  if (nb == kEgM && __builtin_amdgcn_readlane(rowv, 0) == wk.cur_row &&
+      __builtin_amdgcn_readlane(rowv, kEgM - 1) == wk.cur_row) {
+    // the whole batch continues the current row: every lane folds its four edges, two at a time
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      float v[2][NT];
+      const bool ok[2] = {true, true};
+      const int eids[2] = {eidq[2 * h2], eidq[2 * h2 + 1]};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) v[u][ct] = acc[ct][2 * h2 + u];
+      }
+      accumulate<MODE, NT, 2, true, WITH_D, true>(st, v, ok, eids, eps, t2, c0s, p);
+    }
+    wk.cnt += kEgM;
+    return;
+  }
+  // row boundaries inside the batch: edge by edge in CSR order (wave-uniform control), the owning lane group folds
+#pragma unroll
+  for (int e = 0; e < kEgM; ++e) {
+    if (e < nb) {
+      const int row = __builtin_amdgcn_readlane(rowv, e);
+      if (row != wk.cur_row) {
+        egd_flush<MODE, NT>(P, wk, item, st, n, writer, eps_r, p);
+        egd_empty_rows<MODE, NT>(P, wk.cur_row + 1, row, n, writer, p);
+        state_init<MODE, NT>(st);
+        wk.cur_row = row;
+        wk.cnt = 0;
+      }
+      if (q == (e >> 2)) {
+        float v[1][NT];
+        const bool ok[1] = {true};
+        const int eids[1] = {eidq[e & 3]};
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) v[0][ct] = acc[ct][e & 3];
+        accumulate<MODE, NT, 1, true, WITH_D, true>(st, v, ok, eids, eps, t2, c0s, p);
+      }
+      wk.cnt += 1;
+    }
+  }
+}
+
+template <int MODE, int NT>
+__device__ __forceinline__ void egd_finish_item(const EgParams& P, EgWalk& wk, int item, int ie, int next_row,
+                                                State<NT>& st, int n, bool writer, float eps_r, float p) {
+  const bool continues = next_row == wk.cur_row;
+  if (continues && !wk.head) {
+    egd_merge_groups<MODE, NT>(st);
+    eg_fix_eps<MODE, NT>(st, eps_r, P.with_d != 0);
+    egd_store_partial<MODE, NT>(P, item, 1, n, writer, st);
+    wk.tail_row = wk.cur_row;
+  } else {
+    wk.head_cont = (continues && wk.head) ? 1 : 0;
+    egd_flush<MODE, NT>(P, wk, item, st, n, writer, eps_r, p);
+  }
+  if (ie >= P.n_edges) egd_empty_rows<MODE, NT>(P, wk.cur_row + 1, P.n_rows, n, writer, p);
+}
+
+template <int NT, int KC, int MODE>
+__global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_pipe_kernel(const EgParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int H = 2 * KC;                 // 16-float halves of a feature row
+  constexpr int D = kEgAhead < H ? kEgAhead : H;
+  constexpr int G0 = (NT + 1) / 2;          // channel tiles of the first B group
+  constexpr int G1 = NT - G0;
+  const int C = P.C, K = P.K;
+  constexpr int Kpad = KC * kEgChunk;       // == P.Kpad (the launcher picks KC from it)
+  constexpr int WS = Kpad + kEgWPad;        // compile-time stride: LDS offsets become immediates
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  float* Wl = smem;
+  {
+    constexpr int q4 = Kpad / 4;
+    for (int idx = threadIdx.x; idx < NT * 16 * q4; idx += blockDim.x) {
+      const int r = idx / q4, c4 = (idx - r * q4) * 4;
+      f4v v = {0.f, 0.f, 0.f, 0.f};
+      if (r < C && c4 < K) v = *reinterpret_cast<const f4v*>(P.w + static_cast<int64_t>(r) * K + c4);
+      *reinterpret_cast<f4v*>(Wl + r * WS + c4) = v;
+    }
+  }
+  __syncthreads();
+
+  const int n = lane & 15;
+  const int kb = lane >> 4;                 // k slot of the A / B operands = row block q of the D tile
+  const bool writer = lane < 16;
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const float eps_r = eps;                  // this variant serves msg = relu(z) + eps only
+  const float t2 = t * 1.4426950408889634f;
+  const float c0s = t2 * eps_r;
+  const int E = P.n_edges;
+  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
+  const int istride = gridDim.x * nwaves;
+  const bool last_half_ok = (H - 1) * 16 < K;        // K % 32 == 16: the last half-chunk is padding
+
+  float bias[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
+
+  EgCoord cur;
+  cur.item = blockIdx.x * nwaves + wave;
+  if (cur.item >= P.n_items) return;
+  cur.b = cur.item * P.item_len;
+  cur.ie = min(cur.b + P.item_len, E);
+  auto next_coord = [&](const EgCoord& c, bool& valid) {
+    EgCoord x = c;
+    valid = true;
+    if (c.b + kEgM < c.ie) {
+      x.b = c.b + kEgM;
+    } else if (c.item + istride < P.n_items) {
+      x.item = c.item + istride;
+      x.b = x.item * P.item_len;
+      x.ie = min(x.b + P.item_len, E);
+    } else {
+      valid = false;          // x == c: loads issued for it are harmless duplicates
+    }
+    return x;
+  };
+  // x rows of the batch in the D layout (lane (n, q): edges 4 q + j, channels 16 ct + n); requested at the top of the
+  // MFMA chain and added to the tile after it, so their (L2) latency is covered by the chain
+  auto gather_x = [&](f4v (&xg)[NT], int srcv) {
+    int srcj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) srcj[j] = __shfl(srcv, 4 * kb + j);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const int ch = ct * 16 + n;
+      const bool chok = ch < C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xg[ct][j] = chok ? row_ptr(P.x, srcj[j], xs32)[ch] : 0.f;
+    }
+  };
+  auto load_a = [&](const float* arow, int h) -> f4v {
+    if (P.dbg & 4) return f4v{1.f, 1.f, 1.f, 1.f};
+    if (h == H - 1 && !last_half_ok) return f4v{0.f, 0.f, 0.f, 0.f};
+    return *reinterpret_cast<const f4v*>(arow + h * 16);
+  };
+  const float* wl0 = Wl + n * WS + 4 * kb;
+
+  bool vn, vnn;
+  EgCoord nxt = next_coord(cur, vn);
+  EgMeta mc = eg_load_meta(P, cur, lane);
+  EgMeta mn = eg_load_meta(P, nxt, lane);
+  const float* arow_c = P.feat + static_cast<int64_t>(mc.eid) * P.feat_stride + 4 * kb;
+  f4v a[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) a[h] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < D; ++h) a[h] = load_a(arow_c, h);
+  f4v acc[NT];
+  f4v b0[G0], b1[G1 > 0 ? G1 : 1];
+#pragma unroll
+  for (int g = 0; g < G0; ++g) b0[g] = *reinterpret_cast<const f4v*>(wl0 + g * 16 * WS);
+
+  EgWalk wk;
+  State<NT> st;
+  wk.cur_row = -1; wk.cnt = 0; wk.head = 0; wk.head_row = -1; wk.head_cont = 0; wk.tail_row = -1;
+  state_init<MODE, NT>(st);
+
+  while (true) {
+    const EgCoord nn = next_coord(nxt, vnn);
+    const EgMeta mnn = eg_load_meta(P, nn, lane);
+    const float* arow_n = P.feat + static_cast<int64_t>(mn.eid) * P.feat_stride + 4 * kb;
+
+    // ---- tile = bias + F W^T (+ x after the chain) ----
+    f4v xg[NT];
+    gather_x(xg, mc.src);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = f4v{bias[ct], bias[ct], bias[ct], bias[ct]};
+    if (!(P.dbg & 2))
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      // feature halves kEgAhead steps ahead (wrapping into the next batch's rows)
+      if (h + D < H) {
+        a[h + D] = load_a(arow_c, h + D);
+      } else if (H > D) {
+        a[h + D - H] = load_a(arow_n, h + D - H);       // ring slot consumed earlier in this batch
+      }
+      if constexpr (G1 > 0) {
+#pragma unroll
+        for (int g = 0; g < G1; ++g) b1[g] = *reinterpret_cast<const f4v*>(wl0 + (G0 + g) * 16 * WS + h * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const f4v ah = a[h];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g = 0; g < G0; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], b0[g][j], acc[g], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int hn = (h + 1 < H) ? h + 1 : 0;      // the first group of the next half (of the next batch at the end)
+#pragma unroll
+        for (int g = 0; g < G0; ++g) b0[g] = *reinterpret_cast<const f4v*>(wl0 + g * 16 * WS + hn * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (G1 > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int g = 0; g < G1; ++g) {
+            acc[G0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], b1[g][j], acc[G0 + g], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (H <= D) {
+      // short rows: the ring holds a whole row; request the next batch's row now
+#pragma unroll
+      for (int h = 0; h < H; ++h) a[h] = load_a(arow_n, h);
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] += xg[ct];
+
+    // ---- fold the tile (it stays in the accumulators) ----
+    const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
+    const int item = cur.item;
+    if (cur.b == cur.item * P.item_len) {       // first batch of an item: whose row comes in, which rows are empty
+      const int first_row = __builtin_amdgcn_readlane(mc.row, 0);
+      const int prev_row = cur.b > 0 ? __builtin_amdgcn_readlane(mc.row, kEgLanePrev) : -1;
+      wk.head_row = -1; wk.tail_row = -1; wk.head_cont = 0; wk.cnt = 0;
+      wk.head = (prev_row == first_row) ? 1 : 0;
+      wk.cur_row = first_row;
+      state_init<MODE, NT>(st);
+      if (!wk.head) egd_empty_rows<MODE, NT>(P, prev_row + 1, first_row, n, writer, p);
+    }
+    constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
+    if (CAN_D && P.with_d) {
+      egd_walk_batch<MODE, NT, CAN_D>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kb, writer, eps, eps_r, t2, c0s, p);
+    } else {
+      egd_walk_batch<MODE, NT, false>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kb, writer, eps, eps_r, t2, c0s, p);
+    }
+    if (cur.b + kEgM >= cur.ie) {               // last batch of the item
+      const int ie = cur.ie;
+      const int next_row = (ie < E) ? __builtin_amdgcn_readlane(mc.row, kEgLaneNext) : P.n_rows;
+      egd_finish_item<MODE, NT>(P, wk, item, ie, next_row, st, n, writer, eps_r, p);
+      if (lane == 0) {
+        int32_t* info = P.info + static_cast<int64_t>(item) * kEgInfo;
+        info[0] = wk.head_row;
+        info[1] = wk.tail_row;
+        info[2] = wk.head_cont;
+        info[3] = 0;
+      }
+    }
+    if (!vn) break;
+    cur = nxt; mc = mn; nxt = nn; mn = mnn; vn = vnn;
+    arow_c = arow_n;
+  }
+}
+
+// ---- the same kernel with the GEMM on the bf16 matrix cores, fp32-faithful ("bf16x6") ----------------------------
+// fp32 MFMA runs on the vector ALU at the vector rate; v_mfma_f32_16x16x32_bf16 runs on the matrix pipe at 16x that
+// rate and overlaps with VALU work of the other wave.  Every fp32 operand is split EXACTLY into three bf16 values by
+// truncation (hi = top 16 bits, mid = top 16 bits of the remainder, lo = top 16 bits of what is left: 3 x 8 = 24
+// significand bits, f == hi + mid + lo bit for bit) and the product a*b is accumulated in fp32 from the six largest
+// cross terms  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2  (the dropped ones are <= 3 * 2^-24 |a b|, i.e. at the
+// level of fp32 rounding; measured max error / sum|a||b| = 1.7e-7 against 3.3e-7 for a plain fp32 GEMM).
+// 6 MFMAs of 16 cycles replace 8 fp32 MFMAs of 32 cycles per 16x16x32 block: 2.7x less matrix time, and it is
+// hidden time.  The weight matrix is split once per workgroup into three bf16 planes in LDS (161 KB at C = 112,
+// K = 224: possible because the tile-free fold needs no LDS); features are split in registers as they arrive.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+constexpr int kEgAheadB = 2;     // 32-float feature blocks requested ahead of the one being multiplied
+
+__device__ __forceinline__ unsigned eg_pack_hi16(float e0, float e1) {   // (top 16 bits of e0) | (top 16 bits of e1) << 16
+  return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+__device__ __forceinline__ float eg_top16(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
+
+// eight fp32 values -> three bf16x8 MFMA fragments (element e in the low/high half of register e / 2)
+__device__ __forceinline__ void eg_split3(const f4v& f0, const f4v& f1, i4v& h, i4v& m, i4v& l) {
+  const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+  float r[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r[e] = v[e] - eg_top16(v[e]);
+    r2[e] = r[e] - eg_top16(r[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = static_cast<int>(eg_pack_hi16(v[2 * e], v[2 * e + 1]));
+    m[e] = static_cast<int>(eg_pack_hi16(r[2 * e], r[2 * e + 1]));
+    l[e] = static_cast<int>(eg_pack_hi16(r2[2 * e], r2[2 * e + 1]));
+  }
+}
+
+__device__ __forceinline__ f4v eg_mfma_bf16(const i4v& a, const i4v& b, const f4v& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
+template <int NT, int KC, int MODE>
+__global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(const EgParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DB = kEgAheadB < KC ? kEgAheadB : KC;
+  constexpr int SU = 4 * KC + 2;            // row stride of a weight plane in 16-byte units: % 4 == 2, conflict-free
+  constexpr int PLANE = NT * 16 * SU;       // units per plane
+  const int C = P.C, K = P.K;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  i4v* Wp = reinterpret_cast<i4v*>(smem);   // [3][NT*16][SU] units of 8 bf16
+  {
+    // split the weights once: unit (row r, group g8) holds W[r][8 g8 .. 8 g8 + 7]; rows >= C and columns >= K are zero
+    for (int idx = threadIdx.x; idx < NT * 16 * 4 * KC; idx += blockDim.x) {
+      const int r = idx / (4 * KC), g8 = idx - r * (4 * KC);
+      f4v f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+      if (r < C) {
+        const float* wr = P.w + static_cast<int64_t>(r) * K + 8 * g8;
+        if (8 * g8 < K) f0 = *reinterpret_cast<const f4v*>(wr);
+        if (8 * g8 + 4 < K) f1 = *reinterpret_cast<const f4v*>(wr + 4);
+      }
+      i4v h, m, l;
+      eg_split3(f0, f1, h, m, l);
+      Wp[r * SU + g8] = h;
+      Wp[PLANE + r * SU + g8] = m;
+      Wp[2 * PLANE + r * SU + g8] = l;
+    }
+  }
+  __syncthreads();
+
+  const int n = lane & 15;
+  const int kq = lane >> 4;                 // k octet of the A / B fragments = row block q of the D tile
+  const bool writer = lane < 16;
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const float eps_r = eps;
+  const float t2 = t * 1.4426950408889634f;
+  const float c0s = t2 * eps_r;
+  const int E = P.n_edges;
+  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
+  const int istride = gridDim.x * nwaves;
+
+  float bias[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
+
+  if ((wave & 4) == 0) __builtin_amdgcn_s_setprio(1);   // waves w and w + 4 share a SIMD: stagger their phases
+  if ((P.dbg & 16) && (wave & 4)) {
+    for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(127);      // experiment: ~half a batch period
+  }
+  EgCoord cur;
+  cur.item = blockIdx.x * nwaves + wave;
+  if (cur.item >= P.n_items) return;
+  cur.b = cur.item * P.item_len;
+  cur.ie = min(cur.b + P.item_len, E);
+  auto next_coord = [&](const EgCoord& c, bool& valid) {
+    EgCoord x = c;
+    valid = true;
+    if (c.b + kEgM < c.ie) {
+      x.b = c.b + kEgM;
+    } else if (c.item + istride < P.n_items) {
+      x.item = c.item + istride;
+      x.b = x.item * P.item_len;
+      x.ie = min(x.b + P.item_len, E);
+    } else {
+      valid = false;
+    }
+    return x;
+  };
+  // x rows of a batch in the D layout (lane (n, q): edges 4 q + j, channels 16 ct + n), parked in a weight-fragment
+  // buffer that is idle between two MFMA chains: requested before the current tile is folded, they are in registers
+  // when the next chain starts
+  auto gather_x = [&](i4v (&dst)[NT], int srcv) {
+    int srcj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) srcj[j] = __shfl(srcv, 4 * kq + j);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const int ch = ct * 16 + n;
+      const bool chok = ch < C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[ct][j] = chok ? __float_as_int(row_ptr(P.x, srcj[j], xs32)[ch]) : 0;
+    }
+  };
+  // raw feature block s of a row: lane (m = n, kq) owns floats 32 s + 8 kq .. + 7 (two 16-byte loads)
+  auto load_raw = [&](const float* arow, int sblk, f4v& f0, f4v& f1) {
+    f0 = f4v{0.f, 0.f, 0.f, 0.f};
+    f1 = f4v{0.f, 0.f, 0.f, 0.f};
+    if (P.dbg & 4) return;
+    const int o = sblk * kEgChunk + 8 * kq;
+    if (sblk + 1 < KC || o < K) f0 = *reinterpret_cast<const f4v*>(arow + o);        // K % 16 == 0
+    if (sblk + 1 < KC || o + 4 < K) f1 = *reinterpret_cast<const f4v*>(arow + o + 4);
+  };
+  const i4v* wb = Wp + n * SU + kq;          // + plane * PLANE + ct * 16 * SU + 4 * s
+
+  bool vn, vnn;
+  EgCoord nxt = next_coord(cur, vn);
+  EgMeta mc = eg_load_meta(P, cur, lane);
+  EgMeta mn = eg_load_meta(P, nxt, lane);
+  const float* arow_c = P.feat + static_cast<int64_t>(mc.eid) * P.feat_stride;
+  f4v ra[KC][2];
+#pragma unroll
+  for (int sb = 0; sb < KC; ++sb) { ra[sb][0] = f4v{0.f, 0.f, 0.f, 0.f}; ra[sb][1] = f4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int sb = 0; sb < DB; ++sb) load_raw(arow_c, sb, ra[sb][0], ra[sb][1]);
+  f4v acc[NT];
+  i4v bx[2][NT];                              // two weight-plane fragment buffers
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) bx[0][ct] = wb[ct * 16 * SU];       // plane 1 of block 0
+  gather_x(bx[1], mc.src);
+
+  EgWalk wk;
+  State<NT> st;
+  wk.cur_row = -1; wk.cnt = 0; wk.head = 0; wk.head_row = -1; wk.head_cont = 0; wk.tail_row = -1;
+  state_init<MODE, NT>(st);
+
+  while (true) {
+    const EgCoord nn = next_coord(nxt, vnn);
+    const EgMeta mnn = eg_load_meta(P, nn, lane);
+    const float* arow_n = P.feat + static_cast<int64_t>(mn.eid) * P.feat_stride;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ct][j] = __int_as_float(bx[1][ct][j]) + bias[ct];
+    }
+
+    // ---- tile = x + bias + F W^T, six bf16 MFMAs per 16x16x32 block ----
+    if (!(P.dbg & 2))
+#pragma unroll
+    for (int sb = 0; sb < KC; ++sb) {
+      constexpr int X = 0;                     // buffer roles alternate with the block parity
+      const int bi = sb & 1;                   // holds plane 1 of this block
+      const int bo = bi ^ 1;
+      (void)X;
+      if (sb + DB < KC) {
+        load_raw(arow_c, sb + DB, ra[sb + DB][0], ra[sb + DB][1]);
+      } else if (KC > DB) {
+        load_raw(arow_n, sb + DB - KC, ra[sb + DB - KC][0], ra[sb + DB - KC][1]);
+      }
+      i4v a1, a2, a3;
+      eg_split3(ra[sb][0], ra[sb][1], a1, a2, a3);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[PLANE + ct * 16 * SU + 4 * sb];            // plane 2
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bi][ct], acc[ct]);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a3, bx[bi][ct], acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) bx[bi][ct] = wb[2 * PLANE + ct * 16 * SU + 4 * sb];        // plane 3
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bo][ct], acc[ct]);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bo][ct], acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int sn = (sb + 1 < KC) ? sb + 1 : 0;                                              // next plane 1
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[ct * 16 * SU + 4 * sn];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (KC <= DB) {
+#pragma unroll
+      for (int sb = 0; sb < KC; ++sb) load_raw(arow_n, sb, ra[sb][0], ra[sb][1]);
+    }
+    if constexpr (KC % 2 == 1) {
+      // an odd number of blocks leaves the next plane 1 in buffer 1: move it where block 0 expects it
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) bx[0][ct] = bx[1][ct];
+    }
+
+    gather_x(bx[1], mn.src);                    // next batch's x rows; bx[1] is idle until the next chain
+    if (P.dbg & 8) {
+      // experiment: touch the feature lines of the batch after next (one dword per 128-byte line) so that the real
+      // loads find them in L2
+      const float* trow = P.feat + static_cast<int64_t>(mnn.eid) * P.feat_stride + kq * kEgChunk;
+#pragma unroll
+      for (int tb = 0; tb < KC; tb += 4) {
+        if (tb + kq < KC) {
+          float sink;
+          asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(trow + tb * kEgChunk));
+        }
+      }
+    }
+
+    // ---- fold the tile (it stays in the accumulators) ----
+    const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
+    const int item = cur.item;
+    if (cur.b == cur.item * P.item_len) {
+      const int first_row = __builtin_amdgcn_readlane(mc.row, 0);
+      const int prev_row = cur.b > 0 ? __builtin_amdgcn_readlane(mc.row, kEgLanePrev) : -1;
+      wk.head_row = -1; wk.tail_row = -1; wk.head_cont = 0; wk.cnt = 0;
+      wk.head = (prev_row == first_row) ? 1 : 0;
+      wk.cur_row = first_row;
+      state_init<MODE, NT>(st);
+      if (!wk.head) egd_empty_rows<MODE, NT>(P, prev_row + 1, first_row, n, writer, p);
+    }
+    constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
+    if (CAN_D && P.with_d) {
+      egd_walk_batch<MODE, NT, CAN_D>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kq, writer, eps, eps_r, t2, c0s, p);
+    } else {
+      egd_walk_batch<MODE, NT, false>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kq, writer, eps, eps_r, t2, c0s, p);
+    }
+    if (cur.b + kEgM >= cur.ie) {
+      const int ie = cur.ie;
+      const int next_row = (ie < E) ? __builtin_amdgcn_readlane(mc.row, kEgLaneNext) : P.n_rows;
+      egd_finish_item<MODE, NT>(P, wk, item, ie, next_row, st, n, writer, eps_r, p);
+      if (lane == 0) {
+        int32_t* info = P.info + static_cast<int64_t>(item) * kEgInfo;
+        info[0] = wk.head_row;
+        info[1] = wk.tail_row;
+        info[2] = wk.head_cont;
+        info[3] = 0;
+      }
+    }
+    if (!vn) break;
+    cur = nxt; mc = mn; nxt = nn; mn = mnn; vn = vnn;
+    arow_c = arow_n;
+  }
+}
+
+// Rows that straddle item boundaries: the item where such a row STARTS (it holds the row's tail partial) owns the
+// merge, one wave per item.  The row's extent comes from rowptr, so the partials of a long chain (a hub row of
+// 11 k edges spans ~30 items) are independent loads: lanes 0..31 / 32..63 hold the channels as float4 and take the
+// even / odd items of the chain, the two halves are merged at the end -- a fixed order, deterministic.
 template <int MODE>
 __device__ __forceinline__ void eg_fixup_body(const EgParams& P, int item) {
   const int lane = lane_id();
@@ -467,29 +1176,40 @@ __device__ __forceinline__ void eg_fixup_body(const EgParams& P, int item) {
   const int row = uni(P.info[static_cast<int64_t>(item) * kEgInfo + 1]);
   if (row < 0) return;
   const float p = P.p_dev ? *P.p_dev : P.p;
-  const float deg = static_cast<float>(P.rowptr[row + 1] - P.rowptr[row]);
-  for (int c = lane; c < C; c += kWave) {
-    State<1> st;
-    state_init<MODE, 1>(st);
-    int it = item, which = 1;
-    while (true) {
-      const float* ws = P.part + (static_cast<int64_t>(it) * 2 + which) * 4 * C + c;
-      State<1> o;
-      state_init<MODE, 1>(o);
+  const int rb = uni(P.rowptr[row]), re = uni(P.rowptr[row + 1]);
+  const float deg = static_cast<float>(re - rb);
+  const int last = (re - 1) / P.item_len;         // the chain: items item .. last (item == rb / item_len)
+  const int half = lane >> 5;
+  const int c0 = (lane & 31) * 4;
+  const bool act = c0 < C;
+  State<4> st;
+  state_init<MODE, 4>(st);
+  for (int it = item + half; it <= last; it += 2) {
+    const int which = (it == item) ? 1 : 0;       // the first item holds the tail partial, the others head partials
+    State<4> o;
+    state_init<MODE, 4>(o);
+    if (act) {
+      const float* ws = P.part + (static_cast<int64_t>(it) * 2 + which) * 4 * C + c0;
+      load_vec<4>(o.a, ws);
       if constexpr (MODE == DGCN_AGGR_MAX) {
-        o.a[0] = ws[0];
-        o.idx[0] = __float_as_int(ws[C]);
+        float fi[4];
+        load_vec<4>(fi, ws + C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o.idx[q] = __float_as_int(fi[q]);
       } else {
-        o.a[0] = ws[0]; o.b[0] = ws[C]; o.c[0] = ws[2 * C]; o.d[0] = ws[3 * C];
+        load_vec<4>(o.b, ws + C);
+        load_vec<4>(o.c, ws + 2 * C);
+        load_vec<4>(o.d, ws + 3 * C);
       }
-      state_merge<MODE, 1>(st, o);
-      const bool more = (which == 1) || (uni(P.info[static_cast<int64_t>(it) * kEgInfo + 2]) != 0);
-      if (!more) break;
-      ++it;
-      which = 0;
-      if (it >= P.n_items || uni(P.info[static_cast<int64_t>(it) * kEgInfo + 0]) != row) break;
     }
-    eg_write_row<MODE, 1>(P, row, c, st, deg, p);
+    state_merge<MODE, 4>(st, o);
+  }
+  {
+    const State<4> o = state_shfl_xor<MODE, 4>(st, 32);
+    if (half == 0) {
+      state_merge<MODE, 4>(st, o);
+      if (act) eg_write_row<MODE, 4>(P, row, c0, st, deg, p);
+    }
   }
 }
 
@@ -503,6 +1223,18 @@ __global__ __launch_bounds__(kWgThreads) void egemm_fixup_kernel(const EgParams 
     case DGCN_AGGR_SOFTMAX: eg_fixup_body<DGCN_AGGR_SOFTMAX>(P, item); break;
     default: eg_fixup_body<DGCN_AGGR_POWER>(P, item); break;
   }
+}
+
+// item length: one item per wave slot of the chip, a multiple of the 16-edge batch, at least kEgMinItem
+inline int eg_item_len(int n_edges) {
+  const int64_t slots = static_cast<int64_t>(kNumCU) * kEgMaxWaves;
+  int64_t len = (n_edges + slots - 1) / slots;
+  len = (len + kEgM - 1) / kEgM * kEgM;
+  return static_cast<int>(len < kEgMinItem ? kEgMinItem : len);
+}
+inline int eg_num_items(int n_edges) {
+  const int len = eg_item_len(n_edges);
+  return (n_edges + len - 1) / len;
 }
 
 struct EgLayout {
@@ -539,18 +1271,78 @@ int launch_egemm(const EgParams& P, const EgLayout& L, hipStream_t s) {
   return DGCN_OK;
 }
 
-// (channel tiles, feature chunks) of the reference's models get the register-resident feature row; every other
-// supported shape takes the generic kernel.  hidden/group: 224/2, 64/2, 80/2 (RevGNN-Deep), 128/2; ungrouped
+template <int NT, int KC, int MODE>
+int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(NT) * 16 * (KC * kEgChunk + kEgWPad) * sizeof(float);   // weights only
+  const void* fn = reinterpret_cast<const void*>(egemm_fwd_pipe_kernel<NT, KC, MODE>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  int nwaves = kEgMaxWaves;
+  {
+    const char* w = getenv("DGCN_EG_WAVES");
+    if (w && atoi(w) >= 1 && atoi(w) <= kEgMaxWaves) nwaves = atoi(w);
+  }
+  int grid = (P.n_items + nwaves - 1) / nwaves;
+  if (grid > kNumCU) grid = kNumCU;                 // VGPR-bound: one workgroup of 8 waves per CU
+  hipLaunchKernelGGL((egemm_fwd_pipe_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  return DGCN_OK;
+}
+
+template <int NT, int KC, int MODE>
+int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(3) * NT * 16 * (4 * KC + 2) * 16;                  // three bf16 weight planes
+  const void* fn = reinterpret_cast<const void*>(egemm_fwd_bf16_kernel<NT, KC, MODE>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  int nwaves = kEgMaxWaves;
+  {
+    const char* w = getenv("DGCN_EG_WAVES");
+    if (w && atoi(w) >= 1 && atoi(w) <= kEgMaxWaves) nwaves = atoi(w);
+  }
+  int grid = (P.n_items + nwaves - 1) / nwaves;
+  if (grid > kNumCU) grid = kNumCU;
+  hipLaunchKernelGGL((egemm_fwd_bf16_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  return DGCN_OK;
+}
+
+template <int NT, int KC>
+int launch_egemm_bf16(const EgParams& P, hipStream_t s) {
+  switch (P.mode) {
+    case DGCN_AGGR_ADD: return launch_egemm_bf16_mode<NT, KC, DGCN_AGGR_ADD>(P, s);
+    case DGCN_AGGR_MEAN: return launch_egemm_bf16_mode<NT, KC, DGCN_AGGR_MEAN>(P, s);
+    case DGCN_AGGR_MAX: return launch_egemm_bf16_mode<NT, KC, DGCN_AGGR_MAX>(P, s);
+    case DGCN_AGGR_SOFTMAX: return launch_egemm_bf16_mode<NT, KC, DGCN_AGGR_SOFTMAX>(P, s);
+    default: return launch_egemm_bf16_mode<NT, KC, DGCN_AGGR_POWER>(P, s);
+  }
+}
+
+template <int NT, int KC>
+int launch_egemm_pipe(const EgParams& P, hipStream_t s) {
+  switch (P.mode) {
+    case DGCN_AGGR_ADD: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_ADD>(P, s);
+    case DGCN_AGGR_MEAN: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_MEAN>(P, s);
+    case DGCN_AGGR_MAX: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_MAX>(P, s);
+    case DGCN_AGGR_SOFTMAX: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_SOFTMAX>(P, s);
+    default: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_POWER>(P, s);
+  }
+}
+
+// (channel tiles, feature chunks) of the reference's models get the pipelined kernel; every other supported shape
+// (and the identity message) takes the generic one.  hidden/group: 224/2, 64/2, 80/2 (RevGNN-Deep), 128/2; ungrouped
 // hidden 64 and 128 (examples/ogb/ogbn_proteins/model.py, ogbg_ppa/model.py).
 int launch_egemm_any(const EgParams& P, const EgLayout& L, hipStream_t s) {
   const int kc = L.kpad / kEgChunk;
-#define DGCN_EG_CASE(NTV, KCV) if (L.nt == NTV && kc == KCV) return launch_egemm<NTV, KCV>(P, L, s);
+  const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !getenv("DGCN_EG_GENERIC");
+  const bool fp32_mfma = getenv("DGCN_EG_FP32") != nullptr;    // profiling: the fp32-MFMA variant of the same kernel
+#define DGCN_EG_CASE(NTV, KCV)                                                    \
+  if (pipe_ok && L.nt == NTV && kc == KCV) {                                      \
+    return fp32_mfma ? launch_egemm_pipe<NTV, KCV>(P, s) : launch_egemm_bf16<NTV, KCV>(P, s); \
+  }
   DGCN_EG_CASE(7, 7)
   DGCN_EG_CASE(2, 2)
   DGCN_EG_CASE(3, 3)
   DGCN_EG_CASE(4, 4)
   DGCN_EG_CASE(4, 2)
-  DGCN_EG_CASE(8, 4)
 #undef DGCN_EG_CASE
   switch (L.nt) {
     case 1: return launch_egemm<1, 0>(P, L, s);
@@ -576,7 +1368,7 @@ extern "C" int32_t dgcn_gen_aggr_egemm_supported(int32_t n_feat, int32_t channel
 
 extern "C" size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t channels) {
   if (n_edges <= 0 || channels <= 0) return 0;
-  const size_t n_items = (static_cast<size_t>(n_edges) + kEgItem - 1) / kEgItem;
+  const size_t n_items = static_cast<size_t>(eg_num_items(n_edges));
   return n_items * (2u * 4u * static_cast<size_t>(channels) * sizeof(float) + kEgInfo * sizeof(int32_t));
 }
 
@@ -598,6 +1390,7 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
   if (!g->rowptr || !g->col || !erow) return DGCN_E_NULL;
   if (!aligned16(edge_feat) || feat_stride % 4 != 0 || !aligned16(enc_weight) || !aligned16(out) ||
       (aux1 && !aligned16(aux1)) || (aux2 && !aligned16(aux2)) || (z_save && !aligned16(z_save)) ||
+      (enc_bias && !aligned16(enc_bias)) ||
       !aligned16(x) || x_stride % 4 != 0 || !aligned16(workspace)) {
     return DGCN_E_ALIGN;
   }
@@ -606,7 +1399,8 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
   }
   EgParams P;
   P.n_rows = g->n_dst; P.n_edges = g->n_edges;
-  P.n_items = (g->n_edges + kEgItem - 1) / kEgItem;
+  P.item_len = eg_item_len(g->n_edges);
+  P.n_items = eg_num_items(g->n_edges);
   P.rowptr = g->rowptr; P.col = g->col; P.eperm = g->eperm; P.erow = erow;
   P.x = x; P.x_stride = x_stride; P.feat = edge_feat; P.feat_stride = feat_stride;
   P.w = enc_weight; P.b = enc_bias;
@@ -618,6 +1412,10 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
   P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
   P.z_save = z_save;
+  {
+    const char* e = getenv("DGCN_EG_DEBUG");
+    P.dbg = e ? atoi(e) : 0;
+  }
   P.part = static_cast<float*>(workspace);
   P.info = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                       static_cast<size_t>(P.n_items) * 2u * 4u * channels * sizeof(float));
