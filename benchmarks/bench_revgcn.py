@@ -10,8 +10,8 @@ Prints one JSON line per measurement:
   * one GENConv (C = hidden/group, edge_feat_dim = hidden) forward and forward+backward on the strided group view
     of the edge embedding -- the unit the model repeats 2 x layers x (forward + inverse + recompute) times;
   * the whole train step (forward + backward) of an L-layer RevGCN, and the per-layer time it implies.
-The reversible wrapper is the restated one of tests/rev_restated.py (the reference's own files do not travel to
-the GPU box) or, with --product-rev, this package's eff_gcn_modules.rev drop-in when present.
+--rev product (default): this package's eff_gcn_modules.rev drop-in; --rev restated: the reference's reversible
+algorithm restated in tests/rev_restated.py (the reference's own files do not travel to the GPU box).
 """
 import argparse
 import json
@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--fused", type=int, default=1, help="0: stock GEMM + (E,C) edge embedding; 1: fused edge GEMM kernels")
     ap.add_argument("--skip-model", action="store_true")
+    ap.add_argument("--rev", default="product", choices=["product", "restated"],
+                    help="product: this package's eff_gcn_modules.rev (fused reversible step); restated: the reference's "
+                         "algorithm (tests/rev_restated.py: inverse + separate recompute, autograd-summed edge gradients)")
     a = ap.parse_args()
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
@@ -101,7 +104,7 @@ def main():
     import rev_restated
     table = torch.rand(N, 8, device=dev)
     m = rev_restated.RevGCN(num_layers=a.layers, hidden=hidden, aggr=a.aggr, dropout=0.2, node_table=table,
-                            learn_p=(a.aggr == "power")).to(dev).train()
+                            learn_p=(a.aggr == "power"), impl=a.rev).to(dev).train()
     xin = torch.rand(N, 8, device=dev)
     node_index = torch.arange(N, device=dev)
     edge_attr = torch.rand(E, 8, device=dev)
@@ -115,7 +118,7 @@ def main():
         loss.backward()
         opt.step()
     ms = timed(step, a.iters, warmup=2)
-    print(json.dumps(dict(base, what=f"RevGCN-{a.layers} train step (fwd + inverse + recompute + bwd + Adam)",
+    print(json.dumps(dict(base, rev=a.rev, what=f"RevGCN-{a.layers} train step (fwd + inverse + recompute + bwd + Adam)",
                           ms_per_step=ms, ms_per_layer=ms / a.layers, layers=a.layers,
                           peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30,
                           edges_per_s=E * a.layers * group / (ms * 1e-3))), flush=True)

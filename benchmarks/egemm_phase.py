@@ -41,8 +41,7 @@ def timed(iters=20):
 
 for waves in ("8",):
     for dbg, name in ((0, "full"), (1, "no walk"), (2, "no MFMA chain"), (3, "no walk, no MFMA"), (4, "no feature loads"),
-                      (5, "no feature loads, no walk"), (8, "full + L2 touch"), (16, "full + stagger"), (24, "full + touch + stagger"),
-                      (9, "no walk + touch")):
+                      (5, "no feature loads, no walk"), (16, "full + stagger")):
         os.environ["DGCN_EG_DEBUG"] = str(dbg)
         os.environ["DGCN_EG_WAVES"] = waves
         print(json.dumps(dict(waves_per_wg=int(waves), variant=name, ms=round(timed(), 4))), flush=True)

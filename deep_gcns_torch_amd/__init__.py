@@ -19,6 +19,8 @@ _SUBMODULES = (
     "gcn_lib.sparse.torch_message", "gcn_lib.sparse.torch_vertex",
     "gcn_lib.dense", "gcn_lib.dense.torch_nn", "gcn_lib.dense.torch_edge", "gcn_lib.dense.torch_vertex",
     "utils", "utils.pyg_util", "utils.data_util",
+    "eff_gcn_modules", "eff_gcn_modules.rev", "eff_gcn_modules.rev.gcn_revop", "eff_gcn_modules.rev.memgcn",
+    "eff_gcn_modules.rev.rev_layer",
 )
 
 

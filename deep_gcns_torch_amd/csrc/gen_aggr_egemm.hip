@@ -699,6 +699,7 @@ __device__ __forceinline__ void egd_finish_item(const EgParams& P, EgWalk& wk, i
   if (ie >= P.n_edges) egd_empty_rows<MODE, NT>(P, wk.cur_row + 1, P.n_rows, n, writer, p);
 }
 
+#ifdef DGCN_EG_WITH_FP32_PIPE   // tuning builds only: the fp32-MFMA core behind the same fold, for A/B measurements
 template <int NT, int KC, int MODE>
 __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_pipe_kernel(const EgParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -895,6 +896,8 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_pipe_kernel(con
   }
 }
 
+#endif  // DGCN_EG_WITH_FP32_PIPE
+
 // ---- the same kernel with the GEMM on the bf16 matrix cores, fp32-faithful ("bf16x6") ----------------------------
 // fp32 MFMA runs on the vector ALU at the vector rate; v_mfma_f32_16x16x32_bf16 runs on the matrix pipe at 16x that
 // rate and overlaps with VALU work of the other wave.  Every fp32 operand is split EXACTLY into three bf16 values by
@@ -983,9 +986,6 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
   for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
 
   if ((wave & 4) == 0) __builtin_amdgcn_s_setprio(1);   // waves w and w + 4 share a SIMD: stagger their phases
-  if ((P.dbg & 16) && (wave & 4)) {
-    for (int z = 0; z < 40; ++z) __builtin_amdgcn_s_sleep(127);      // experiment: ~half a batch period
-  }
   EgCoord cur;
   cur.item = blockIdx.x * nwaves + wave;
   if (cur.item >= P.n_items) return;
@@ -1116,18 +1116,6 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
     }
 
     gather_x(bx[1], mn.src);                    // next batch's x rows; bx[1] is idle until the next chain
-    if (P.dbg & 8) {
-      // experiment: touch the feature lines of the batch after next (one dword per 128-byte line) so that the real
-      // loads find them in L2
-      const float* trow = P.feat + static_cast<int64_t>(mnn.eid) * P.feat_stride + kq * kEgChunk;
-#pragma unroll
-      for (int tb = 0; tb < KC; tb += 4) {
-        if (tb + kq < KC) {
-          float sink;
-          asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(trow + tb * kEgChunk));
-        }
-      }
-    }
 
     // ---- fold the tile (it stays in the accumulators) ----
     const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
@@ -1271,6 +1259,7 @@ int launch_egemm(const EgParams& P, const EgLayout& L, hipStream_t s) {
   return DGCN_OK;
 }
 
+#ifdef DGCN_EG_WITH_FP32_PIPE
 template <int NT, int KC, int MODE>
 int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
   const size_t lds = static_cast<size_t>(NT) * 16 * (KC * kEgChunk + kEgWPad) * sizeof(float);   // weights only
@@ -1287,6 +1276,8 @@ int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
   hipLaunchKernelGGL((egemm_fwd_pipe_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
   return DGCN_OK;
 }
+
+#endif
 
 template <int NT, int KC, int MODE>
 int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
@@ -1316,6 +1307,7 @@ int launch_egemm_bf16(const EgParams& P, hipStream_t s) {
   }
 }
 
+#ifdef DGCN_EG_WITH_FP32_PIPE
 template <int NT, int KC>
 int launch_egemm_pipe(const EgParams& P, hipStream_t s) {
   switch (P.mode) {
@@ -1327,17 +1319,23 @@ int launch_egemm_pipe(const EgParams& P, hipStream_t s) {
   }
 }
 
+#endif
+
 // (channel tiles, feature chunks) of the reference's models get the pipelined kernel; every other supported shape
 // (and the identity message) takes the generic one.  hidden/group: 224/2, 64/2, 80/2 (RevGNN-Deep), 128/2; ungrouped
 // hidden 64 and 128 (examples/ogb/ogbn_proteins/model.py, ogbg_ppa/model.py).
 int launch_egemm_any(const EgParams& P, const EgLayout& L, hipStream_t s) {
   const int kc = L.kpad / kEgChunk;
   const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !getenv("DGCN_EG_GENERIC");
-  const bool fp32_mfma = getenv("DGCN_EG_FP32") != nullptr;    // profiling: the fp32-MFMA variant of the same kernel
+#ifdef DGCN_EG_WITH_FP32_PIPE
+  const bool fp32_mfma = getenv("DGCN_EG_FP32") != nullptr;    // the fp32-MFMA variant of the same kernel
 #define DGCN_EG_CASE(NTV, KCV)                                                    \
   if (pipe_ok && L.nt == NTV && kc == KCV) {                                      \
     return fp32_mfma ? launch_egemm_pipe<NTV, KCV>(P, s) : launch_egemm_bf16<NTV, KCV>(P, s); \
   }
+#else
+#define DGCN_EG_CASE(NTV, KCV) if (pipe_ok && L.nt == NTV && kc == KCV) return launch_egemm_bf16<NTV, KCV>(P, s);
+#endif
   DGCN_EG_CASE(7, 7)
   DGCN_EG_CASE(2, 2)
   DGCN_EG_CASE(3, 3)

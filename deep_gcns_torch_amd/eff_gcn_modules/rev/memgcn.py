@@ -1,0 +1,112 @@
+"""Group additive coupling: public surface of the reference's eff_gcn_modules/rev/memgcn.py (:8-52), plus the fused
+backward step used by ``gcn_revop.InvertibleCheckpointFunction``.
+
+    forward :  y_0 = x_0 + F_0(x_1 + ... + x_{g-1}),   y_i = x_i + F_i(y_{i-1})
+    inverse :  x_i = y_i - F_i(y_{i-1})  (i = g-1 .. 1),   x_0 = y_0 - F_0(x_1 + ... + x_{g-1})
+"""
+import torch
+
+from .gcn_revop import InvertibleModuleWrapper  # noqa: F401  (model_rev.py reaches it as memgcn.InvertibleModuleWrapper)
+
+__all__ = ["GroupAdditiveCoupling", "InvertibleModuleWrapper"]
+
+
+class GroupAdditiveCoupling(torch.nn.Module):
+    def __init__(self, Fms, split_dim=-1, group=2):
+        super().__init__()
+        self.Fms = Fms
+        self.split_dim = split_dim
+        self.group = group
+
+    def _arg_chunks(self, args):
+        per_arg = [torch.chunk(a, self.group, dim=self.split_dim) for a in args]
+        return list(zip(*per_arg))                      # [group][arg]
+
+    def forward(self, x, edge_index, *args):
+        xs = torch.chunk(x, self.group, dim=self.split_dim)
+        extra = self._arg_chunks(args)
+        y_in = sum(xs[1:])
+        ys = []
+        for i in range(self.group):
+            y_in = xs[i] + self.Fms[i](y_in, edge_index, *extra[i])
+            ys.append(y_in)
+        return torch.cat(ys, dim=self.split_dim)
+
+    def inverse(self, y, edge_index, *args):
+        ys = torch.chunk(y, self.group, dim=self.split_dim)
+        extra = self._arg_chunks(args)
+        xs = [None] * self.group
+        for i in range(self.group - 1, -1, -1):
+            y_in = ys[i - 1] if i != 0 else sum(xs[1:])
+            xs[i] = ys[i] - self.Fms[i](y_in, edge_index, *extra[i])
+        return torch.cat(xs, dim=self.split_dim)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def fused_backward(self, y, grad_y, edge_index, args, weights, arg_sinks, sink_ctx):
+        """Inverse and gradient of one coupling step from ONE grad-enabled evaluation of every F_i.
+
+        ``F_i`` sees the same input in ``inverse`` and in the recompute of ``forward`` (y_{i-1}, or the sum of the
+        other groups for i = 0), so its output is computed once: ``x_i = y_i - F_i(.)`` rebuilds the input and the
+        recorded graph is differentiated with the total gradient that reaches ``y_i``.
+        Returns (x, grad_x, gradients of ``weights`` in order).  Gradients of the extra tensor arguments are ADDED
+        into ``arg_sinks`` (one buffer per floating argument that requires grad, or None when the caller keeps no
+        buffer for it); ``sink_ctx(arg_leaf, buffer_view)`` lets GENConv add its edge-feature gradient in place."""
+        g = self.group
+        dim = self.split_dim
+        ys = torch.chunk(y, g, dim=dim)
+        gys = torch.chunk(grad_y, g, dim=dim)
+        float_args = [a for a in args if isinstance(a, torch.Tensor) and a.requires_grad and a.is_floating_point()]
+        assert len(float_args) == len(arg_sinks)
+        sink_of = {id(a): s for a, s in zip(float_args, arg_sinks)}
+        wpos = {id(w): k for k, w in enumerate(weights)}
+        wgrads = [None] * len(weights)
+        xs = [None] * g
+        gx = [None] * g
+        carry = None                                   # gradient flowing into y_{i-1} from F_i's input
+        for i in range(g - 1, -1, -1):
+            Fm = self.Fms[i]
+            with torch.enable_grad():
+                src = ys[i - 1] if i != 0 else sum(xs[1:])
+                leaf = src.detach().requires_grad_(True)
+                leaves, views = [], []
+                call_args = []
+                for a in args:
+                    if isinstance(a, torch.Tensor):
+                        c = torch.chunk(a.detach(), g, dim=dim)[i]
+                        if id(a) in sink_of:
+                            c.requires_grad_(True)
+                            leaves.append(c)
+                            s = sink_of[id(a)]
+                            views.append(None if s is None else torch.chunk(s, g, dim=dim)[i])
+                        call_args.append(c)
+                    else:
+                        call_args.append(a)
+                ctxs = [sink_ctx(c, v) for c, v in zip(leaves, views) if v is not None]
+                for cm in ctxs:
+                    cm.__enter__()
+                try:
+                    out = Fm(leaf, edge_index, *call_args)
+                    xs[i] = ys[i] - out.detach()
+                    total = gys[i] if carry is None else gys[i] + carry
+                    gx[i] = total
+                    params = [p for p in Fm.parameters() if p.requires_grad]
+                    grads = torch.autograd.grad(out, [leaf] + leaves + params, total, allow_unused=True)
+                finally:
+                    for cm in reversed(ctxs):
+                        cm.__exit__(None, None, None)
+            carry = grads[0]
+            for c, v, gr in zip(leaves, views, grads[1:1 + len(leaves)]):
+                if gr is not None and v is not None:
+                    v.add_(gr)                         # anything that did not go through the in-place sink
+            for p, gr in zip(params, grads[1 + len(leaves):]):
+                k = wpos.get(id(p))
+                if k is not None and gr is not None:
+                    wgrads[k] = gr if wgrads[k] is None else wgrads[k] + gr
+        # the gradient into F_0's input (the sum of the other groups) goes to every x_i, i >= 1
+        if carry is not None:
+            for i in range(1, g):
+                gx[i] = gx[i] + carry
+        x = torch.cat(xs, dim=dim)
+        grad_x = torch.cat(gx, dim=dim)
+        wgrads = [torch.zeros_like(w) if gr is None else gr for w, gr in zip(weights, wgrads)]
+        return x, grad_x, wgrads

@@ -78,6 +78,37 @@ def _splitk_tn(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return part
 
 
+# ---- in-place accumulation of edge-feature gradients ------------------------------------------------------------------
+# The reference's deep models hand ONE (E, hidden) edge embedding to every layer (ogbn_proteins/model.py:116-127,
+# ogb_eff/ogbn_proteins/model_rev.py:98-107); autograd then materialises an (E, hidden) gradient per layer and adds
+# them up.  A caller that owns a running sum can register it for the duration of a backward step: the fused edge-GEMM
+# backward then ADDS its ``dz @ W`` into the registered buffer (one GEMM with beta = 1) and reports no gradient.
+_EDGE_GRAD_SINKS = {}
+
+
+def _sink_key(t: torch.Tensor):
+    return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
+
+
+class edge_grad_sink:
+    """``with edge_grad_sink(feat, buffer): ...``: while active, gradients of ``feat`` (an (E, F) edge-feature tensor,
+    identified by storage pointer + geometry) produced by the fused edge-GEMM backward are accumulated into ``buffer``
+    (same shape, fp32) instead of being returned to autograd."""
+
+    def __init__(self, feat: torch.Tensor, buffer: torch.Tensor):
+        if buffer.shape != feat.shape or buffer.dtype != torch.float32:
+            raise ValueError("edge_grad_sink: buffer must be fp32 with the shape of the feature tensor")
+        self._key, self._buf = _sink_key(feat), buffer
+
+    def __enter__(self):
+        _EDGE_GRAD_SINKS[self._key] = self._buf
+        return self
+
+    def __exit__(self, *exc):
+        _EDGE_GRAD_SINKS.pop(self._key, None)
+        return False
+
+
 _ZEROS = {}
 
 
@@ -282,7 +313,11 @@ class _GenAggregate(torch.autograd.Function):
                 dz, grad_ea = grad_ea, None
                 if dz is not None:
                     if ctx.needs_input_grad[14]:
-                        grad_feat = dz @ w_enc
+                        sink = _EDGE_GRAD_SINKS.get(_sink_key(feat)) if _EDGE_GRAD_SINKS else None
+                        if sink is not None:
+                            torch.addmm(sink, dz, w_enc, out=sink)       # running sum owned by the caller
+                        else:
+                            grad_feat = dz @ w_enc
                     if ctx.needs_input_grad[15]:
                         grad_w = _splitk_tn(dz, feat)
                     if b_enc is not None and ctx.needs_input_grad[16]:

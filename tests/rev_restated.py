@@ -129,19 +129,27 @@ class GENBlock(nn.Module):
 class RevGCN(nn.Module):
     def __init__(self, num_layers=3, hidden=64, group=2, num_tasks=112, aggr="max", dropout=0.2, t=1.0, learn_t=False,
                  p=1.0, learn_p=False, norm="layer", mlp_layers=2, conv_encode_edge=True, node_table=None,
-                 use_one_hot_encoding=True):
+                 use_one_hot_encoding=True, impl="restated"):
+        """impl='restated': the wrapper / coupling / block classes of this file (the reference's algorithm);
+        impl='product': the package's own eff_gcn_modules.rev drop-ins (fused inverse + recompute, in-place
+        accumulation of the shared edge-embedding gradient), as model_rev.py would import them after install()."""
         super().__init__()
         from gcn_lib.sparse.torch_nn import norm_layer
+        if impl == "product":
+            from eff_gcn_modules.rev import memgcn as _mem, rev_layer as _rl
+            _Block, _Coupling, _Wrapper = _rl.GENBlock, _mem.GroupAdditiveCoupling, _mem.InvertibleModuleWrapper
+        else:
+            _Block, _Coupling, _Wrapper = GENBlock, GroupAdditiveCoupling, InvertibleModuleWrapper
         self.num_layers, self.dropout, self.group = num_layers, dropout, group
         self.use_one_hot_encoding = use_one_hot_encoding
         self.gcns = nn.ModuleList()
         self.last_norm = norm_layer(norm, hidden)
         for _ in range(num_layers):
-            fm = GENBlock(hidden // group, hidden // group, norm=norm, aggr=aggr, t=t, learn_t=learn_t, p=p,
-                          learn_p=learn_p, y=0.0, learn_y=False, msg_norm=False, learn_msg_scale=False,
-                          encode_edge=conv_encode_edge, edge_feat_dim=hidden, mlp_layers=mlp_layers)
+            fm = _Block(hidden // group, hidden // group, norm=norm, aggr=aggr, t=t, learn_t=learn_t, p=p,
+                        learn_p=learn_p, y=0.0, learn_y=False, msg_norm=False, learn_msg_scale=False,
+                        encode_edge=conv_encode_edge, edge_feat_dim=hidden, mlp_layers=mlp_layers)
             Fms = nn.ModuleList([fm] + [copy.deepcopy(fm) for _ in range(group - 1)])
-            self.gcns.append(InvertibleModuleWrapper(GroupAdditiveCoupling(Fms, group=group)))
+            self.gcns.append(_Wrapper(_Coupling(Fms, group=group), keep_input=False))
         self.node_features = node_table                      # a plain attribute in the reference (not a buffer)
         if use_one_hot_encoding:
             self.node_one_hot_encoder = nn.Linear(8, 8)

@@ -33,18 +33,18 @@ def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_r
     return x + m if add_root else m
 
 
-def _build(case, dev):
+def _build(case, dev, impl="restated"):
     c = case["ctor"]
     m = rev_restated.RevGCN(num_layers=c["num_layers"], hidden=c["hidden"], aggr=c["aggr"], dropout=c["dropout"],
                             learn_p=c.get("learn_p", False), p=c.get("p", 1.0), t=c.get("t", 1.0),
-                            learn_t=c.get("learn_t", False), node_table=case["node_table"].to(dev))
+                            learn_t=c.get("learn_t", False), node_table=case["node_table"].to(dev), impl=impl)
     assert list(m.state_dict().keys()) == list(case["state_dict_before"].keys())
     m.load_state_dict(case["state_dict_before"])
     return m.to(dev).train()
 
 
-def _run(case, dev):
-    m = _build(case, dev)
+def _run(case, dev, impl="restated"):
+    m = _build(case, dev, impl)
     pred, hn = m(case["x"].to(dev), case["node_index"].to(dev), case["edge_index"].to(dev),
                  case["edge_attr"].to(dev), mask=case["mask"].to(dev))
     assert tuple(pred.shape) == case["pred_shape"]
@@ -61,27 +61,32 @@ def _check(case, hn, grads, rtol, gtol):
         assert err < gtol, f"{k}: max error {err:.3e} of the gradient scale"
 
 
+@pytest.mark.parametrize("impl", ["restated", "product"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
-def test_restated_reversible_wrapper_matches_reference_on_cpu(case):
+def test_restated_reversible_wrapper_matches_reference_on_cpu(case, impl):
+    """impl='product': the package's eff_gcn_modules.rev (one grad-enabled evaluation per coupling function, shared
+    edge-embedding gradient accumulated across layers) must give the reference's values as well."""
     _install()
     from gcn_lib.sparse import torch_message
     saved = torch_message.GenMessagePassing.propagate
     torch_message.GenMessagePassing.propagate = _oracle_propagate
     try:
-        hn, grads = _run(case, torch.device("cpu"))
+        hn, grads = _run(case, torch.device("cpu"), impl)
     finally:
         torch_message.GenMessagePassing.propagate = saved
     _check(case, hn, grads, 1e-4, 2e-4)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["restated", "product"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
-def test_revgcn_reference_pattern_on_hip_kernels(case):
+def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
     """Forward under no_grad, freed input storage, inverse, recompute with grad: everything the reference's
-    InvertibleCheckpointFunction does, around the HIP GENConv."""
+    InvertibleCheckpointFunction does, around the HIP GENConv (impl='restated'), and the package's own fused
+    reversible step (impl='product': eff_gcn_modules.rev)."""
     _install()
     assert torch.cuda.is_available()
-    hn, grads = _run(case, torch.device("cuda:0"))
+    hn, grads = _run(case, torch.device("cuda:0"), impl)
     # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge
     # on another device, so the gradient gate is relative to each tensor's scale (not elementwise)
     _check(case, hn, grads, 2e-4, 2e-3)
