@@ -67,7 +67,7 @@ def _splitk_tn(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     GEMM runs on a handful of CUs); row-strided operands are used in place (no (R, K) copy)."""
     R = g2.size(0)
     S = 1
-    while S < 128 and R // (S * 2) >= 1024:
+    while S < 128 and R // (S * 2) >= 256:
         S *= 2
     if S == 1:
         return g2.t() @ x2
@@ -321,7 +321,9 @@ class _GenAggregate(torch.autograd.Function):
                     if ctx.needs_input_grad[15]:
                         grad_w = _splitk_tn(dz, feat)
                     if b_enc is not None and ctx.needs_input_grad[16]:
-                        grad_b = dz.sum(0)
+                        # sum_e dz_e = sum_s grad_x[s] (every edge lands in exactly one source row): an (N, C)
+                        # reduction instead of an (E, C) one; the fused root term adds g to every row
+                        grad_b = grad_x.sum(0) - g.sum(0) if ctx.add_root else grad_x.sum(0)
             if not ctx.needs_input_grad[0]:
                 grad_x = None
         return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10 + (grad_feat, grad_w, grad_b)
