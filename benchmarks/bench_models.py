@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """End-to-end step times of the BASELINE configs' model shapes on this package's gcn_lib (synthetic data,
-random-init weights): ResGCN-28 dense (config 2), DeeperGCN-28 on the arxiv shape (config 3) and a GENConv
-layer with edge features on the proteins-cluster shape (config 5's conv).  One JSON line each.
+random-init weights): ResGCN-28 dense (config 2) and DeeperGCN-28 on the arxiv shape (config 3); config 5 (RevGCN, per-layer edge encoder
+on the model-level edge embedding) lives in benchmarks/bench_revgcn.py.  One JSON line each.
     python benchmarks/bench_models.py [--iters 10]
 """
 import argparse
@@ -104,23 +104,7 @@ def main():
         print(json.dumps(dict(model="DeeperGCN-28 HIP-graph replay", error=repr(exc)[:300])), flush=True)
     del m, opt
 
-    # config 5's convolution: GENConv with edge features on the proteins-cluster shape, power (learn p) and max
-    s = synth.SHAPES["proteins_cluster"]
-    ei = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"], device=dev)
-    E = ei.size(1)
-    for aggr, kw in (("power", dict(p=1.0, learn_p=True)), ("max", {}), ("softmax", dict(t=1.0, learn_t=True))):
-        for C in (32, 112):
-            # ogbn-proteins carries 8 raw features per edge; each layer owns a Linear(8 -> C) edge encoder
-            conv = GENConv(C, C, aggr=aggr, norm="layer", mlp_layers=2, encode_edge=True, edge_feat_dim=8, **kw).to(dev)
-            xr = torch.randn(s["n"], C, device=dev, requires_grad=True)
-            ea = torch.randn(E, 8, device=dev)
-
-            def step_conv():
-                out = conv(xr, ei, ea)
-                torch.autograd.grad(out.sum(), [xr] + list(conv.parameters()))
-            ms = timed(step_conv, a.iters)
-            print(json.dumps(dict(model=f"GENConv({aggr}) + edge encoder, proteins cluster N={s['n']} E={E} C={C}, fwd+bwd",
-                                  ms_per_step=ms, edges_per_s=E / (ms * 1e-3))), flush=True)
+    # config 5 (RevGCN on ogbn-proteins, Linear(hidden -> hidden/group) edge encoder per layer): benchmarks/bench_revgcn.py
 
 
 if __name__ == "__main__":

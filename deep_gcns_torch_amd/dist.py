@@ -619,3 +619,61 @@ def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, ran
     if scheme == "halo":
         return HaloGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
     raise ValueError(f"unknown scheme {scheme!r}")
+
+
+def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = "softmax", reps: int = 5, group=None,
+                **kw) -> dict:
+    """Where one forward+backward of ``aggregate`` spends its time on this job (max over ranks, ms):
+    ``step`` = exchange + kernels as they run together (pipelined / overlapped where the scheme does that);
+    ``kernels`` = the rank-local aggregation kernels alone, on a feature tensor of the shape the exchange delivers;
+    ``exchange_and_wait`` = step - kernels (what the collectives, packing and cross-rank waiting add on top).
+    For the all-gather scheme the bare collectives (all-gather forward, reduce-scatter backward) are timed as well.
+    Meant for reading a scaling run: kernels shrink with 1/W, the exchange does not."""
+    import time as _time
+    from . import ops
+    dev = x_local.device
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        dist.barrier(group)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def timed(fn):
+        fn()
+        sync()
+        t0 = _time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        tt = torch.tensor([(_time.perf_counter() - t0) / reps * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+        return float(tt.item())
+
+    xl = x_local.detach().clone().requires_grad_(True)
+
+    def step():
+        torch.autograd.grad(aggregate(xl, part, aggr=aggr, group=group, **kw), xl, g_local)
+
+    C = x_local.size(1)
+    c_loc = C // part.channel_groups if isinstance(part, TransposedGraph) else C
+    g = part.graph
+    xin = torch.randn(g.n_src, c_loc, device=dev, requires_grad=True)
+    gout = torch.randn(g.n_dst, c_loc, device=dev)
+    kk = {k: v for k, v in kw.items() if k != "pipeline_chunks"}
+
+    def kernels():
+        torch.autograd.grad(ops.gen_aggregate(xin, g, aggr=aggr, **kk), xin, gout)
+
+    out = {"step": timed(step), "kernels": timed(kernels)}
+    out["exchange_and_wait"] = out["step"] - out["kernels"]
+    if isinstance(part, PartitionedGraph):
+        def gather():
+            xf = all_gather_rows(xl, part, group)
+            torch.autograd.grad(xf, xl, torch.ones_like(xf))
+        out["allgather_plus_reduce_scatter_alone"] = timed(gather)
+    out["local_edges"] = int(g.n_edges)
+    out["local_channels"] = int(c_loc)
+    return out
+

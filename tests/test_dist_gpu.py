@@ -61,6 +61,11 @@ def test_partitioned_aggregate_on_rccl_single_rank():
             (outh * probe).sum().backward()
             torch.testing.assert_close(outh, ref, rtol=1e-6, atol=1e-7)
             torch.testing.assert_close(xe.grad, xb.grad, rtol=1e-5, atol=1e-6)
+        # the per-phase timing helper bench.py prints for multi-rank runs (exchange vs local kernels), every scheme
+        from deep_gcns_torch_amd.dist import phase_times
+        for p_ in (part, tg, hg):
+            ph = phase_times(x, probe, p_, aggr="softmax_sg", t=0.1, reps=2)
+            assert ph["step"] > 0 and ph["kernels"] > 0 and ph["local_edges"] == ei.size(1)
     finally:
         if created:
             dist.destroy_process_group()

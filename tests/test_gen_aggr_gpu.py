@@ -351,11 +351,13 @@ def test_add_root_equals_x_plus_aggregate(aggr, kw, C, with_ea):
         ops.gen_aggregate(xa, ei, aggr="softmax", t=torch.ones(1, device=dev, requires_grad=True), learn_t=True, add_root=True)
 
 
-@pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.3)), ("softmax", dict(t=1.0, learn_t=True)), ("power", dict(p=2.0)),
-                                     ("max", {}), ("mean", {})])
-@pytest.mark.parametrize("C", [64, 112, 32, 16, 256])
+@pytest.mark.parametrize("aggr,kw,C", [("softmax_sg", dict(t=0.3), 64), ("softmax", dict(t=1.0, learn_t=True), 112),
+                                       ("power", dict(p=2.0), 32), ("max", {}, 16), ("mean", {}, 256), ("max", {}, 64)])
 def test_fused_edge_encoder_matches_linear_then_aggregate(aggr, kw, C):
-    """GENConv(encode_edge=True): relu(x_j + Linear(8 -> C)(f_e)) + eps aggregated with the Linear evaluated inside
+    """The small-feature tier of the fused edge encoder (8 RAW features per edge, a GENConv built directly on
+    ogbn-proteins' edge_attr; the reference's own models encode at model level and hand every layer the wide
+    embedding -- that shape is served by the matrix-core kernel, tests/test_egemm_gpu.py).
+    GENConv(encode_edge=True): relu(x_j + Linear(8 -> C)(f_e)) + eps aggregated with the Linear evaluated inside
     the kernels (no (E, C) embedding) against the two-step composition; gradients w.r.t. x, the encoder weight and
     bias (per-workgroup partial sums), learnable t; hub rows, sub-group and padded-lane layouts."""
     from deep_gcns_torch_amd import ops, synth
