@@ -125,6 +125,7 @@ def extras(dev):
     # ---- config 3 shape: GENConv softmax_sg aggregation on the arxiv graph -------------------------------------------
     s = synth.SHAPES["arxiv"]
     ei = synth.undirected_random_graph(s["n"], s["n_undirected"], s["seed"], device=dev)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     g = Graph.from_edge_index(ei, s["n"])
     torch.cuda.synchronize()
@@ -214,6 +215,7 @@ def extras(dev):
     # ---- config 5: RevGCN (hidden 224, group 2) on the ogbn-proteins cluster shape ----------------------------------
     s = synth.SHAPES["proteins_cluster"]
     eip = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"], device=dev)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     Graph.from_edge_index(eip, s["n"])
     torch.cuda.synchronize()
@@ -478,8 +480,8 @@ def main():
                 tj = json.load(open(tfile))
                 if tj.get("shape") == args.shape and tj.get("graph") == args.graph and tj.get("channels") == C:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = ("NOT measured in this run: profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / "
-                                      "WRITE_SIZE passes of this command, builder run, " + str(tj.get("source", "")) + ")")
+                    traffic_source = ("NOT measured in this run: profiles/traffic_latest.json = rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command in a builder run (tag " + str(tj.get("tag", "?")) + ")")
             except Exception:
                 traffic = None
         res = {
