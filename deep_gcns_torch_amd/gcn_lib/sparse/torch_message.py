@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import node_ops, ops
-from ...graph import Graph, graph_of
+from ...graph import Graph, graph_of, scatter_graph_of
 
 __all__ = ["GenMessagePassing", "MsgNorm"]
 
@@ -93,9 +93,7 @@ class GenMessagePassing(torch.nn.Module):
         """Aggregate an ALREADY materialised (E, C) message tensor by destination ``index``
         (torch_message.py:44).  Prefer ``propagate``: it never builds ``inputs``."""
         n = int(dim_size) if dim_size is not None else int(index.max()) + 1
-        ids = torch.arange(inputs.size(0), device=inputs.device, dtype=index.dtype)
-        g = Graph(ids, index, n_src=inputs.size(0), n_dst=n)
-        return self._aggregate_fused(inputs, g, None, relu_eps=False)
+        return self._aggregate_fused(inputs, scatter_graph_of(index, n), None, relu_eps=False)
 
     def update(self, aggr_out):
         return aggr_out

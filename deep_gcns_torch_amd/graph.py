@@ -64,8 +64,61 @@ class Graph:
             raise ValueError("graph too large for int32 indices")
         self.device = dev
         self.n_src, self.n_dst, self.n_edges = int(n_src), int(n_dst), int(E)
-        src = src.long()
-        dst = dst.long()
+        src = src.long().contiguous()
+        dst = dst.long().contiguous()
+        self.t_rowptr = self.t_col = self.t_eperm = None
+        self.t_work = None
+        self.out_deg = None
+        if dev.type == "cuda":
+            self._build_on_device(src, dst, need_transpose, hub_chunk)
+        else:
+            self._build_with_torch(src, dst, need_transpose, hub_chunk)
+        self._c = self._make_struct()
+
+    # ------------------------------------------------------------------
+    def _build_on_device(self, src, dst, need_transpose, hub_chunk):
+        """libdgcn's graph builder (csrc/graph_build.hip): histogram + scan + 32-bit LSD radix sort per orientation,
+        validation / maximum degree / sortedness returned in a device status block that is read ONCE for both
+        orientations (the torch composition below synchronises after min, max, is-sorted and every bincount)."""
+        lib = _lib.load()
+        dev, E = self.device, self.n_edges
+        i32 = dict(device=dev, dtype=torch.int32)
+        stream = _lib.current_stream_handle(dev)
+
+        def build(key, other, n_rows, n_other, want_erow):
+            rowptr = torch.empty(n_rows + 1, **i32)
+            col, eperm = torch.empty(E, **i32), torch.empty(E, **i32)
+            erow = torch.empty(E, **i32) if want_erow else None
+            status = torch.empty(4, **i32)
+            ws_bytes = lib.dgcn_graph_csr_workspace_bytes(E, n_rows)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            with _lib.device_ctx(dev):
+                rc = lib.dgcn_graph_csr_build(key.data_ptr(), other.data_ptr(), E, n_rows, n_other, rowptr.data_ptr(),
+                                              _lib.ptr(col), _lib.ptr(eperm), _lib.ptr(erow), status.data_ptr(),
+                                              ws.data_ptr(), ws_bytes, stream)
+            _lib.check(rc, "dgcn_graph_csr_build")
+            return rowptr, col, eperm, erow, status
+
+        rowptr, col, eperm, erow, st = build(dst, src, self.n_dst, self.n_src, True)
+        parts = [st]
+        if need_transpose:
+            t_rowptr, t_col, t_eperm, _, t_st = build(src, dst, self.n_src, self.n_dst, False)
+            parts.append(t_st)
+        flags = torch.stack(parts).tolist()                      # the one host read of this graph
+        if any(f[0] for f in flags):
+            raise ValueError("edge_index out of range")
+        self.rowptr, self.col, self._erow = rowptr, col, erow
+        self.eperm = eperm if flags[0][2] else None               # already destination-sorted: identity permutation
+        self.deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)   # in-degree, float like PyG degree()
+        self.work = _work_list(self.rowptr, hub_chunk) if flags[0][1] > 2 * hub_chunk else None
+        if need_transpose:
+            self.t_rowptr, self.t_col, self.t_eperm = t_rowptr, t_col, t_eperm
+            self.out_deg = (t_rowptr[1:] - t_rowptr[:-1]).to(torch.float32)
+            self.t_work = _work_list(self.t_rowptr, hub_chunk) if flags[1][1] > 2 * hub_chunk else None
+
+    def _build_with_torch(self, src, dst, need_transpose, hub_chunk):
+        """The same structure from torch ops (CPU tensors: host-logic and gloo tests)."""
+        dev, E, n_src, n_dst = self.device, self.n_edges, self.n_src, self.n_dst
         if E:
             lo = int(torch.minimum(src.min(), dst.min()))
             if lo < 0 or int(src.max()) >= n_src or int(dst.max()) >= n_dst:
@@ -88,9 +141,6 @@ class Graph:
         self.work = _work_list(self.rowptr, hub_chunk)
 
         # --- CSC by source (stable) ---
-        self.t_rowptr = self.t_col = self.t_eperm = None
-        self.t_work = None
-        self.out_deg = None
         if need_transpose:
             tperm = torch.sort(src, stable=True).indices if E else torch.zeros(0, dtype=torch.long, device=dev)
             tcounts = torch.bincount(src, minlength=n_src) if E else torch.zeros(n_src, dtype=torch.long, device=dev)
@@ -102,9 +152,6 @@ class Graph:
             self.out_deg = tcounts.to(torch.float32)
             self.t_work = _work_list(self.t_rowptr, hub_chunk)
 
-        self._c = self._make_struct()
-
-    # ------------------------------------------------------------------
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, **kw) -> "Graph":
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -203,3 +250,33 @@ def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
 def clear_cache() -> None:
     _cache.clear()
     _by_storage.clear()
+    _scatter_cache.clear()
+
+
+# ----------------------------------------------------------------------------------------
+# "scatter" graphs: aggregate the rows of an ALREADY materialised (E, C) tensor by a destination index
+# (utils/pyg_util.scatter_, GenMessagePassing.aggregate).  Source of edge e is row e, so only the destination index
+# defines the structure; it is cached per live index tensor exactly like edge_index above (the reference's
+# sem_seg_sparse / part_sem_seg models call scatter_ with the same `edge_index[1]` object in every layer and epoch).
+# ----------------------------------------------------------------------------------------
+_scatter_cache: dict = {}   # (id(owner), geometry) -> (weakref to owner, Graph); owner = the index tensor or its view base
+
+
+def scatter_graph_of(index: torch.Tensor, n_dst: int) -> Graph:
+    """The usual call is ``scatter_(..., edge_index[1], ...)``: a fresh VIEW object per call whose base
+    (``edge_index``) stays alive in the caller.  Entries are keyed by the owner object + the view's geometry and
+    version and die with the owner, so a recycled allocation never resurrects a stale structure."""
+    owner = index._base if index._base is not None else index
+    key = (id(owner), index.storage_offset(), tuple(index.shape), tuple(index.stride()), index._version, int(n_dst))
+    hit = _scatter_cache.get(key)
+    if hit is not None and hit[0]() is owner:
+        return hit[1]
+    E = index.numel()
+    ids = torch.arange(E, device=index.device, dtype=torch.long)
+    g = Graph(ids, index.reshape(-1), n_src=E, n_dst=int(n_dst))
+
+    def _evict(_r, key=key):
+        _scatter_cache.pop(key, None)
+
+    _scatter_cache[key] = (weakref.ref(owner, _evict), g)
+    return g

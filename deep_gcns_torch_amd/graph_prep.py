@@ -2,11 +2,15 @@
 
 The reference prepares graphs on the CPU every epoch: PyG ``to_undirected`` / ``add_self_loops``
 (examples/ogb/ogbn_arxiv/main.py:72-75), a random node partition and scipy CSR slicing per cluster
-(utils/data_util.py:43-61, examples/ogb/ogbn_products/main.py:120-126), then an H2D copy per cluster.  Once the
-aggregation runs at HBM speed that host work is the epoch bottleneck.  These helpers do the same integer work
-with device-side sort / scan / compaction (rocPRIM through torch) on whatever device ``edge_index`` lives on, and
-return COO ``edge_index`` tensors with the reference's conventions so they can be fed to the modules (and cached
-as CSR/CSC by ``graph.graph_of``) without touching the host.
+(utils/data_util.py:43-61, examples/ogb/ogbn_products/main.py:120-126; ogbn_proteins/dataset.py:87-151 additionally
+looks every edge up in a python dict to recover its edge_attr row), then an H2D copy per cluster.  Once the
+aggregation runs at HBM speed that host work is the epoch bottleneck.  Here the same integer work runs on the
+device: the induced sub-graph of a cluster (nodes, relabelled edges in original order, kept edge ids for
+``edge_attr``) is ONE libdgcn call (``dgcn_subgraph_extract``: flag -> scan -> compact, csrc/graph_build.hip) with a
+single host read of the two counts; ``to_undirected`` / coalescing use the device sort.  Everything returns COO
+``edge_index`` tensors with the reference's conventions, ready for the modules (whose CSR/CSC is built by
+``dgcn_graph_csr_build`` and cached by ``graph.graph_of``).  CPU tensors take the torch compositions (host-logic
+tests).
 """
 from __future__ import annotations
 
@@ -51,14 +55,40 @@ def induced_subgraph(edge_index: torch.Tensor, parts: torch.Tensor, cluster: int
     """Sub-graph induced by the nodes with ``parts == cluster`` (what ``adj[nodes, :][:, nodes]`` does on the
     host, utils/data_util.py:55-60): returns (node ids ascending, relabelled edge_index in the original edge
     order, the matching rows of ``edge_attr``, ids of the kept edges)."""
-    mask = parts == cluster
-    nodes = torch.nonzero(mask).flatten()
-    new_id = torch.full((num_nodes,), -1, dtype=edge_index.dtype, device=edge_index.device)
-    new_id[nodes] = torch.arange(nodes.numel(), device=edge_index.device, dtype=edge_index.dtype)
-    keep = mask[edge_index[0]] & mask[edge_index[1]]
-    eids = torch.nonzero(keep).flatten()
-    sub = new_id[edge_index[:, eids]]
+    if edge_index.is_cuda:
+        nodes, sub, eids = _induced_subgraph_device(edge_index, parts, cluster, num_nodes)
+    else:
+        mask = parts == cluster
+        nodes = torch.nonzero(mask).flatten()
+        new_id = torch.full((num_nodes,), -1, dtype=edge_index.dtype, device=edge_index.device)
+        new_id[nodes] = torch.arange(nodes.numel(), device=edge_index.device, dtype=edge_index.dtype)
+        keep = mask[edge_index[0]] & mask[edge_index[1]]
+        eids = torch.nonzero(keep).flatten()
+        sub = new_id[edge_index[:, eids]]
     return nodes, sub, (None if edge_attr is None else edge_attr[eids]), eids
+
+
+def _induced_subgraph_device(edge_index, parts, cluster, num_nodes):
+    from . import _lib
+    lib = _lib.load()
+    dev = edge_index.device
+    ei = edge_index.long().contiguous()
+    pt = parts.to(device=dev, dtype=torch.long).contiguous()
+    E = ei.size(1)
+    i64 = dict(device=dev, dtype=torch.long)
+    nodes = torch.empty(num_nodes, **i64)
+    sub = torch.empty(2, E, **i64)
+    eids = torch.empty(E, **i64)
+    counts = torch.empty(2, **i64)
+    ws_bytes = lib.dgcn_subgraph_workspace_bytes(E, num_nodes)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_subgraph_extract(ei[0].data_ptr(), ei[1].data_ptr(), E, pt.data_ptr(), num_nodes, int(cluster),
+                                       nodes.data_ptr(), sub[0].data_ptr(), sub[1].data_ptr(), eids.data_ptr(),
+                                       counts.data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_subgraph_extract")
+    n_sub, e_sub = counts.tolist()                       # the one host read
+    return nodes[:n_sub], sub[:, :e_sub], eids[:e_sub]
 
 
 def generate_sub_graphs(edge_index: torch.Tensor, parts: torch.Tensor, num_nodes: int, cluster_number: int = 10,

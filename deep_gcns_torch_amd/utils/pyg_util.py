@@ -3,6 +3,7 @@ backed by the fused libdgcn aggregation kernel instead of atomics."""
 import torch
 
 from .. import ops
+from ..graph import scatter_graph_of
 
 __all__ = ["scatter_"]
 
@@ -15,10 +16,9 @@ def scatter_(name, src, index, dim=0, dim_size=None):
     if dim not in (0, -2) or src.dim() != 2:
         raise NotImplementedError("scatter_ supports (E, C) tensors along dim 0")
     n = int(dim_size) if dim_size is not None else (int(index.max()) + 1 if index.numel() else 0)
-    E = src.size(0)
-    # rows of `src` are already per-edge values: gather them through the identity "source" map
-    edge_ids = torch.arange(E, device=src.device, dtype=index.dtype)
-    g = ops.Graph(edge_ids, index, n_src=E, n_dst=n)
+    # rows of `src` are already per-edge values: gather them through the identity "source" map; the structure
+    # depends on `index` only and is cached per live index tensor (no sort / host sync per call)
+    g = scatter_graph_of(index, n)
     if name == "min":
         out = -ops.gen_aggregate(-src, g, aggr="max", relu_eps=False)
         return torch.where(out > 10000, torch.zeros_like(out), out)

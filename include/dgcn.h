@@ -234,6 +234,34 @@ int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshif
                               int64_t n_rows, int32_t channels, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Device-side graph structure.  The reference keeps a COO edge_index and re-partitions it on
+ * the host every epoch (utils/data_util.py:43-61 random_partition_graph / generate_sub_graphs: scipy CSR slicing;
+ * examples/ogb/ogbn_proteins/dataset.py:87-151: a python dict lookup per edge for the edge ids).
+ *
+ * dgcn_graph_csr_build: stable order of the E edges by `key` (edge_index[1] for the forward CSR, edge_index[0] for
+ *   the backward CSC), `other` = the opposite endpoint:
+ *     rowptr [n_rows+1], col [E] = other endpoint of CSR position p, eperm [E] = original edge id of position p,
+ *     erow [E] or NULL = key of position p (the sorted keys)
+ *   status [4] int32 (device): [0] != 0 an id was out of range (such edges are dropped from the counts: treat the
+ *   structure as invalid), [1] maximum row length, [2] != 0 the keys were NOT already non-decreasing, [3] reserved.
+ *   One host read of `status` replaces the min / max / is-sorted / bincount synchronisations of a host-driven build.
+ * dgcn_subgraph_extract: the sub-graph induced by the nodes with parts[i] == cluster:
+ *     node_ids [<= n_nodes] ascending, (sub_src, sub_dst) [<= E] relabelled to positions in node_ids, original edge
+ *     order, edge_ids [<= E] = kept original edge ids (to slice edge_attr); counts [2] int64 (device) = {#nodes, #edges}.
+ *   edge endpoints must be valid ids (0 <= id < n_nodes).
+ * All int64 inputs are contiguous device arrays; workspaces from the *_workspace_bytes functions; asynchronous on
+ * `stream`.
+ */
+size_t dgcn_graph_csr_workspace_bytes(int64_t n_edges, int32_t n_rows);
+int dgcn_graph_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int32_t n_rows, int32_t n_other,
+                         int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* erow, int32_t* status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+size_t dgcn_subgraph_workspace_bytes(int64_t n_edges, int32_t n_nodes);
+int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edges, const int64_t* parts,
+                          int32_t n_nodes, int64_t cluster, int64_t* node_ids, int64_t* sub_src, int64_t* sub_dst,
+                          int64_t* edge_ids, int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Dense (B x C x N x 1) point-cloud path.
  * ------------------------------------------------------------------------------------ */
 
