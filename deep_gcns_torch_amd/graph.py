@@ -125,7 +125,7 @@ class Graph:
                 raise ValueError("edge_index out of range")
 
         # --- CSR by destination (stable) ---
-        if E and bool((dst[1:] >= dst[:-1]).all()):
+        if E == 0 or bool((dst[1:] >= dst[:-1]).all()):
             perm = None
             col = src
         else:
