@@ -5,7 +5,7 @@ R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 cd /tmp
-B="python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 $*"
+B="python $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- $B > $R/gpurun_out/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- $B > $R/gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- $B > $R/gpurun_out/prof_write.log 2>&1

@@ -1026,8 +1026,9 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
     f1 = f4v{0.f, 0.f, 0.f, 0.f};
     if (P.dbg & 4) return;
     const int o = sblk * kEgChunk + 8 * kq;
-    if (sblk + 1 < KC || o < K) f0 = *reinterpret_cast<const f4v*>(arow + o);        // K % 16 == 0
-    if (sblk + 1 < KC || o + 4 < K) f1 = *reinterpret_cast<const f4v*>(arow + o + 4);
+    // streamed once: non-temporal, so the 709 MB of features do not evict the gathered x rows (5.9 MB) from L2
+    if (sblk + 1 < KC || o < K) f0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(arow + o));   // K % 16 == 0
+    if (sblk + 1 < KC || o + 4 < K) f1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(arow + o + 4));
   };
   const i4v* wb = Wp + n * SU + kq;          // + plane * PLANE + ct * 16 * SU + 4 * s
 
