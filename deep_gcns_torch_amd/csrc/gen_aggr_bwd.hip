@@ -333,12 +333,13 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
   if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
-    const bool one = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows) == kWave;
+    const int sw_sel = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows, P.n_edges_hint);
+    const bool one = sw_sel == kWave;
     switch (lpr) {
       case 4: one ? launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, kSubWidth(4)>(P, grid, s); break;
       case 8: one ? launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, kSubWidth(8)>(P, grid, s); break;
       case 16: one ? launch_bwd_ea<MODE, 4, 16, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 16, kSubWidth(16)>(P, grid, s); break;
-      case 32: one ? launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 32, kSubWidth(32)>(P, grid, s); break;
+      case 32: (sw_sel == 32) ? launch_bwd_ea<MODE, 4, 32, 32>(P, grid, s) : launch_bwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
       default: launch_bwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
     }
   } else {
@@ -353,7 +354,7 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
 
 int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
   const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
-  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src)) : 1;
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src), g->n_edges) : 1;
   const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
   int grid = round_up8(grid_for_waves(n_items));
   if (enc && grid > kEncMaxParts) grid = kEncMaxParts;
@@ -408,6 +409,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.enc_w = enc ? enc->w : nullptr;
   P.enc_b = enc ? enc->b : nullptr;
   P.enc_gpart = enc_gpart;
+  P.n_edges_hint = g->n_edges;
   if (enc && !vec4) return DGCN_E_ALIGN;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;

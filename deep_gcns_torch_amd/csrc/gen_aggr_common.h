@@ -49,6 +49,7 @@ struct FwdParams {
   const float* enc_feat;  // EA == 2: raw edge features [E, kEncF] in original edge order; e_e = enc_w f_e + enc_b
   const float* enc_w;     // [C, kEncF] (nn.Linear weight)
   const float* enc_b;     // [C] or null
+  int n_edges_hint;     // edges of the walk (layout choice only)
   float* ws;  // partial slots: [slot][4][C]
 };
 
@@ -78,6 +79,7 @@ struct BwdParams {
   float* enc_gpart;       // EA == 2: [gridDim.x][C][kEncF + 1] per-workgroup partial (dW | db)
   float* grad_x;
   float* grad_ea;
+  int n_edges_hint;       // edges of the walk (layout choice only)
   float* ws;  // partial slots: [slot][C]
 };
 
@@ -225,7 +227,12 @@ constexpr int kSubWidth(int lpr) { return lpr * kEdgeGroups(lpr) < kWave ? lpr *
 // when it still leaves >= kMinWaves waves (two per wave slot of the chip); a small graph (ogbn-proteins clusters,
 // PPI) needs every row as its own wave.
 constexpr int kMinWaves = 12288;
-inline int subgroup_width(int lpr, int64_t n_items) {
+inline int subgroup_width(int lpr, int64_t n_items, int64_t n_edges = -1) {
+  // 128-channel rows on a LOW-DEGREE graph (ogbn-arxiv: 14.7 edges per row): two rows per wave, one edge group each.
+  // There the kernel is VALU-issue bound by per-row work (SQ_INSTS_VALU = 35 per edge against ~12 of fold; the
+  // cross-group state merge, the epilogue and the item bookkeeping are paid per wave), so sharing a wave between two
+  // rows and dropping the merge beats walking two edges of one row at once.  High-degree graphs keep one row per wave.
+  if (lpr == 32 && n_edges >= 0 && n_edges < 32 * n_items && n_items * 32 / kWave >= kMinWaves) return 32;
   const int sw = kSubWidth(lpr);
   return (n_items * sw / kWave >= kMinWaves) ? sw : kWave;
 }

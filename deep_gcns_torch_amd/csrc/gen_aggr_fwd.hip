@@ -344,12 +344,13 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
   if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
-    const bool one = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows) == kWave;
+    const int sw_sel = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows, P.n_edges_hint);
+    const bool one = sw_sel == kWave;
     switch (lpr) {
       case 4: one ? launch_fwd_ea<MODE, 4, 4, 64>(P, grid, s) : launch_fwd_ea<MODE, 4, 4, kSubWidth(4)>(P, grid, s); break;
       case 8: one ? launch_fwd_ea<MODE, 4, 8, 64>(P, grid, s) : launch_fwd_ea<MODE, 4, 8, kSubWidth(8)>(P, grid, s); break;
       case 16: one ? launch_fwd_ea<MODE, 4, 16, 64>(P, grid, s) : launch_fwd_ea<MODE, 4, 16, kSubWidth(16)>(P, grid, s); break;
-      case 32: one ? launch_fwd_ea<MODE, 4, 32, 64>(P, grid, s) : launch_fwd_ea<MODE, 4, 32, kSubWidth(32)>(P, grid, s); break;
+      case 32: (sw_sel == 32) ? launch_fwd_ea<MODE, 4, 32, 32>(P, grid, s) : launch_fwd_ea<MODE, 4, 32, 64>(P, grid, s); break;
       default: launch_fwd_ea<MODE, 4, 64, 64>(P, grid, s); break;
     }
   } else {
@@ -399,9 +400,10 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.enc_feat = enc ? enc->feat : nullptr;
   P.enc_w = enc ? enc->w : nullptr;
   P.enc_b = enc ? enc->b : nullptr;
+  P.n_edges_hint = g->n_edges;
   if (enc && !vec4) return DGCN_E_ALIGN;
 
-  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->n_work ? g->n_work : g->n_dst)) : 1;   // items walked side by side by one wave
+  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->n_work ? g->n_work : g->n_dst), g->n_edges) : 1;   // items walked side by side by one wave
   const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
 #ifdef DGCN_FWD_WAVES_PER_CU
   const int grid = round_up8(grid_for_waves(n_items, DGCN_FWD_WAVES_PER_CU));

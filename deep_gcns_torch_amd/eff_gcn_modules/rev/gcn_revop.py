@@ -155,7 +155,7 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
         for t in shared:                              # running gradient sums of the tensors all layers share
             acc = getattr(t, _ACC, None)
             if acc is None:
-                acc = torch.zeros_like(t, memory_format=torch.contiguous_format)
+                acc = module.make_arg_sink(t)
                 setattr(t, _ACC, acc)
             sinks.append(acc)
         x, grad_x, weight_grads = module.fused_backward(y, grad_outputs[0], inputs[1], inputs[2:], ctx.weights,
@@ -173,7 +173,7 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
                 setattr(t, _USES, left)
                 arg_grads.append(None)                # a layer further down the backward pass hands the sum over
             else:
-                arg_grads.append(sinks[k])
+                arg_grads.append(module.finish_arg_sink(sinks[k], t))
                 for name in (_USES, _ACC):
                     if hasattr(t, name):
                         delattr(t, name)

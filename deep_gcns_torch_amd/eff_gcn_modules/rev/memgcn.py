@@ -42,6 +42,17 @@ class GroupAdditiveCoupling(torch.nn.Module):
         return torch.cat(xs, dim=self.split_dim)
 
     # ------------------------------------------------------------------------------------------------------------
+    def make_arg_sink(self, t):
+        """Running gradient sum of a tensor argument every layer receives: one CONTIGUOUS (rows, width / group) block
+        per group (GENConv's ``dz @ W`` is accumulated into it by a plain GEMM with beta = 1, no strided output)."""
+        width = t.size(self.split_dim)
+        assert t.dim() == 2 and self.split_dim in (-1, 1) and width % self.group == 0
+        return torch.zeros(self.group, t.size(0), width // self.group, device=t.device, dtype=torch.float32)
+
+    def finish_arg_sink(self, buf, t):
+        """(group, rows, w) -> the layout of the argument (rows, group * w)."""
+        return buf.permute(1, 0, 2).reshape(t.shape).to(t.dtype)
+
     def fused_backward(self, y, grad_y, edge_index, args, weights, arg_sinks, sink_ctx):
         """Inverse and gradient of one coupling step from ONE grad-enabled evaluation of every F_i.
 
@@ -49,8 +60,8 @@ class GroupAdditiveCoupling(torch.nn.Module):
         other groups for i = 0), so its output is computed once: ``x_i = y_i - F_i(.)`` rebuilds the input and the
         recorded graph is differentiated with the total gradient that reaches ``y_i``.
         Returns (x, grad_x, gradients of ``weights`` in order).  Gradients of the extra tensor arguments are ADDED
-        into ``arg_sinks`` (one buffer per floating argument that requires grad, or None when the caller keeps no
-        buffer for it); ``sink_ctx(arg_leaf, buffer_view)`` lets GENConv add its edge-feature gradient in place."""
+        into ``arg_sinks`` (one ``make_arg_sink`` buffer per floating argument that requires grad);
+        ``sink_ctx(arg_leaf, buffer_block)`` lets GENConv add its edge-feature gradient in place."""
         g = self.group
         dim = self.split_dim
         ys = torch.chunk(y, g, dim=dim)
@@ -77,7 +88,7 @@ class GroupAdditiveCoupling(torch.nn.Module):
                             c.requires_grad_(True)
                             leaves.append(c)
                             s = sink_of[id(a)]
-                            views.append(None if s is None else torch.chunk(s, g, dim=dim)[i])
+                            views.append(None if s is None else s[i])
                         call_args.append(c)
                     else:
                         call_args.append(a)

@@ -96,8 +96,8 @@ class edge_grad_sink:
     (same shape, fp32) instead of being returned to autograd."""
 
     def __init__(self, feat: torch.Tensor, buffer: torch.Tensor):
-        if buffer.shape != feat.shape or buffer.dtype != torch.float32:
-            raise ValueError("edge_grad_sink: buffer must be fp32 with the shape of the feature tensor")
+        if buffer.shape != feat.shape or buffer.dtype != torch.float32 or not buffer.is_contiguous():
+            raise ValueError("edge_grad_sink: buffer must be a contiguous fp32 tensor with the shape of the feature tensor")
         self._key, self._buf = _sink_key(feat), buffer
 
     def __enter__(self):

@@ -135,6 +135,45 @@ def test_vs_oracle_powerlaw_graph(aggr, kw, C, with_ea):
         torch.testing.assert_close(ed.grad.cpu().double(), er.grad, rtol=RTOL, atol=2e-6 * max(gs, 1.0))
 
 
+@pytest.mark.parametrize("with_ea", [False, True])
+@pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.1)), ("softmax", dict(t=0.8, learn_t=True)), ("power", dict(p=2.0)),
+                                     ("max", {}), ("mean", {}), ("add", {})])
+def test_low_degree_128_channel_rows_two_per_wave(aggr, kw, with_ea):
+    """C = 128 on a low-degree graph with many rows (ogbn-arxiv's regime: < 32 edges per row, >= 24,576 rows) takes the
+    two-rows-per-wave layout (LPR = 32, one edge group per row) in both walks; also the fp32 oracle comparison the
+    power-law test leaves out (the fp64 oracle is not the reference's fp32 path) -- degrees here are
+    small, so fp32 summation order costs ~1e-6."""
+    from deep_gcns_torch_amd import ops, synth
+    from oracle import sparse_ref
+    dev = _dev()
+    n, C = 30000, 128
+    ei = synth.undirected_random_graph(n, 180_000, seed=21)           # 13 edges per row incl. self loops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=gen)
+    probe = torch.randn(n, C, generator=gen)
+    ea = 0.5 * torch.randn(ei.size(1), C, generator=gen) if with_ea else None
+    kw = dict(kw)
+    tr = td = None
+    if kw.get("learn_t"):
+        tr = torch.tensor([kw["t"]], requires_grad=True)
+        td = torch.tensor([kw["t"]], device=dev, requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    er = ea.clone().requires_grad_(True) if with_ea else None
+    ref = sparse_ref.gen_propagate(xr, ei, edge_attr=er, aggr=aggr, **(dict(kw, t=tr) if tr is not None else kw))
+    (ref * probe).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    ed = ea.to(dev).requires_grad_(True) if with_ea else None
+    out = ops.gen_aggregate(xd, ei.to(dev), edge_attr=ed, aggr=aggr, **(dict(kw, t=td) if td is not None else kw))
+    (out * probe.to(dev)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=1e-5)
+    gs = float(xr.grad.abs().max())
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=1e-5 * max(gs, 1.0))
+    if with_ea:
+        torch.testing.assert_close(ed.grad.cpu(), er.grad, rtol=RTOL, atol=1e-5 * max(gs, 1.0))
+    if td is not None:
+        torch.testing.assert_close(td.grad.cpu(), tr.grad, rtol=1e-3, atol=1e-3 * float(tr.grad.abs().max()))
+
+
 def test_arxiv_shape_properties():
     """Full ogbn-arxiv-shaped input: size-independent properties instead of a CPU replay."""
     from deep_gcns_torch_amd import ops, synth
