@@ -29,18 +29,43 @@ class Dilated(nn.Module):
         return edge_index[:, ::self.dilation]
 
 
-def _knn_flat(x, k, batch, exclude_self):
+def _knn_flat(x, k, batch, exclude_self, allow_ragged=False):
     from ... import dense_ops
     with torch.no_grad():
         n_clouds = 1 if batch is None else int(batch[-1]) + 1
-        if x.shape[0] % n_clouds != 0:
-            raise NotImplementedError("kNN kernel needs equally sized clouds (N_total divisible by batch size)")
+        equal = x.shape[0] % n_clouds == 0
+        if equal and batch is not None and n_clouds > 1 and allow_ragged:
+            n_each = x.shape[0] // n_clouds                       # equal count is not enough: check the boundaries
+            equal = bool((batch[::n_each] == torch.arange(n_clouds, device=batch.device)).all()) and \
+                bool((batch[n_each - 1::n_each] == torch.arange(n_clouds, device=batch.device)).all())
+        if not equal:
+            if not allow_ragged:
+                raise NotImplementedError("kNN kernel needs equally sized clouds (N_total divisible by batch size)")
+            return _knn_ragged(x, k, batch, exclude_self)
         pts = x.detach().reshape(n_clouds, -1, x.shape[-1])
         n_points = pts.shape[1]
         nn_idx = dense_ops.knn_indices(pts, k, 1, exclude_self)                  # (B, N, k) int64
         nn_idx = nn_idx + torch.arange(0, n_points * n_clouds, n_points, device=x.device).view(n_clouds, 1, 1)
         center = torch.arange(0, n_points * n_clouds, device=x.device).repeat_interleave(k)
     return nn_idx.reshape(1, -1), center.view(1, -1)
+
+
+def _knn_ragged(x, k, batch, exclude_self):
+    """Clouds of different sizes (torch_cluster.knn_graph accepts any sorted ``batch`` vector,
+    gcn_lib/dense/torch_edge.py:97, gcn_lib/sparse/torch_edge.py:46): one kernel launch per cloud on its slice.
+    ``batch`` must be sorted (as PyG batches are); every cloud needs at least k (+1 without self) points."""
+    from ... import dense_ops
+    sizes = torch.bincount(batch).tolist()
+    nn_parts, ctr_parts, start = [], [], 0
+    for n_b in sizes:
+        if n_b == 0:
+            continue
+        pts = x.detach()[start:start + n_b].unsqueeze(0)
+        idx = dense_ops.knn_indices(pts, k, 1, exclude_self)[0] + start         # (n_b, k)
+        nn_parts.append(idx.reshape(-1))
+        ctr_parts.append(torch.arange(start, start + n_b, device=x.device).repeat_interleave(k))
+        start += n_b
+    return torch.cat(nn_parts).view(1, -1), torch.cat(ctr_parts).view(1, -1)
 
 
 def knn_matrix(x, k=16, batch=None):
@@ -50,9 +75,10 @@ def knn_matrix(x, k=16, batch=None):
 
 
 def knn_graph(x, k, batch=None, loop=False, flow="source_to_target"):
-    """Stand-in for torch_cluster.knn_graph on equally sized clouds: (2, N_total*k), row 0 = neighbour,
-    row 1 = centre, grouped by centre, self excluded unless ``loop`` (exact brute force on the GPU)."""
-    nn_idx, center_idx = _knn_flat(x, k, batch, not loop)
+    """Stand-in for torch_cluster.knn_graph: (2, N_total*k), row 0 = neighbour, row 1 = centre, grouped by centre,
+    self excluded unless ``loop`` (exact brute force on the GPU).  Equally sized clouds go through one batched launch,
+    ragged batches through one launch per cloud."""
+    nn_idx, center_idx = _knn_flat(x, k, batch, not loop, allow_ragged=True)
     return torch.cat((nn_idx, center_idx), dim=0)
 
 

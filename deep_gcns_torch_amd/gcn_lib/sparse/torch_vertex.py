@@ -114,15 +114,25 @@ class EdgConv(nn.Module):
         self.nn = MLP([in_channels * 2, out_channels], act, norm, bias)
         self.aggr = aggr
         self.in_channels = in_channels
-        if aggr != 'max':
-            raise NotImplementedError("EdgConv: only aggr='max' (the reference default) is implemented")
-        for m in self.nn:
-            if isinstance(m, (nn.LayerNorm, nn.InstanceNorm1d, nn.PReLU)):
-                raise NotImplementedError(
-                    f"EdgConv: {type(m).__name__} does not commute with the neighbourhood max; "
-                    "use norm in {None,'batch'} and act in {'relu','leakyrelu'}")
+        if aggr not in ('max', 'add', 'mean'):
+            raise NotImplementedError("EdgConv: aggr must be one of max / add / mean (tg.nn.EdgeConv)")
+        # The per-vertex split needs a reduction that commutes with the per-edge affine norm and a monotone
+        # activation: max with BatchNorm / no norm and ReLU / LeakyReLU.  Every other option of the reference
+        # (aggr add / mean; layer or instance norm; PReLU) is evaluated per edge like the reference does
+        # (torch_vertex.py:111 -> tg.nn.EdgeConv.message) and reduced by the aggregation kernel.
+        self._per_edge = aggr != 'max' or any(isinstance(m, (nn.LayerNorm, nn.InstanceNorm1d, nn.PReLU))
+                                              for m in self.nn)
+
+    def _forward_per_edge(self, x, edge_index):
+        dst = edge_index[1]
+        x_i, x_j = x.index_select(0, dst), x.index_select(0, edge_index[0])
+        msg = self.nn(torch.cat([x_i, x_j - x_i], dim=1))            # (E, C')
+        from ...graph import scatter_graph_of
+        return ops.gen_aggregate(msg, scatter_graph_of(dst, x.size(0)), aggr=self.aggr, relu_eps=False)
 
     def forward(self, x, edge_index):
+        if self._per_edge:
+            return self._forward_per_edge(x, edge_index)
         lin = self.nn[0]
         C = self.in_channels
         g = graph_of(edge_index, x.size(0))

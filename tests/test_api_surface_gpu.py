@@ -110,3 +110,72 @@ def test_dense_blocks_and_composed_edgeconv():
     out.sum().backward()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("aggr,norm,act", [("add", None, "relu"), ("mean", "batch", "relu"), ("max", "layer", "relu"),
+                                           ("max", "batch", "prelu"), ("add", "batch", "leakyrelu")])
+def test_sparse_edgconv_every_option_of_the_reference(aggr, norm, act):
+    """EdgConv(aggr != 'max') and layer norm / PReLU inside it (gcn_lib/sparse/torch_vertex.py:106-114 passes them
+    straight to tg.nn.EdgeConv): evaluated per edge, reduced by the HIP aggregation kernel, against the oracle."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import synth
+    from gcn_lib.sparse.torch_vertex import EdgConv
+    from oracle import thirdparty as tp
+    dev = torch.device("cuda:0")
+    ei = synth.tricky_graph()
+    torch.manual_seed(3)
+    m = EdgConv(24, 40, act, norm, True, aggr)
+    x = torch.randn(257, 24)
+    probe = torch.randn(257, 40)
+    xr = x.clone().requires_grad_(True)
+    m.train()
+    ref = tp.EdgeConv(m.nn, aggr)(xr, ei)                      # the same nn module, per-edge on the CPU
+    (ref * probe).sum().backward()
+    ref_grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    import copy
+    md = copy.deepcopy(m).to(dev).train()
+    if norm == "batch":                                        # the CPU pass above already advanced the running stats
+        for mod in md.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.reset_running_stats()
+    xd = x.to(dev).requires_grad_(True)
+    out = md(xd, ei.to(dev))
+    (out * probe.to(dev)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()) + 1e-6)
+    for k, p in md.named_parameters():
+        g = ref_grads[k]
+        torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-3, atol=2e-4 * float(g.abs().max()) + 1e-6)
+
+
+def test_ragged_batches_through_knn_graph():
+    """torch_cluster-style knn_graph on clouds of different sizes (sorted batch vector): one launch per cloud; exact
+    neighbour distances on lattice clouds, ids offset per cloud, self excluded."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import synth
+    from gcn_lib.sparse.torch_edge import knn_graph
+    dev = torch.device("cuda:0")
+    sizes = [150, 97, 230]
+    clouds = [synth.lattice_cloud(1, 5, n, seed=40 + i)[0, :, :, 0].t().contiguous() for i, n in enumerate(sizes)]
+    x = torch.cat(clouds)
+    batch = torch.cat([torch.full((n,), i) for i, n in enumerate(sizes)])
+    k = 7
+    ei = knn_graph(x.to(dev), k, batch.to(dev)).cpu()
+    assert ei.shape == (2, sum(sizes) * k)
+    start = 0
+    for c, n in zip(clouds, sizes):
+        d = torch.cdist(c.double(), c.double()) ** 2
+        d.fill_diagonal_(float("inf"))
+        want = torch.sort(d, dim=1).values[:, :k]
+        sl = slice(start * k, (start + n) * k)
+        nb = ei[0, sl].view(n, k) - start
+        ct = ei[1, sl].view(n, k) - start
+        assert bool((nb >= 0).all()) and bool((nb < n).all())
+        assert torch.equal(ct, torch.arange(n).view(n, 1).expand(n, k))
+        got = torch.gather(d, 1, nb)
+        torch.testing.assert_close(got, want, rtol=0, atol=1e-9)
+        start += n
+
