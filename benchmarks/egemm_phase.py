@@ -39,9 +39,10 @@ def timed(iters=20):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-for waves in ("8",):
+for waves in ((sys.argv[2],) if len(sys.argv) > 2 else ("0",)):
     for dbg, name in ((0, "full"), (1, "no walk"), (2, "no MFMA chain"), (3, "no walk, no MFMA"), (4, "no feature loads"),
                       (5, "no feature loads, no walk"), (16, "full + stagger")):
         os.environ["DGCN_EG_DEBUG"] = str(dbg)
-        os.environ["DGCN_EG_WAVES"] = waves
+        if waves != "0":
+            os.environ["DGCN_EG_WAVES"] = waves
         print(json.dumps(dict(waves_per_wg=int(waves), variant=name, ms=round(timed(), 4))), flush=True)

@@ -55,6 +55,8 @@ struct EgParams {
   const int32_t* erow;      // [E] destination row of every CSR position
   const float* x;
   int64_t x_stride;
+  const float* xg;          // gather source of the pipelined kernels: x, or x + bias (prepared in the workspace)
+  int64_t xg_stride;
   const float* feat;
   int64_t feat_stride;
   const float* w;           // [C][K]
@@ -938,10 +940,16 @@ __device__ __forceinline__ f4v eg_mfma_bf16(const i4v& a, const i4v& b, const f4
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
-template <int NT, int KC, int MODE>
-__global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(const EgParams P) {
+// WPS = waves per SIMD the register budget is written for.  2: two full weight-fragment buffers (a plane's fragments
+// are requested a whole MFMA phase ahead), feature ring two blocks deep, 256 VGPRs.  3: the wide shapes (NT >= 5) are
+// latency-bound at two waves (SQ_WAIT_ANY 43 %, profiles/r02_egemm_analysis.md), so the same chain is written for
+// <= 168 VGPRs and 12 waves per CU: the fragments of the two tile halves alternate in two half-size buffers (a
+// half is re-filled right after its MFMAs and consumed after the other half's), feature ring one block deep.
+template <int NT, int KC, int MODE, int WPS>
+__device__ __forceinline__ void egemm_bf16_body(const EgParams& P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int DB = kEgAheadB < KC ? kEgAheadB : KC;
+  constexpr int DBW = WPS == 3 ? 1 : kEgAheadB;
+  constexpr int DB = DBW < KC ? DBW : KC;
   constexpr int SU = 4 * KC + 2;            // row stride of a weight plane in 16-byte units: % 4 == 2, conflict-free
   constexpr int PLANE = NT * 16 * SU;       // units per plane
   const int C = P.C, K = P.K;
@@ -978,14 +986,9 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
   const float t2 = t * 1.4426950408889634f;
   const float c0s = t2 * eps_r;
   const int E = P.n_edges;
-  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
+  const uint32_t xg32 = static_cast<uint32_t>(P.xg_stride);   // gather source: x, or x + bias prepared by the entry point
   const int istride = gridDim.x * nwaves;
 
-  float bias[NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
-
-  if ((wave & 4) == 0) __builtin_amdgcn_s_setprio(1);   // waves w and w + 4 share a SIMD: stagger their phases
   EgCoord cur;
   cur.item = blockIdx.x * nwaves + wave;
   if (cur.item >= P.n_items) return;
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
       const int ch = ct * 16 + n;
       const bool chok = ch < C;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[ct][j] = chok ? __float_as_int(row_ptr(P.x, srcj[j], xs32)[ch]) : 0;
+      for (int j = 0; j < 4; ++j) dst[ct][j] = chok ? __float_as_int(row_ptr(P.xg, srcj[j], xg32)[ch]) : 0;
     }
   };
   // raw feature block s of a row: lane (m = n, kq) owns floats 32 s + 8 kq .. + 7 (two 16-byte loads)
@@ -1043,10 +1046,12 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
 #pragma unroll
   for (int sb = 0; sb < DB; ++sb) load_raw(arow_c, sb, ra[sb][0], ra[sb][1]);
   f4v acc[NT];
-  i4v bx[2][NT];                              // two weight-plane fragment buffers
+  constexpr int G0 = (NT + 1) / 2, G1 = NT - G0;      // WPS == 3: tile halves of the two half-size buffers
+  i4v bx[WPS == 3 ? 1 : 2][NT];               // WPS == 2: two weight-plane fragment buffers (bx[1] also parks the next
+                                              // batch's x rows between two chains); WPS == 3: one, used as two halves
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bx[0][ct] = wb[ct * 16 * SU];       // plane 1 of block 0
-  gather_x(bx[1], mc.src);
+  if constexpr (WPS == 2) gather_x(bx[1], mc.src);
 
   EgWalk wk;
   State<NT> st;
@@ -1057,66 +1062,129 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
     const EgCoord nn = next_coord(nxt, vnn);
     const EgMeta mnn = eg_load_meta(P, nn, lane);
     const float* arow_n = P.feat + static_cast<int64_t>(mn.eid) * P.feat_stride;
+    if constexpr (WPS == 2) {
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
+      for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[ct][j] = __int_as_float(bx[1][ct][j]) + bias[ct];
+        for (int j = 0; j < 4; ++j) acc[ct][j] = __int_as_float(bx[1][ct][j]);
+      }
+    } else {
+      // three waves per SIMD cover this gather's (L2) latency; no register left to park it earlier
+      i4v (&ai)[NT] = *reinterpret_cast<i4v(*)[NT]>(&acc[0]);
+      gather_x(ai, mc.src);
     }
 
     // ---- tile = x + bias + F W^T, six bf16 MFMAs per 16x16x32 block ----
+    if constexpr (WPS == 3) {
+      if (!(P.dbg & 2))
+#pragma unroll
+      for (int sb = 0; sb < KC; ++sb) {
+        if (sb + DB < KC) {
+          load_raw(arow_c, sb + DB, ra[sb + DB][0], ra[sb + DB][1]);
+        } else if (KC > DB) {
+          load_raw(arow_n, sb + DB - KC, ra[sb + DB - KC][0], ra[sb + DB - KC][1]);
+        }
+        i4v a1, a2, a3;
+        eg_split3(ra[sb][0], ra[sb][1], a1, a2, a3);
+        const int sn = (sb + 1 < KC) ? sb + 1 : 0;
+        // bx[0][0 .. G0) = half X, bx[0][G0 .. NT) = half Y; both hold plane 1 of this block on entry
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          // --- half X: MFMAs of this plane, then refill with the next plane (or plane 1 of the next block) ---
+#pragma unroll
+          for (int g = 0; g < G0; ++g) acc[g] = eg_mfma_bf16(a1, bx[0][g], acc[g]);
+          if (pl < 2) {
+#pragma unroll
+            for (int g = 0; g < G0; ++g) acc[g] = eg_mfma_bf16(a2, bx[0][g], acc[g]);
+          }
+          if (pl < 1) {
+#pragma unroll
+            for (int g = 0; g < G0; ++g) acc[g] = eg_mfma_bf16(a3, bx[0][g], acc[g]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < G0; ++g) {
+            bx[0][g] = (pl < 2) ? wb[(pl + 1) * PLANE + g * 16 * SU + 4 * sb] : wb[g * 16 * SU + 4 * sn];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // --- half Y ---
+#pragma unroll
+          for (int g = G0; g < NT; ++g) acc[g] = eg_mfma_bf16(a1, bx[0][g], acc[g]);
+          if (pl < 2) {
+#pragma unroll
+            for (int g = G0; g < NT; ++g) acc[g] = eg_mfma_bf16(a2, bx[0][g], acc[g]);
+          }
+          if (pl < 1) {
+#pragma unroll
+            for (int g = G0; g < NT; ++g) acc[g] = eg_mfma_bf16(a3, bx[0][g], acc[g]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = G0; g < NT; ++g) {
+            bx[0][g] = (pl < 2) ? wb[(pl + 1) * PLANE + g * 16 * SU + 4 * sb] : wb[g * 16 * SU + 4 * sn];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (KC <= DB) {
+#pragma unroll
+        for (int sb = 0; sb < KC; ++sb) load_raw(arow_n, sb, ra[sb][0], ra[sb][1]);
+      }
+    } else {
     if (!(P.dbg & 2))
 #pragma unroll
-    for (int sb = 0; sb < KC; ++sb) {
-      constexpr int X = 0;                     // buffer roles alternate with the block parity
-      const int bi = sb & 1;                   // holds plane 1 of this block
-      const int bo = bi ^ 1;
-      (void)X;
-      if (sb + DB < KC) {
-        load_raw(arow_c, sb + DB, ra[sb + DB][0], ra[sb + DB][1]);
-      } else if (KC > DB) {
-        load_raw(arow_n, sb + DB - KC, ra[sb + DB - KC][0], ra[sb + DB - KC][1]);
+      for (int sb = 0; sb < KC; ++sb) {
+        constexpr int X = 0;                     // buffer roles alternate with the block parity
+        const int bi = sb & 1;                   // holds plane 1 of this block
+        const int bo = bi ^ 1;
+        (void)X;
+        if (sb + DB < KC) {
+          load_raw(arow_c, sb + DB, ra[sb + DB][0], ra[sb + DB][1]);
+        } else if (KC > DB) {
+          load_raw(arow_n, sb + DB - KC, ra[sb + DB - KC][0], ra[sb + DB - KC][1]);
+        }
+        i4v a1, a2, a3;
+        eg_split3(ra[sb][0], ra[sb][1], a1, a2, a3);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[PLANE + ct * 16 * SU + 4 * sb];            // plane 2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bi][ct], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a3, bx[bi][ct], acc[ct]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) bx[bi][ct] = wb[2 * PLANE + ct * 16 * SU + 4 * sb];        // plane 3
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bo][ct], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bo][ct], acc[ct]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int sn = (sb + 1 < KC) ? sb + 1 : 0;                                              // next plane 1
+#pragma unroll
+          for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[ct * 16 * SU + 4 * sn];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      i4v a1, a2, a3;
-      eg_split3(ra[sb][0], ra[sb][1], a1, a2, a3);
+      if constexpr (KC <= DB) {
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[PLANE + ct * 16 * SU + 4 * sb];            // plane 2
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bi][ct], acc[ct]);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a3, bx[bi][ct], acc[ct]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) bx[bi][ct] = wb[2 * PLANE + ct * 16 * SU + 4 * sb];        // plane 3
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bo][ct], acc[ct]);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a2, bx[bo][ct], acc[ct]);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const int sn = (sb + 1 < KC) ? sb + 1 : 0;                                              // next plane 1
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) bx[bo][ct] = wb[ct * 16 * SU + 4 * sn];
+        for (int sb = 0; sb < KC; ++sb) load_raw(arow_n, sb, ra[sb][0], ra[sb][1]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (KC % 2 == 1) {
+        // an odd number of blocks leaves the next plane 1 in buffer 1: move it where block 0 expects it
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = eg_mfma_bf16(a1, bx[bi][ct], acc[ct]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (KC <= DB) {
-#pragma unroll
-      for (int sb = 0; sb < KC; ++sb) load_raw(arow_n, sb, ra[sb][0], ra[sb][1]);
-    }
-    if constexpr (KC % 2 == 1) {
-      // an odd number of blocks leaves the next plane 1 in buffer 1: move it where block 0 expects it
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) bx[0][ct] = bx[1][ct];
+        for (int ct = 0; ct < NT; ++ct) bx[0][ct] = bx[1][ct];
+      }
     }
 
-    gather_x(bx[1], mn.src);                    // next batch's x rows; bx[1] is idle until the next chain
+    if constexpr (WPS == 2) gather_x(bx[1], mn.src);   // next batch's x rows; bx[1] is idle until the next chain
 
     // ---- fold the tile (it stays in the accumulators) ----
     const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
@@ -1152,6 +1220,16 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(con
     cur = nxt; mc = mn; nxt = nn; mn = mnn; vn = vnn;
     arow_c = arow_n;
   }
+}
+
+template <int NT, int KC, int MODE>
+__global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_bf16_kernel(const EgParams P) {
+  egemm_bf16_body<NT, KC, MODE, 2>(P);
+}
+
+template <int NT, int KC, int MODE>
+__global__ __launch_bounds__(12 * kWave) void egemm_fwd_bf16_w3_kernel(const EgParams P) {
+  egemm_bf16_body<NT, KC, MODE, 3>(P);
 }
 
 // Rows that straddle item boundaries: the item where such a row STARTS (it holds the row's tail partial) owns the
@@ -1215,15 +1293,44 @@ __global__ __launch_bounds__(kWgThreads) void egemm_fixup_kernel(const EgParams 
 }
 
 // item length: one item per wave slot of the chip, a multiple of the 16-edge batch, at least kEgMinItem
-inline int eg_item_len(int n_edges) {
-  const int64_t slots = static_cast<int64_t>(kNumCU) * kEgMaxWaves;
+inline int eg_item_len(int n_edges, int waves_per_cu) {
+  const int64_t slots = static_cast<int64_t>(kNumCU) * waves_per_cu;
   int64_t len = (n_edges + slots - 1) / slots;
   len = (len + kEgM - 1) / kEgM * kEgM;
   return static_cast<int>(len < kEgMinItem ? kEgMinItem : len);
 }
-inline int eg_num_items(int n_edges) {
-  const int len = eg_item_len(n_edges);
+inline int eg_num_items(int n_edges, int waves_per_cu) {
+  const int len = eg_item_len(n_edges, waves_per_cu);
   return (n_edges + len - 1) / len;
+}
+
+// xg[r][c] = x[r][c] + bias[c]: the pipelined kernels gather from it, so the bias costs no register and no add
+__global__ __launch_bounds__(kWgThreads) void eg_bias_rows_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                                  const float* __restrict__ b, float* __restrict__ xg,
+                                                                  int64_t n4, int c4) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t r = i / c4;
+    const int cc = static_cast<int>(i - r * c4) * 4;
+    const f4v xv = *reinterpret_cast<const f4v*>(x + r * x_stride + cc);
+    const f4v bv = *reinterpret_cast<const f4v*>(b + cc);
+    *reinterpret_cast<f4v*>(xg + r * (static_cast<int64_t>(c4) * 4) + cc) = xv + bv;
+  }
+}
+
+// waves per CU of the kernel that serves (n_feat, channels): 12 for the wide pipelined shapes (register-lean variant),
+// 8 for the other pipelined shapes, the LDS-limited count for the generic kernel
+inline bool eg_pipelined_shape(int nt, int kc) {
+  return (nt == 7 && kc == 7) || (nt == 2 && kc == 2) || (nt == 3 && kc == 3) || (nt == 4 && kc == 4) ||
+         (nt == 4 && kc == 2);
+}
+inline int eg_wps(int nt, int mode) {
+  const char* e = getenv("DGCN_EG_WPS");
+  if (e && atoi(e) == 2) return 2;
+  // the register-lean variant pays off where the fold state is small (max: 0.378 -> 0.347 ms at K = 224, C = 112);
+  // the softmax / power folds spill in it and stay on the two-waves layout
+  const bool small_state = mode == DGCN_AGGR_MAX || mode == DGCN_AGGR_ADD || mode == DGCN_AGGR_MEAN;
+  return (nt >= 5 && small_state) ? 3 : 2;
 }
 
 struct EgLayout {
@@ -1245,6 +1352,14 @@ inline bool eg_layout(int n_feat, int channels, EgLayout* L) {
   L->nwaves = nw;
   L->lds_bytes = wbytes + nw * zbytes;
   return true;
+}
+
+inline int eg_waves_per_cu(const EgLayout& L, int msg, int mode) {
+  const int kc = L.kpad / kEgChunk;
+  if (msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, kc) && !getenv("DGCN_EG_GENERIC")) {
+    return eg_wps(L.nt, mode) == 3 ? 12 : kEgMaxWaves;
+  }
+  return L.nwaves;
 }
 
 template <int NT, int KC>
@@ -1283,17 +1398,23 @@ int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
 template <int NT, int KC, int MODE>
 int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
   const size_t lds = static_cast<size_t>(3) * NT * 16 * (4 * KC + 2) * 16;                  // three bf16 weight planes
-  const void* fn = reinterpret_cast<const void*>(egemm_fwd_bf16_kernel<NT, KC, MODE>);
+  const bool w3 = eg_wps(NT, MODE) == 3;
+  const void* fn = w3 ? reinterpret_cast<const void*>(egemm_fwd_bf16_w3_kernel<NT, KC, MODE>)
+                      : reinterpret_cast<const void*>(egemm_fwd_bf16_kernel<NT, KC, MODE>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  int nwaves = kEgMaxWaves;
+  int nwaves = w3 ? 12 : kEgMaxWaves;
   {
     const char* w = getenv("DGCN_EG_WAVES");
-    if (w && atoi(w) >= 1 && atoi(w) <= kEgMaxWaves) nwaves = atoi(w);
+    if (w && atoi(w) >= 1 && atoi(w) <= nwaves) nwaves = atoi(w);
   }
   int grid = (P.n_items + nwaves - 1) / nwaves;
-  if (grid > kNumCU) grid = kNumCU;
-  hipLaunchKernelGGL((egemm_fwd_bf16_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  if (grid > kNumCU) grid = kNumCU;                 // the weight planes fill the LDS: one workgroup per CU
+  if (w3) {
+    hipLaunchKernelGGL((egemm_fwd_bf16_w3_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  } else {
+    hipLaunchKernelGGL((egemm_fwd_bf16_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  }
   return DGCN_OK;
 }
 
@@ -1327,7 +1448,7 @@ int launch_egemm_pipe(const EgParams& P, hipStream_t s) {
 // hidden 64 and 128 (examples/ogb/ogbn_proteins/model.py, ogbg_ppa/model.py).
 int launch_egemm_any(const EgParams& P, const EgLayout& L, hipStream_t s) {
   const int kc = L.kpad / kEgChunk;
-  const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !getenv("DGCN_EG_GENERIC");
+  const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !getenv("DGCN_EG_GENERIC") && eg_pipelined_shape(L.nt, kc);
 #ifdef DGCN_EG_WITH_FP32_PIPE
   const bool fp32_mfma = getenv("DGCN_EG_FP32") != nullptr;    // the fp32-MFMA variant of the same kernel
 #define DGCN_EG_CASE(NTV, KCV)                                                    \
@@ -1365,10 +1486,15 @@ extern "C" int32_t dgcn_gen_aggr_egemm_supported(int32_t n_feat, int32_t channel
   return eg_layout(n_feat, channels, &L) ? 1 : 0;
 }
 
-extern "C" size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t channels) {
-  if (n_edges <= 0 || channels <= 0) return 0;
-  const size_t n_items = static_cast<size_t>(eg_num_items(n_edges));
-  return n_items * (2u * 4u * static_cast<size_t>(channels) * sizeof(float) + kEgInfo * sizeof(int32_t));
+extern "C" size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t n_src, int32_t n_feat,
+                                                          int32_t channels) {
+  EgLayout L;
+  if (n_edges <= 0 || n_src <= 0 || !eg_layout(n_feat, channels, &L)) return 0;
+  // the message kind is not known here: size for the finer of the two possible item cuts
+  const size_t n_items = static_cast<size_t>(eg_num_items(n_edges, 12));
+  const size_t part = n_items * (2u * 4u * static_cast<size_t>(channels) * sizeof(float) + kEgInfo * sizeof(int32_t));
+  const size_t xg = static_cast<size_t>(n_src) * static_cast<size_t>(channels) * sizeof(float);
+  return ((part + 255) & ~static_cast<size_t>(255)) + xg;
 }
 
 extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* erow, const float* x, int64_t x_stride,
@@ -1393,13 +1519,14 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
       !aligned16(x) || x_stride % 4 != 0 || !aligned16(workspace)) {
     return DGCN_E_ALIGN;
   }
-  if (!workspace || workspace_bytes < dgcn_gen_aggr_egemm_fwd_workspace_bytes(g->n_edges, channels)) {
+  if (!workspace || workspace_bytes < dgcn_gen_aggr_egemm_fwd_workspace_bytes(g->n_edges, g->n_src, n_feat, channels)) {
     return DGCN_E_WORKSPACE;
   }
   EgParams P;
   P.n_rows = g->n_dst; P.n_edges = g->n_edges;
-  P.item_len = eg_item_len(g->n_edges);
-  P.n_items = eg_num_items(g->n_edges);
+  const int wpc = eg_waves_per_cu(L, msg, mode);
+  P.item_len = eg_item_len(g->n_edges, wpc);
+  P.n_items = eg_num_items(g->n_edges, wpc);
   P.rowptr = g->rowptr; P.col = g->col; P.eperm = g->eperm; P.erow = erow;
   P.x = x; P.x_stride = x_stride; P.feat = edge_feat; P.feat_stride = feat_stride;
   P.w = enc_weight; P.b = enc_bias;
@@ -1419,6 +1546,19 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
   P.info = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                       static_cast<size_t>(P.n_items) * 2u * 4u * channels * sizeof(float));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  P.xg = x; P.xg_stride = x_stride;
+  if (enc_bias && msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, L.kpad / kEgChunk) && !getenv("DGCN_EG_GENERIC")) {
+    // gather source with the bias folded in, behind the partial-state area of the workspace
+    const size_t n_items12 = static_cast<size_t>(eg_num_items(g->n_edges, 12));
+    const size_t part = n_items12 * (2u * 4u * static_cast<size_t>(channels) * sizeof(float) + kEgInfo * sizeof(int32_t));
+    float* xg = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((part + 255) & ~static_cast<size_t>(255)));
+    const int64_t n4 = static_cast<int64_t>(g->n_src) * (channels / 4);
+    int64_t blocks = (n4 + kWgThreads - 1) / kWgThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(eg_bias_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWgThreads), 0, s, x, x_stride,
+                       enc_bias, xg, n4, channels / 4);
+    P.xg = xg; P.xg_stride = channels;
+  }
   const int rc = launch_egemm_any(P, L, s);
   if (rc != DGCN_OK) return rc;
   const int fg = (P.n_items + kWavesPerWg - 1) / kWavesPerWg;

@@ -186,7 +186,7 @@ class _GenAggregate(torch.autograd.Function):
         if egemm:
             if need_grad:
                 z_save = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)   # z_e, original edge order
-            ws_bytes = lib.dgcn_gen_aggr_egemm_fwd_workspace_bytes(graph.n_edges, C)
+            ws_bytes = lib.dgcn_gen_aggr_egemm_fwd_workspace_bytes(graph.n_edges, graph.n_src, n_feat, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with _lib.device_ctx(dev):
             if egemm:

@@ -203,12 +203,13 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
  *   z_save      [E, channels] or NULL: receives z_e = x[src] + W f_e + b in ORIGINAL edge order; the backward is
  *               then dgcn_gen_aggr_bwd_f32(edge_attr = z_save, flags | DGCN_FLAG_EA_IS_Z), whose grad_edge_attr is
  *               dL/dz_e = the gradient of the (never materialised) edge embedding
- *   workspace   dgcn_gen_aggr_egemm_fwd_workspace_bytes(E, channels) bytes, 16-byte aligned
+ *   workspace   dgcn_gen_aggr_egemm_fwd_workspace_bytes(E, n_src, n_feat, channels) bytes, 16-byte aligned (partial
+ *               row states of the work items + the gather source x + bias)
  * Supported (dgcn_gen_aggr_egemm_supported): channels % 4 == 0, channels <= 128, n_feat % 16 == 0, n_feat <= 256,
  * weight tile + two wave tiles within the 160 KiB LDS; E >= 1.  Everything else as dgcn_gen_aggr_fwd_f32.
  */
 int32_t dgcn_gen_aggr_egemm_supported(int32_t n_feat, int32_t channels);
-size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t channels);
+size_t dgcn_gen_aggr_egemm_fwd_workspace_bytes(int32_t n_edges, int32_t n_src, int32_t n_feat, int32_t channels);
 int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* erow, const float* x, int64_t x_stride,
                                 const float* edge_feat, int64_t feat_stride, const float* enc_weight,
                                 const float* enc_bias, int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
