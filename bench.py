@@ -263,7 +263,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="products")
-    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw"])
+    ap.add_argument("--graph", default="uniform", choices=["uniform", "powerlaw", "local"],
+                    help="uniform / power-law random graphs (every partition references every row: the worst case for the "
+                         "multi-GPU exchange) or 'local': a locality-ordered graph (METIS-like ids; the halo scheme's case)")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--aggr", default="softmax_sg")
     ap.add_argument("--t", type=float, default=0.1)
@@ -306,7 +308,7 @@ def main():
     s = synth.SHAPES[args.shape]
     C = args.channels or s["channels"]
     n = s["n"]
-    gen = synth.undirected_random_graph if args.graph == "uniform" else synth.powerlaw_graph
+    gen = {"uniform": synth.undirected_random_graph, "powerlaw": synth.powerlaw_graph, "local": synth.local_graph}[args.graph]
     ei = gen(n, s["n_undirected"], seed=s["seed"], device=dev)
     E = ei.size(1)
 

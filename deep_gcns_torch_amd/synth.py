@@ -62,6 +62,31 @@ def powerlaw_graph(n: int, n_undirected: int, seed: int, exponent: float = 2.5, 
     return torch.stack([src, dst])
 
 
+def local_graph(n: int, n_undirected: int, seed: int, window: int = 0, far_fraction: float = 0.02, device="cpu",
+                self_loops: bool = True) -> torch.Tensor:
+    """Locality-ordered graph: the node ids are a good ordering (what METIS / RCM give a real graph such as
+    ogbn-products, whose co-purchase neighbourhoods are tight): an edge joins node a to a node within ``window`` ids
+    of it, except a small ``far_fraction`` of uniformly random long-range edges.  Destination partitions of such a graph
+    reference few remote source rows, which is the regime the halo exchange scheme (dist.HaloGraph) is built for; the
+    uniform graph above is the opposite extreme (every partition references every row)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if window <= 0:
+        window = max(64, n // 256)
+    a = torch.randint(0, n, (n_undirected,), generator=g, device=device)
+    off = torch.randint(1, window + 1, (n_undirected,), generator=g, device=device)
+    sign = torch.randint(0, 2, (n_undirected,), generator=g, device=device) * 2 - 1
+    b = (a + sign * off).clamp_(0, n - 1)
+    far = torch.rand(n_undirected, generator=g, device=device) < far_fraction
+    b = torch.where(far, torch.randint(0, n, (n_undirected,), generator=g, device=device), b)
+    src = torch.cat([a, b])
+    dst = torch.cat([b, a])
+    if self_loops:
+        loop = torch.arange(n, device=device)
+        src = torch.cat([src, loop])
+        dst = torch.cat([dst, loop])
+    return torch.stack([src, dst])
+
+
 # named shapes (BASELINE.md §2)
 SHAPES = {
     "arxiv": dict(n=169_343, n_undirected=1_157_799, channels=128, seed=3),       # E = 2,484,941

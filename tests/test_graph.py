@@ -88,3 +88,24 @@ def test_empty_and_rectangular():
     g = Graph(src, dst, 5, 3)
     assert g.rowptr.tolist() == [0, 1, 3, 4] and g.col.tolist() == [4, 4, 0, 2]
     assert g.t_rowptr.tolist() == [0, 1, 1, 2, 2, 4] and g.t_col.tolist() == [1, 2, 1, 0]
+
+
+def test_locality_ordered_synthetic_graph_keeps_partitions_mostly_local():
+    """bench.py --graph local: symmetric, in range, and a destination partition references few remote rows
+    (the uniform graph references nearly all of them)."""
+    from deep_gcns_torch_amd import synth
+    n = 20000
+    ei = synth.local_graph(n, 200_000, seed=3)
+    assert ei.shape == (2, 2 * 200_000 + n) and int(ei.min()) >= 0 and int(ei.max()) < n
+    fwd = set(map(tuple, ei.t()[:1000].tolist()))
+    rev = set(map(tuple, ei.flip(0).t().tolist()))
+    assert fwd <= rev                                                   # every edge has its reverse
+    lo, hi = n // 4, n // 2
+
+    def remote_rows(e):
+        s = e[0][(e[1] >= lo) & (e[1] < hi)]
+        return torch.unique(s[(s < lo) | (s >= hi)]).numel()
+
+    uniform = synth.undirected_random_graph(n, 200_000, seed=3)
+    assert remote_rows(ei) < 0.5 * (hi - lo)
+    assert remote_rows(uniform) > 2 * (hi - lo)
