@@ -109,7 +109,11 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
                 load_vec_i<VEC>(ai[u], static_cast<const int32_t*>(P.aux1) + ro);
               }
               if constexpr (EA == 1) {
-                load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
+                // max over saved pre-activations: the forward marked the channels without a positive neighbour in the
+                // arg-max ids, so the relu mask is known without reading z (P.ea may be null)
+                if (!(MODE == DGCN_AGGR_MAX && ea_is_z)) {
+                  load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
+                }
               }
               if constexpr (EA == 2) enc_feat_row(fe[u], P.enc_feat, eid[u]);
             }
@@ -136,7 +140,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
             for (int j = 0; j < VEC; ++j) {
               const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];   // xs == 0 when the edge rows are z itself
               const float m = msg_apply(z, msg, eps);
-              const float r = (msg == DGCN_MSG_RELU_EPS) ? (z > 0.f ? 1.f : 0.f) : 1.f;
+              const float r = (msg == DGCN_MSG_RELU_EPS && !(MODE == DGCN_AGGR_MAX && ea_is_z)) ? (z > 0.f ? 1.f : 0.f) : 1.f;
               float k;
               if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
                 float wgt = fast_exp(t * m - a1[u][j]);
@@ -321,7 +325,7 @@ void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
       return;
     }
   }
-  if (P.ea) {
+  if (P.ea || P.ea_is_z) {
     hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 1>), dim3(grid), dim3(kWgThreads), 0, s, P);
   } else {
     hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 0>), dim3(grid), dim3(kWgThreads), 0, s, P);
@@ -370,8 +374,9 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                       float* grad_x, float* grad_edge_attr, void* workspace,
                       size_t workspace_bytes, void* stream) {
   const bool ea_is_z = (flags & DGCN_FLAG_EA_IS_Z) != 0;
-  if (ea_is_z && (!edge_attr || enc)) return DGCN_E_MODE;
-  if (ea_is_z && !x) { x = edge_attr; x_stride = channels; }    // never read: the rows of edge_attr are z_e itself
+  // max needs no pre-activations at all (the forward's arg-max ids carry the relu mask): edge_attr may be NULL there
+  if (ea_is_z && (enc || (!edge_attr && mode != DGCN_AGGR_MAX))) return DGCN_E_MODE;
+  if (ea_is_z && !x) { x = gcoef; x_stride = channels; }        // never read: the rows of edge_attr are z_e itself
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
   if (const int rc = enc_check(enc, channels)) return rc;
   if (enc && !enc_gpart) return DGCN_E_NULL;

@@ -79,8 +79,12 @@ struct EgParams {
 
 // ---- state -> result ------------------------------------------------------------------------------------------
 // (same formulas as the epilogue of gen_aggr_fwd_kernel; the softmax sums arrive already corrected for eps)
+__device__ __forceinline__ float eg_dead_at(const EgParams& P) {
+  return P.msg == DGCN_MSG_RELU_EPS ? P.eps : DGCN_NEG_INF;
+}
+
 template <int MODE, int VEC>
-__device__ __forceinline__ void eg_finalize(const State<VEC>& st, float deg, float p, float (&res)[VEC],
+__device__ __forceinline__ void eg_finalize(const State<VEC>& st, float deg, float p, float dead_at, float (&res)[VEC],
                                             float (&x1)[VEC], float (&x2)[VEC], int (&xi)[VEC], bool& out_of_range) {
   out_of_range = false;
 #pragma unroll
@@ -101,7 +105,9 @@ __device__ __forceinline__ void eg_finalize(const State<VEC>& st, float deg, flo
       x2[j] = st.d[j];
     } else if constexpr (MODE == DGCN_AGGR_MAX) {
       res[j] = st.idx[j] >= 0 ? st.a[j] : 0.f;
-      xi[j] = st.idx[j];
+      // m = relu(z) + eps equals eps exactly where no neighbour has z > 0: no edge receives a gradient there, and
+      // saying so in the arg-max id lets the backward run without the pre-activations (z_save is not needed for max)
+      xi[j] = st.a[j] > dead_at ? st.idx[j] : -1;
     } else if constexpr (MODE == DGCN_AGGR_MEAN) {
       res[j] = st.b[j] / fmaxf(deg, 1.f);
     } else {
@@ -116,7 +122,7 @@ __device__ __forceinline__ void eg_write_row(const EgParams& P, int row, int c0,
   float res[VEC], x1[VEC], x2[VEC];
   int xi[VEC];
   bool oor;
-  eg_finalize<MODE, VEC>(st, deg, p, res, x1, x2, xi, oor);
+  eg_finalize<MODE, VEC>(st, deg, p, eg_dead_at(P), res, x1, x2, xi, oor);
   const int64_t o = static_cast<int64_t>(row) * P.C + c0;
   if (P.add_root) {
     float xr[VEC];
@@ -542,7 +548,7 @@ __device__ __forceinline__ void egd_write_row(const EgParams& P, int row, int n,
   float res[NT], x1[NT], x2[NT];
   int xi[NT];
   bool oor;
-  eg_finalize<MODE, NT>(st, deg, p, res, x1, x2, xi, oor);
+  eg_finalize<MODE, NT>(st, deg, p, eg_dead_at(P), res, x1, x2, xi, oor);
   if (!writer) return;
   bool flag = false;
 #pragma unroll

@@ -184,7 +184,7 @@ class _GenAggregate(torch.autograd.Function):
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
         z_save = None
         if egemm:
-            if need_grad:
+            if need_grad and mode != _lib.AGGR_MAX:    # max: the arg-max ids carry all the backward needs
                 z_save = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)   # z_e, original edge order
             ws_bytes = lib.dgcn_gen_aggr_egemm_fwd_workspace_bytes(graph.n_edges, graph.n_src, n_feat, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
@@ -263,7 +263,7 @@ class _GenAggregate(torch.autograd.Function):
                 (enc is not None and any(ctx.needs_input_grad[15:17])):
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
-            if edge_attr is not None and (ctx.needs_input_grad[1] or need_dz):
+            if (edge_attr is not None or egemm) and (ctx.needs_input_grad[1] or need_dz):
                 grad_ea = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None

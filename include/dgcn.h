@@ -52,7 +52,9 @@ extern "C" {
 #define DGCN_FLAG_SHIFT_FLAG_IS_RANGE 8 /* backward: shift_ok points at the forward's range_flag (0 = safe), not at an "ok" flag */
 #define DGCN_FLAG_ADD_ROOT 4 /* forward: out_i += x_i, the h = x + m of GENConv.forward (torch_vertex.py:74) fused in */
 #define DGCN_FLAG_EA_IS_Z 16 /* backward: the rows of edge_attr are the pre-activations z_e themselves (saved by
-                                dgcn_gen_aggr_egemm_fwd_f32), x is not gathered (may be NULL) */
+                                dgcn_gen_aggr_egemm_fwd_f32), x is not gathered (may be NULL).  With DGCN_AGGR_MAX the
+                                rows are not read either (edge_attr may be NULL, no z_save needed): that forward marks
+                                the channels whose best neighbour has z <= 0 with arg-max id -1 */
 
 /*
  * Graph structure, built once per distinct edge_index and reused by every layer
@@ -202,7 +204,8 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
  *   enc_weight  [channels, n_feat] contiguous (nn.Linear.weight), enc_bias [channels] or NULL
  *   z_save      [E, channels] or NULL: receives z_e = x[src] + W f_e + b in ORIGINAL edge order; the backward is
  *               then dgcn_gen_aggr_bwd_f32(edge_attr = z_save, flags | DGCN_FLAG_EA_IS_Z), whose grad_edge_attr is
- *               dL/dz_e = the gradient of the (never materialised) edge embedding
+ *               dL/dz_e = the gradient of the (never materialised) edge embedding.  DGCN_AGGR_MAX: pass NULL here and
+ *               NULL as the backward's edge_attr (aux1 is enough)
  *   workspace   dgcn_gen_aggr_egemm_fwd_workspace_bytes(E, n_src, n_feat, channels) bytes, 16-byte aligned (partial
  *               row states of the work items + the gather source x + bias)
  * Supported (dgcn_gen_aggr_egemm_supported): channels % 4 == 0, channels <= 128, n_feat % 16 == 0, n_feat <= 256,

@@ -145,9 +145,12 @@ def test_sparse_edgconv_every_option_of_the_reference(aggr, norm, act):
     (out * probe.to(dev)).sum().backward()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()) + 1e-6)
+    # one scale for all parameters: the bias in front of a BatchNorm has a gradient of exactly zero in real numbers
+    # (rounding noise in both implementations), so its own magnitude is no yardstick
+    scale = max(float(g.abs().max()) for g in ref_grads.values())
     for k, p in md.named_parameters():
         g = ref_grads[k]
-        torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-3, atol=2e-4 * float(g.abs().max()) + 1e-6)
+        torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-3, atol=2e-4 * scale + 1e-6)
 
 
 def test_ragged_batches_through_knn_graph():
