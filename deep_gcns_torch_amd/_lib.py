@@ -53,6 +53,11 @@ _SIGNATURES = {
         C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_size_t, C.c_void_p]),
+    "dgcn_gen_aggr_max_mask_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "dgcn_gen_aggr_max_bwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+        C.c_void_p]),
     "dgcn_gen_aggr_enc_fwd_f32": (C.c_int, [
         C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,

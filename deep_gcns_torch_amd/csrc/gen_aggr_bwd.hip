@@ -45,6 +45,36 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   const int msg = P.msg;
   const bool learn_t = P.learn_t != 0;
   const bool ea_is_z = (EA == 1) && P.ea_is_z != 0;
+  // MAX without edge rows: per-edge arg-max bit masks (<= 4 words) travel with the column ids -- loaded one item ahead,
+  // parked in LDS per block, read back per edge with one ds_read instead of a dependent global gather
+  constexpr bool MASKP = (MODE == DGCN_AGGR_MAX) && (EA == 0);
+  __shared__ uint32_t smask[MASKP ? kWavesPerWg * kWave * 4 : 1];
+  const bool mask_lds = MASKP && P.maxmask != nullptr && P.mask_words <= 4;
+  uint32_t* my_smask = smask + (MASKP ? (threadIdx.x >> 6) * kWave * 4 : 0);
+  auto load_mask = [&](const Work& ww, int blk, int cpos, uint32_t (&mk)[4]) {
+    mk[0] = mk[1] = mk[2] = mk[3] = 0u;
+    if (mask_lds && sl < ww.end - blk) {
+      const uint32_t* mp = P.maxmask + static_cast<int64_t>(cpos) * P.mask_words;
+      if (P.mask_words == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(mp);
+        mk[0] = v.x; mk[1] = v.y; mk[2] = v.z; mk[3] = v.w;
+      } else if (P.mask_words == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(mp);
+        mk[0] = v.x; mk[1] = v.y;
+      } else {
+        mk[0] = mp[0];
+      }
+    }
+  };
+  auto park_mask = [&](const uint32_t (&mk)[4]) {
+    if (mask_lds) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                 // earlier reads of the previous block are done
+      *reinterpret_cast<uint4*>(my_smask + lane * 4) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
 
   // same software pipeline over items as in the forward kernel
   const int stride = total_waves * R;
@@ -53,10 +83,13 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   Work wn = fetch_work<SW>(P.g, wave0 * R + stride + sub, n_items);
   int col0, eid0;
   load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+  uint32_t mk0[4], mkn[4];
+  if constexpr (MASKP) load_mask(w, w.beg, eid0, mk0);
   for (int base = wave0 * R; base < n_items; base += stride) {
 #ifndef DGCN_NO_PREFETCH_BWD
     int coln, eidn;
     load_cols<SW, NEED_EID>(P.g, wn, wn.beg, sl, coln, eidn);
+    if constexpr (MASKP) load_mask(wn, wn.beg, eidn, mkn);
     const Work wnn = fetch_work<SW>(P.g, base + 2 * stride + sub, n_items);
 #endif
     for (int cb = 0; cb < C; cb += LPR * VEC) {
@@ -75,6 +108,15 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
       for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
         const int nb = max(0, min(SW, w.end - blk));
         if (blk != w.beg) load_cols<SW, NEED_EID>(P.g, w, blk, sl, mycol, myeid);
+        if constexpr (MASKP) {
+          if (blk != w.beg) {
+            uint32_t mkb[4];
+            load_mask(w, blk, myeid, mkb);
+            park_mask(mkb);
+          } else {
+            park_mask(mk0);
+          }
+        }
         for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
           float gc[U][VEC], a1[U][VEC], oo[U][VEC], ea[U][VEC];
           float fe[(EA == 2) ? U : 1][kEncF];
@@ -106,7 +148,20 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
                 if (learn_t) load_vec<VEC>(oo[u], P.out + ro);
               }
               if constexpr (MODE == DGCN_AGGR_MAX) {
-                load_vec_i<VEC>(ai[u], static_cast<const int32_t*>(P.aux1) + ro);
+                if (P.maxmask) {
+                  // 4 bytes of this edge's arg-max bit mask (eid is its CSR position here) instead of 4 VEC bytes of
+                  // the destination's arg-max row: the VEC bits of a lane never straddle a word (c0 % VEC == 0)
+                  uint32_t word;
+                  if (MASKP && mask_lds) {
+                    word = my_smask[(sbase + (ei & (SW - 1))) * 4 + (c0 >> 5)];
+                  } else {
+                    word = P.maxmask[static_cast<int64_t>(eid[u]) * P.mask_words + (c0 >> 5)];
+                  }
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) ai[u][j] = ((word >> ((c0 & 31) + j)) & 1u) ? eid[u] : -1;
+                } else {
+                  load_vec_i<VEC>(ai[u], static_cast<const int32_t*>(P.aux1) + ro);
+                }
               }
               if constexpr (EA == 1) {
                 // max over saved pre-activations: the forward marked the channels without a positive neighbour in the
@@ -203,9 +258,11 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
     wn = wnn;
     col0 = coln;
     eid0 = eidn;
+    if constexpr (MASKP) { mk0[0] = mkn[0]; mk0[1] = mkn[1]; mk0[2] = mkn[2]; mk0[3] = mkn[3]; }
 #else
     w = fetch_work<SW>(P.g, base + stride + sub, n_items);
     load_cols<SW, NEED_EID>(P.g, w, w.beg, sl, col0, eid0);
+    if constexpr (MASKP) load_mask(w, w.beg, eid0, mk0);
 #endif
   }
 
@@ -365,6 +422,82 @@ int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
   return grid;
 }
 
+// Arg-max bit masks for the max backward: bit c of mask[p] says whether CSR position p is the arg-max of its destination
+// row in channel c.  One wave per destination row, lane = channel: the arg-max edge id is located among the row's
+// (ascending) original edge ids by bisection, OR-ed into an LDS tile of the row's 64-edge chunk, and the chunk's masks
+// leave with one coalesced store per lane.  Work ~ rows x channels (the winners), not edges x channels.
+template <int W>
+__global__ __launch_bounds__(kWgThreads) void max_mask_build_kernel(const int32_t* __restrict__ argmax,
+                                                                    const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ eperm, int n_rows, int C,
+                                                                    uint32_t* __restrict__ mask) {
+  constexpr int KC = (W + 1) / 2;
+  __shared__ uint32_t tile_all[kWavesPerWg][kWave * W];
+  uint32_t* tile = tile_all[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const int total_waves = gridDim.x * kWavesPerWg;
+  for (int row = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6); row < n_rows; row += total_waves) {
+    const int beg = uni(rowptr[row]), end = uni(rowptr[row + 1]);
+    if (beg == end) continue;
+    int pos[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int c = lane + 64 * k;
+      const int a = (c < C) ? argmax[static_cast<int64_t>(row) * C + c] : -1;
+      int p = -1;
+      if (a >= 0) {
+        if (!eperm) {
+          p = a;                                   // destination-sorted input: CSR position == original edge id
+        } else {
+          int lo = beg, hi = end - 1;              // eperm[beg..end) ascends (stable sort); a is one of them
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (eperm[mid] < a) lo = mid + 1; else hi = mid;
+          }
+          p = lo;
+        }
+      }
+      pos[k] = p;
+    }
+    for (int chunk = beg; chunk < end; chunk += kWave) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < W; ++q) tile[lane * W + q] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int c = lane + 64 * k;
+        const int rel = pos[k] - chunk;
+        if (pos[k] >= 0 && rel >= 0 && rel < kWave) atomicOr(&tile[rel * W + (c >> 5)], 1u << (c & 31));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (chunk + lane < end) {
+        uint32_t* o = mask + static_cast<int64_t>(chunk + lane) * W;
+        if constexpr (W >= 4) {
+#pragma unroll
+          for (int q = 0; q < W; q += 4) {
+            *reinterpret_cast<uint4*>(o + q) =
+                make_uint4(tile[lane * W + q], tile[lane * W + q + 1], tile[lane * W + q + 2], tile[lane * W + q + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < W; ++q) o[q] = tile[lane * W + q];
+        }
+      }
+    }
+  }
+}
+
+inline int max_mask_words(int channels) {
+  const int need = (channels + 31) / 32;
+  int w = 1;
+  while (w < need) w <<= 1;
+  return w;   // 1, 2, 4 or 8 (channels <= 256)
+}
+
 int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                       const float* edge_attr, const EncArgs* enc, float* enc_gpart, int32_t channels, int32_t mode,
                       int32_t msg, int32_t flags, float t, float p, float eps,
@@ -372,7 +505,8 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                       const void* aux1, const float* out, const float* gshift,
                       const float* kshift, const int32_t* shift_ok, const float* groot,
                       float* grad_x, float* grad_edge_attr, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+                      size_t workspace_bytes, void* stream, const uint32_t* maxmask = nullptr,
+                      const int32_t* t_cpos = nullptr) {
   const bool ea_is_z = (flags & DGCN_FLAG_EA_IS_Z) != 0;
   // max needs no pre-activations at all (the forward's arg-max ids carry the relu mask): edge_attr may be NULL there
   if (ea_is_z && (enc || (!edge_attr && mode != DGCN_AGGR_MAX))) return DGCN_E_MODE;
@@ -415,6 +549,12 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.enc_b = enc ? enc->b : nullptr;
   P.enc_gpart = enc_gpart;
   P.n_edges_hint = g->n_edges;
+  P.maxmask = nullptr; P.mask_words = 0;
+  if (maxmask) {
+    if (mode != DGCN_AGGR_MAX || edge_attr || enc || ea_is_z || !t_cpos || channels > 256) return DGCN_E_MODE;
+    P.maxmask = maxmask; P.mask_words = max_mask_words(channels);
+    P.g.eperm = t_cpos;            // the walk's "edge id" is the CSR position: the index of the mask rows
+  }
   if (enc && !vec4) return DGCN_E_ALIGN;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
@@ -484,6 +624,35 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
   return gen_aggr_bwd_impl(g, x, x_stride, edge_attr, nullptr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev,
                            p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, grad_edge_attr,
                            workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t dgcn_gen_aggr_max_mask_bytes(int32_t n_edges, int32_t channels) {
+  if (n_edges <= 0 || channels <= 0 || channels > 256) return 0;
+  return static_cast<size_t>(n_edges) * max_mask_words(channels) * sizeof(uint32_t);
+}
+
+extern "C" int dgcn_gen_aggr_max_bwd_f32(const dgcn_graph* g, const int32_t* t_cpos, const float* x, int64_t x_stride,
+                                         int32_t channels, int32_t msg, int32_t flags, float eps, const float* gcoef,
+                                         const int32_t* argmax, const float* groot, float* grad_x, void* mask,
+                                         size_t mask_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !t_cpos || !argmax || !mask || !g->rowptr) return DGCN_E_NULL;
+  if (channels <= 0 || channels > 256 || g->n_edges <= 0 || g->n_dst <= 0) return DGCN_E_SHAPE;
+  if (mask_bytes < dgcn_gen_aggr_max_mask_bytes(g->n_edges, channels)) return DGCN_E_WORKSPACE;
+  if (!aligned16(mask)) return DGCN_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int W = max_mask_words(channels);
+  uint32_t* m = static_cast<uint32_t*>(mask);
+  const dim3 grid(static_cast<unsigned>(grid_for_waves(g->n_dst))), wg(kWgThreads);
+  switch (W) {
+    case 1: hipLaunchKernelGGL(max_mask_build_kernel<1>, grid, wg, 0, s, argmax, g->rowptr, g->eperm, g->n_dst, channels, m); break;
+    case 2: hipLaunchKernelGGL(max_mask_build_kernel<2>, grid, wg, 0, s, argmax, g->rowptr, g->eperm, g->n_dst, channels, m); break;
+    case 4: hipLaunchKernelGGL(max_mask_build_kernel<4>, grid, wg, 0, s, argmax, g->rowptr, g->eperm, g->n_dst, channels, m); break;
+    default: hipLaunchKernelGGL(max_mask_build_kernel<8>, grid, wg, 0, s, argmax, g->rowptr, g->eperm, g->n_dst, channels, m); break;
+  }
+  if (const int rc = launch_status()) return rc;
+  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, nullptr, nullptr, channels, DGCN_AGGR_MAX, msg, flags, 1.f, 1.f, eps,
+                           nullptr, nullptr, gcoef, argmax, nullptr, nullptr, nullptr, nullptr, groot, grad_x, nullptr,
+                           workspace, workspace_bytes, stream, m, t_cpos);
 }
 
 extern "C" int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels) {

@@ -80,6 +80,10 @@ struct BwdParams {
   float* grad_x;
   float* grad_ea;
   int n_edges_hint;       // edges of the walk (layout choice only)
+  // MAX fast path: per-edge arg-max bit masks [E][mask_words] indexed by CSR position (bit c of edge p set iff p is
+  // the arg-max of its destination row in channel c); g.eperm then holds the CSR position of every CSC position
+  const uint32_t* maxmask;
+  int mask_words;
   float* ws;  // partial slots: [slot][C]
 };
 

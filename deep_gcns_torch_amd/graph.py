@@ -186,6 +186,21 @@ class Graph:
         return t
 
     @property
+    def t_cpos(self) -> torch.Tensor:
+        """CSR position of every CSC position (int32 [E]): the index the source-keyed walk uses into per-edge arrays kept
+        in destination order (the arg-max bit masks of the max backward).  Built on first use."""
+        t = getattr(self, "_t_cpos", None)
+        if t is None:
+            if self.eperm is None:                       # destination-sorted input: CSR position == original edge id
+                t = self.t_eperm
+            else:
+                inv = torch.empty(self.n_edges, device=self.device, dtype=torch.int32)
+                inv[self.eperm.long()] = torch.arange(self.n_edges, device=self.device, dtype=torch.int32)
+                t = inv[self.t_eperm.long()].contiguous()
+            self._t_cpos = t
+        return t
+
+    @property
     def c_struct(self):
         return C.byref(self._c)
 

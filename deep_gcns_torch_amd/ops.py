@@ -26,6 +26,8 @@ ENC_FEATURES = 8                   # raw edge features of the fused edge encoder
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
+MAX_MASK_MIN_EDGES = 1 << 16       # max backward through per-edge arg-max bit masks (two launches) from this many
+                                   # edges on; below, the one-launch walk over gathered arg-max rows
 
 
 def _scalar_arg(v):
@@ -293,6 +295,16 @@ class _GenAggregate(torch.autograd.Function):
                         _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+                elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
+                        graph.n_edges >= MAX_MASK_MIN_EDGES and graph.n_dst > 0:
+                    # arg-max bit masks per edge instead of gathered arg-max rows: a third of the bytes on big graphs
+                    mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
+                    mask = torch.empty(mbytes, device=dev, dtype=torch.uint8)
+                    rc = lib.dgcn_gen_aggr_max_bwd_f32(
+                        graph.c_struct, graph.t_cpos.data_ptr(), x.data_ptr(), x.stride(0), C,
+                        ctx.msg, bwd_flags, ctx.eps, gcoef.data_ptr(), aux1.data_ptr(),
+                        g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(), mask.data_ptr(), mbytes,
+                        _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
                 else:
                     rc = lib.dgcn_gen_aggr_bwd_f32(
                         graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, ctx.msg,

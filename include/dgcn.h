@@ -162,6 +162,28 @@ int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
                           void* stream);
 
 /*
+ * Max aggregation without edge rows, the backward in two launches that move a fraction of the bytes
+ * (scatter_('max') backward of torch_scatter under GenMessagePassing.aggregate, gcn_lib/sparse/torch_message.py:83;
+ * MRConv / EdgConv, gcn_lib/sparse/torch_vertex.py:102,111):
+ *   1. per-edge arg-max bit masks: bit c of mask[p] (p = CSR position, ceil(C/32) rounded up to 1|2|4|8 words) says
+ *      whether edge p is the arg-max of its destination row in channel c -- one wave per destination row locates the
+ *      rows' winners (work ~ rows x channels, not edges x channels);
+ *   2. the CSC walk of dgcn_gen_aggr_bwd_f32 reading 4 mask bytes per (edge, 32 channels) -- fetched with the column
+ *      ids one item ahead and parked in LDS -- instead of gathering the 4 C bytes of the destination's arg-max row, and
+ *      fetching g only where a bit is set.
+ *   t_cpos  [E] CSR position of every CSC position (the CSC walk's index into the masks)
+ *   argmax  [n_dst, C] as written by the forward (aux1), gcoef = the upstream gradient, groot / grad_x as above
+ *   mask    dgcn_gen_aggr_max_mask_bytes(E, C) bytes of scratch, 16-byte aligned; workspace as dgcn_gen_aggr_bwd_f32
+ * Bit-identical to dgcn_gen_aggr_bwd_f32(mode = DGCN_AGGR_MAX).  channels <= 256.
+ */
+size_t dgcn_gen_aggr_max_mask_bytes(int32_t n_edges, int32_t channels);
+
+int dgcn_gen_aggr_max_bwd_f32(const dgcn_graph* g, const int32_t* t_cpos, const float* x, int64_t x_stride,
+                              int32_t channels, int32_t msg, int32_t flags, float eps, const float* gcoef,
+                              const int32_t* argmax, const float* groot, float* grad_x, void* mask, size_t mask_bytes,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The same aggregation with the edge encoder of GENConv(encode_edge=True) fused in
  * (gcn_lib/sparse/torch_vertex.py:56-66: edge_emb = Linear(edge_feat_dim -> C)(edge_attr), then
  * message = relu(x_j + edge_emb) + eps): the (E, C) edge embedding is never built; every edge recomputes its row
