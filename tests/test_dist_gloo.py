@@ -15,6 +15,25 @@ from deep_gcns_torch_amd.dist import (HaloGraph, PartitionedGraph, TransposedGra
                                       transposed_gen_aggregate, transposed_supported)
 
 
+def _pack(obj):
+    """Tensors cross the queue BY VALUE (numpy), not through torch's file-descriptor sharing: a rank that exits before
+    the parent unpickles its result would otherwise take the shared storage's socket with it (flaky FileNotFoundError)."""
+    if isinstance(obj, torch.Tensor):
+        return ("__tensor__", obj.detach().cpu().numpy())
+    if isinstance(obj, tuple):
+        return tuple(_pack(o) for o in obj)
+    return obj
+
+
+def _unpack(obj):
+    if isinstance(obj, tuple):
+        if len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+            return torch.from_numpy(obj[1])
+        return tuple(_unpack(o) for o in obj)
+    return obj
+
+
+
 def _retry_rendezvous(times=3):
     """Multi-process tests rendezvous on a freshly picked local port; on a busy host that can lose a race (port
     taken between probing and binding, slow spawn).  Re-run with a new port before reporting a failure."""
@@ -70,7 +89,7 @@ def _worker(rank, world, port, aggr, kw, q, chunks=1):
         xl = x[part.lo:part.hi].clone().requires_grad_(True)
         out = partitioned_gen_aggregate(xl, part, aggr=aggr, local_aggregate=_oracle_local, pipeline_chunks=chunks, **kw)
         (out * probe[part.lo:part.hi]).sum().backward()
-        q.put((rank, part.bounds, out.detach(), xl.grad.detach(), part.n_local_edges))
+        q.put(_pack((rank, part.bounds, out.detach(), xl.grad.detach(), part.n_local_edges)))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -88,7 +107,7 @@ def test_partitioned_aggregate_world2_matches_single_process(aggr, kw, chunks):
     procs = [ctx.Process(target=_worker, args=(r, world, port, aggr, kw, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -134,8 +153,8 @@ def _worker_params(rank, world, port, case, q, chunks):
         (out * probe[part.lo:part.hi]).sum().backward()
         gt = t.grad.clone()
         dist.all_reduce(gt)                     # replicated parameter: per-rank gradients are summed by the caller
-        q.put((rank, out.detach(), None if xl.grad is None else xl.grad.detach(), gt,
-               None if ea_l is None else (part.edge_mask.nonzero().flatten(), ea_l.grad.detach())))
+        q.put(_pack((rank, out.detach(), None if xl.grad is None else xl.grad.detach(), gt,
+               None if ea_l is None else (part.edge_mask.nonzero().flatten(), ea_l.grad.detach()))))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -152,7 +171,7 @@ def test_partitioned_aggregate_keeps_parameter_and_edge_gradients(case):
     procs = [ctx.Process(target=_worker_params, args=(r, world, port, case, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -222,7 +241,7 @@ def _worker_transposed(rank, world, port, aggr, kw, q, chunks, node_groups=1):
         xl = x[tg.lo:tg.hi].clone().requires_grad_(True)
         out = transposed_gen_aggregate(xl, tg, aggr=aggr, local_aggregate=_oracle_local, pipeline_chunks=chunks, **kw)
         (out * probe[tg.lo:tg.hi]).sum().backward()
-        q.put((rank, tg.bounds, out.detach(), xl.grad.detach(), tg.max_rows, tg.n_edges))
+        q.put(_pack((rank, tg.bounds, out.detach(), xl.grad.detach(), tg.max_rows, tg.n_edges)))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -242,7 +261,7 @@ def test_channel_transposed_aggregate_world2_matches_single_process(aggr, kw, ch
     procs = [ctx.Process(target=_worker_transposed, args=(r, world, port, aggr, kw, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -291,7 +310,7 @@ def test_two_dimensional_transposed_aggregate_matches_single_process(world, node
              for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_unpack(q.get(timeout=180)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -334,7 +353,7 @@ def _worker_halo(rank, world, port, aggr, kw, q):
         xl = x[hg.lo:hg.hi].clone().requires_grad_(True)
         out = halo_gen_aggregate(xl, hg, aggr=aggr, local_aggregate=_oracle_local, **kw)
         (out * probe[hg.lo:hg.hi]).sum().backward()
-        q.put((rank, hg.bounds, out.detach(), xl.grad.detach(), hg.n_halo, hg.n_local, sum(hg.send_counts)))
+        q.put(_pack((rank, hg.bounds, out.detach(), xl.grad.detach(), hg.n_halo, hg.n_local, sum(hg.send_counts))))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -351,7 +370,7 @@ def test_halo_exchange_matches_single_process(world, aggr, kw):
     procs = [ctx.Process(target=_worker_halo, args=(r, world, port, aggr, kw, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([_unpack(q.get(timeout=180)) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
