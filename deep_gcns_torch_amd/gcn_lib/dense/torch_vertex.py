@@ -7,7 +7,7 @@ from torch import nn
 
 from ... import dense_ops
 from .torch_edge import DenseDilatedKnnGraph, DilatedKnnGraph
-from .torch_nn import BasicConv
+from .torch_nn import BasicConv, batched_index_select
 
 __all__ = ["MRConv2d", "EdgeConv2d", "GraphConv2d", "DynConv2d", "PlainDynBlock2d", "ResDynBlock2d",
            "DenseDynBlock2d"]
@@ -57,11 +57,21 @@ class EdgeConv2d(nn.Module):
     def __init__(self, in_channels, out_channels, act='relu', norm=None, bias=True):
         super().__init__()
         self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
-        if any(isinstance(m, nn.InstanceNorm2d) for m in self.nn):
-            raise NotImplementedError("EdgeConv2d: norm='instance' is not supported by the fused kernel")
-        _act_code(self.nn)
+        # instance norm (statistics per sample) and PReLU (a learnable slope inside the batch statistics) do not fit
+        # the vertex split: those two options run the reference's per-edge formulation (gcn_lib/dense/torch_vertex.py:
+        # 45-53) on library ops -- same results and the reference's (B, 2C, N, k) memory, no fused kernel
+        self._per_edge = any(isinstance(m, (nn.InstanceNorm2d, nn.PReLU)) for m in self.nn)
+        if not self._per_edge:
+            _act_code(self.nn)
+
+    def _forward_per_edge(self, x, edge_index):
+        x_i = batched_index_select(x, edge_index[1])
+        x_j = batched_index_select(x, edge_index[0])
+        return torch.max(self.nn(torch.cat([x_i, x_j - x_i], dim=1)), -1, keepdim=True)[0]
 
     def forward(self, x, edge_index):
+        if self._per_edge:
+            return self._forward_per_edge(x, edge_index)
         dense_ops.check_centres(edge_index)
         conv = self.nn[0]
         act, slope = _act_code(self.nn)

@@ -182,3 +182,32 @@ def test_ragged_batches_through_knn_graph():
         torch.testing.assert_close(got, want, rtol=0, atol=1e-9)
         start += n
 
+
+
+@pytest.mark.parametrize("act,norm", [("relu", "instance"), ("prelu", "batch"), ("prelu", None)])
+def test_dense_edgeconv_options_outside_the_vertex_split(act, norm):
+    """EdgeConv2d(norm='instance') / act='prelu' (gcn_lib/dense/torch_nn.py:9-33) run the reference's per-edge
+    formulation on library ops: compared with the same stack evaluated on the CPU, parameters and their gradients too."""
+    import copy
+    from gcn_lib.dense import EdgeConv2d, DenseDilatedKnnGraph
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    m = EdgeConv2d(12, 20, act, norm, True).train()
+    x = torch.randn(2, 12, 96, 1)
+    probe = torch.randn(2, 20, 96, 1)
+    md = copy.deepcopy(m).to(dev)
+    ei = DenseDilatedKnnGraph(6, 2)(x.to(dev))
+    xr = x.clone().requires_grad_(True)
+    eic = ei.cpu()
+    xi = torch.gather(xr.squeeze(-1), 2, eic[1].reshape(2, 1, -1).expand(2, 12, -1)).view(2, 12, 96, 6)
+    xj = torch.gather(xr.squeeze(-1), 2, eic[0].reshape(2, 1, -1).expand(2, 12, -1)).view(2, 12, 96, 6)
+    ref = m.nn(torch.cat([xi, xj - xi], dim=1)).max(-1, keepdim=True)[0]
+    (ref * probe).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    out = md(xd, ei)
+    (out * probe.to(dev)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-5)
+    scale = max(float(p.grad.abs().max()) for p in m.parameters())
+    for (k, p), (_, q) in zip(md.named_parameters(), m.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=2e-4 * scale + 1e-6)

@@ -88,8 +88,8 @@ def test_install_registers_every_reference_module_path(dropin):
 def test_unsupported_options_fail_loudly(dropin):
     from gcn_lib.dense import DynConv2d, EdgeConv2d
     from gcn_lib.sparse import GraphConv
-    with pytest.raises(NotImplementedError):
-        EdgeConv2d(8, 8, "relu", "instance")
+    assert EdgeConv2d(8, 8, "relu", "instance")._per_edge and EdgeConv2d(8, 8, "prelu", "batch")._per_edge
+    assert not EdgeConv2d(8, 8, "leakyrelu", "batch")._per_edge
     assert DynConv2d(8, 8, knn="tree").dilated_knn_graph.__class__.__name__ == "DilatedKnnGraph"
     with pytest.raises(NotImplementedError):
         GraphConv(8, 8, "gat")
