@@ -26,8 +26,10 @@ ENC_FEATURES = 8                   # raw edge features of the fused edge encoder
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
-MAX_MASK_MIN_EDGES = 1 << 16       # max backward through per-edge arg-max bit masks (two launches) from this many
-                                   # edges on; below, the one-launch walk over gathered arg-max rows
+MAX_MASK_MIN_TABLE_BYTES = 128 << 20   # max backward through per-edge arg-max bit masks (two launches) when the (n_dst, C)
+                                   # arg-max table is at least this big, i.e. falls out of the 256 MiB Infinity Cache
+                                   # (products: 28.3 -> 23.7 ms per step); cache-resident graphs keep the one-launch
+                                   # walk over gathered arg-max rows (arxiv shape with locality: 0.44 vs 0.53 ms)
 
 
 def _scalar_arg(v):
@@ -296,8 +298,8 @@ class _GenAggregate(torch.autograd.Function):
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
                 elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
-                        graph.n_edges >= MAX_MASK_MIN_EDGES and graph.n_dst > 0:
-                    # arg-max bit masks per edge instead of gathered arg-max rows: a third of the bytes on big graphs
+                        graph.n_dst * C * 4 >= MAX_MASK_MIN_TABLE_BYTES and graph.n_edges > 0:
+                    # arg-max bit masks per edge instead of gathered arg-max rows (big graphs: the table misses the caches)
                     mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
                     mask = torch.empty(mbytes, device=dev, dtype=torch.uint8)
                     rc = lib.dgcn_gen_aggr_max_bwd_f32(

@@ -479,9 +479,9 @@ def test_max_backward_bit_mask_path_equals_the_row_walk(C, sorted_input, monkeyp
         (out * probe).sum().backward()
         grads[(name, "raw")] = xd.grad.clone()
 
-    monkeypatch.setattr(ops, "MAX_MASK_MIN_EDGES", 1 << 60)
+    monkeypatch.setattr(ops, "MAX_MASK_MIN_TABLE_BYTES", 1 << 60)
     run("rows")
-    monkeypatch.setattr(ops, "MAX_MASK_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "MAX_MASK_MIN_TABLE_BYTES", 0)
     run("mask")
     for k in (False, True, "raw"):
         assert torch.equal(grads[("mask", k)], grads[("rows", k)]), k
