@@ -4,8 +4,8 @@
     python profiles/summarize_trace.py gpurun_out/prof_models/<host>/<pid>_kernel_trace.csv --out profiles/r01_models_kernel_breakdown.md
 
 MIOpen's first-call algorithm search and warm-up pollute `--stats`; this takes, for the dense model, the kernels
-between the optimizer launches of the last 4 training steps and, for the sparse model, everything between the first
-and last aggregation kernel (8 training steps + 8 inference forwards), and reports time per kernel per step."""
+between the optimizer launches of the last 4 training steps and, for the sparse model, two eager training steps cut
+the same way, and reports time per kernel per step."""
 import argparse
 import collections
 import csv
@@ -51,11 +51,19 @@ def main():
     lines = ["# Per-step kernel breakdown of the model benchmarks (rocprofv3 --kernel-trace, steady state)", ""]
     lines += table(dense[clusters[-5][-1] + 1:clusters[-1][-1] + 1], 4,
                    "ResGCN-28 dense (B=8, N=4096, k=16): last 4 training steps")
-    idx = [i for i, r in enumerate(rows) if "gen_aggr_fwd_kernel<3, 4, 32, 64," in r["Kernel_Name"]]
-    n_bwd = sum(1 for r in rows[idx[0]:idx[-1] + 1] if "gen_aggr_bwd_kernel<3, 4, 32, 64" in r["Kernel_Name"])
-    steps = max(1, round(n_bwd / 28))
-    lines += table(rows[idx[0]:idx[-1] + 1], steps,
-                   f"DeeperGCN-28 on the arxiv shape: {steps} training steps (+ as many inference forwards, counted in)")
+    # sparse model: the eager training steps only (the HIP-graph capture / replay that follows repeats them), cut at the
+    # optimizer launches like the dense model: the two steps before the 8th optimizer step (3 warm-up + 5 timed)
+    sparse = rows[first_sparse:]
+    adam = [i for i, r in enumerate(sparse) if "multi_tensor_apply" in r["Kernel_Name"]]
+    clusters = []
+    for i in adam:
+        if not clusters or i - clusters[-1][-1] > 50:
+            clusters.append([i])
+        else:
+            clusters[-1].append(i)
+    last = min(len(clusters), 8) - 1
+    lines += table(sparse[clusters[last - 2][-1] + 1:clusters[last][-1] + 1], 2,
+                   "DeeperGCN-28 on the arxiv shape (re-entrant checkpointing: two forwards per step): 2 training steps")
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
