@@ -27,13 +27,12 @@
 // Bound: fp32 MFMA (2*E*K*C flop at 157 TF) against E*K*4 bytes of features from HBM; both ~0.2 ms at the
 // ogbn-proteins cluster shape.  x rows and the index arrays are L2-resident.
 
+#include "bf16x6.h"
 #include "gen_aggr_common.h"
 #include "gen_aggr_state.h"
 
 namespace dgcn {
 namespace {
-
-typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kEgM = 16;        // edges per MFMA batch (M of the 16x16x4 tile)
 constexpr int kEgMinItem = 64;  // a work item = item_len consecutive CSR positions (a multiple of 16, >= 64): the edge
@@ -916,35 +915,7 @@ __global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_pipe_kernel(con
 // 6 MFMAs of 16 cycles replace 8 fp32 MFMAs of 32 cycles per 16x16x32 block: 2.7x less matrix time, and it is
 // hidden time.  The weight matrix is split once per workgroup into three bf16 planes in LDS (161 KB at C = 112,
 // K = 224: possible because the tile-free fold needs no LDS); features are split in registers as they arrive.
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
-typedef int i4v __attribute__((ext_vector_type(4)));
 constexpr int kEgAheadB = 2;     // 32-float feature blocks requested ahead of the one being multiplied
-
-__device__ __forceinline__ unsigned eg_pack_hi16(float e0, float e1) {   // (top 16 bits of e0) | (top 16 bits of e1) << 16
-  return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
-}
-__device__ __forceinline__ float eg_top16(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
-
-// eight fp32 values -> three bf16x8 MFMA fragments (element e in the low/high half of register e / 2)
-__device__ __forceinline__ void eg_split3(const f4v& f0, const f4v& f1, i4v& h, i4v& m, i4v& l) {
-  const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-  float r[8], r2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    r[e] = v[e] - eg_top16(v[e]);
-    r2[e] = r[e] - eg_top16(r[e]);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    h[e] = static_cast<int>(eg_pack_hi16(v[2 * e], v[2 * e + 1]));
-    m[e] = static_cast<int>(eg_pack_hi16(r[2 * e], r[2 * e + 1]));
-    l[e] = static_cast<int>(eg_pack_hi16(r2[2 * e], r2[2 * e + 1]));
-  }
-}
-
-__device__ __forceinline__ f4v eg_mfma_bf16(const i4v& a, const i4v& b, const f4v& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
-}
 
 // WPS = waves per SIMD the register budget is written for.  2: two full weight-fragment buffers (a plane's fragments
 // are requested a whole MFMA phase ahead), feature ring two blocks deep, 256 VGPRs.  3: the wide shapes (NT >= 5) are
