@@ -58,6 +58,29 @@ def main():
     print(json.dumps(dict(model="ResGCN-28 dense (B=8,N=4096,k=16, dilation 1..27), train step fwd+bwd+Adam",
                           ms_per_step=ms, ms_forward=ms_f, edges_per_s=edges / (ms * 1e-3),
                           params=sum(p.numel() for p in m.parameters()))), flush=True)
+    # the same step replayed as ONE HIP graph: what the ~890 launches per step cost on the host side
+    try:
+        opt_g = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt_g.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(m(x), y).backward()
+                opt_g.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt_g.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss_g = torch.nn.functional.cross_entropy(m(x), y)
+            loss_g.backward()
+            opt_g.step()
+        ms_g = timed(graph.replay, a.iters)
+        print(json.dumps(dict(model="ResGCN-28 dense train step, whole step replayed as ONE HIP graph",
+                              ms_per_step=ms_g, edges_per_s=edges / (ms_g * 1e-3),
+                              loss_finite=bool(torch.isfinite(loss_g).item()))), flush=True)
+    except Exception as exc:   # report, do not hide
+        print(json.dumps(dict(model="ResGCN-28 HIP-graph replay", error=repr(exc)[:300])), flush=True)
     del m, opt
 
     # config 3: DeeperGCN-28 softmax_sg t=0.1 on the arxiv shape (full graph)

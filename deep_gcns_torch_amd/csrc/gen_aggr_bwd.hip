@@ -369,7 +369,15 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
   while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
   for (int c = lane; c < C; c += kWave) {
     float acc = 0.f;
-    for (int i = i0; i < i1; ++i) acc += P.ws[static_cast<int64_t>(P.g.work_slot[i]) * C + c];
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {          // four partial rows in flight, summed in item order (a hub row has dozens)
+      const float v0 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i])) * C + c];
+      const float v1 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 1])) * C + c];
+      const float v2 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 2])) * C + c];
+      const float v3 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 3])) * C + c];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; i < i1; ++i) acc += P.ws[static_cast<int64_t>(uni(P.g.work_slot[i])) * C + c];
     P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
   }
 }

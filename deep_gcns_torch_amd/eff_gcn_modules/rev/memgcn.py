@@ -26,6 +26,12 @@ class GroupAdditiveCoupling(torch.nn.Module):
         xs = torch.chunk(x, self.group, dim=self.split_dim)
         extra = self._arg_chunks(args)
         y_in = sum(xs[1:])
+        if not torch.is_grad_enabled() and x.dim() == 2 and self.split_dim in (-1, 1):
+            # the reversible wrapper's forward (no graph): every y_i is written straight into its columns of the result
+            y = torch.empty_like(x)
+            for i, yv in enumerate(torch.chunk(y, self.group, dim=1)):
+                y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
+            return y
         ys = []
         for i in range(self.group):
             y_in = xs[i] + self.Fms[i](y_in, edge_index, *extra[i])
@@ -73,6 +79,10 @@ class GroupAdditiveCoupling(torch.nn.Module):
         wgrads = [None] * len(weights)
         xs = [None] * g
         gx = [None] * g
+        flat = y.dim() == 2 and dim in (-1, 1) and not torch.is_grad_enabled()
+        if flat:                                       # x and grad_x are assembled in place, column block by column block
+            x_buf, gx_buf = torch.empty_like(y), torch.empty_like(grad_y)
+            xv, gxv = torch.chunk(x_buf, g, dim=1), torch.chunk(gx_buf, g, dim=1)
         carry = None                                   # gradient flowing into y_{i-1} from F_i's input
         for i in range(g - 1, -1, -1):
             Fm = self.Fms[i]
@@ -97,8 +107,13 @@ class GroupAdditiveCoupling(torch.nn.Module):
                     cm.__enter__()
                 try:
                     out = Fm(leaf, edge_index, *call_args)
-                    xs[i] = ys[i] - out.detach()
-                    total = gys[i] if carry is None else gys[i] + carry
+                    if flat:
+                        with torch.no_grad():
+                            xs[i] = torch.sub(ys[i], out, out=xv[i])
+                            total = gxv[i].copy_(gys[i]) if carry is None else torch.add(gys[i], carry, out=gxv[i])
+                    else:
+                        xs[i] = ys[i] - out.detach()
+                        total = gys[i] if carry is None else gys[i] + carry
                     gx[i] = total
                     params = [p for p in Fm.parameters() if p.requires_grad]
                     grads = torch.autograd.grad(out, [leaf] + leaves + params, total, allow_unused=True)
@@ -116,8 +131,8 @@ class GroupAdditiveCoupling(torch.nn.Module):
         # the gradient into F_0's input (the sum of the other groups) goes to every x_i, i >= 1
         if carry is not None:
             for i in range(1, g):
-                gx[i] = gx[i] + carry
-        x = torch.cat(xs, dim=dim)
-        grad_x = torch.cat(gx, dim=dim)
+                gx[i] = gx[i].add_(carry.detach()) if flat else gx[i] + carry
+        x = x_buf if flat else torch.cat(xs, dim=dim)
+        grad_x = gx_buf if flat else torch.cat(gx, dim=dim)
         wgrads = [torch.zeros_like(w) if gr is None else gr for w, gr in zip(weights, wgrads)]
         return x, grad_x, wgrads
