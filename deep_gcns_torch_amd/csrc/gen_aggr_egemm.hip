@@ -1375,9 +1375,14 @@ int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
 template <int NT, int KC, int MODE>
 int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
   const size_t lds = static_cast<size_t>(3) * NT * 16 * (4 * KC + 2) * 16;                  // three bf16 weight planes
-  const bool w3 = eg_wps(NT, MODE) == 3;
-  const void* fn = w3 ? reinterpret_cast<const void*>(egemm_fwd_bf16_w3_kernel<NT, KC, MODE>)
-                      : reinterpret_cast<const void*>(egemm_fwd_bf16_kernel<NT, KC, MODE>);
+  // the register-lean variant exists only where eg_wps can choose it (wide shapes, small fold state)
+  constexpr bool kHasW3 = NT >= 5 && (MODE == DGCN_AGGR_MAX || MODE == DGCN_AGGR_ADD || MODE == DGCN_AGGR_MEAN);
+  bool w3 = false;
+  if constexpr (kHasW3) w3 = eg_wps(NT, MODE) == 3;
+  const void* fn = reinterpret_cast<const void*>(egemm_fwd_bf16_kernel<NT, KC, MODE>);
+  if constexpr (kHasW3) {
+    if (w3) fn = reinterpret_cast<const void*>(egemm_fwd_bf16_w3_kernel<NT, KC, MODE>);
+  }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
   int nwaves = w3 ? 12 : kEgMaxWaves;
@@ -1387,11 +1392,13 @@ int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
   }
   int grid = (P.n_items + nwaves - 1) / nwaves;
   if (grid > kNumCU) grid = kNumCU;                 // the weight planes fill the LDS: one workgroup per CU
-  if (w3) {
-    hipLaunchKernelGGL((egemm_fwd_bf16_w3_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
-  } else {
-    hipLaunchKernelGGL((egemm_fwd_bf16_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+  if constexpr (kHasW3) {
+    if (w3) {
+      hipLaunchKernelGGL((egemm_fwd_bf16_w3_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
+      return DGCN_OK;
+    }
   }
+  hipLaunchKernelGGL((egemm_fwd_bf16_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
   return DGCN_OK;
 }
 

@@ -27,7 +27,7 @@ def _ref(x, ei, feat, W, b, n, aggr, kw):
     return sparse_ref.gen_propagate(x, ei, emb, aggr=aggr, dim_size=n, **kw)
 
 
-def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=False, rtol=1e-4):
+def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=False, rtol=1e-4, dead_channels=0):
     from deep_gcns_torch_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(seed)
@@ -35,6 +35,8 @@ def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=
     x = torch.randn(n, C, generator=g)
     W = torch.randn(C, K, generator=g) / K ** 0.5
     b = torch.randn(C, generator=g) if bias else None
+    if dead_channels:               # these channels see z < 0 on every edge: m = eps, the relu floor
+        b[:dead_channels] = -1e3
     probe = torch.randn(n, C, generator=g)
     if strided:                     # (E, K) chunk of an (E, 2K) embedding: row stride 2K, offset K
         full = torch.randn(E, 2 * K, generator=g)
@@ -161,3 +163,12 @@ def test_bit_reproducible_and_matches_unfused_path():
             u = ops.gen_aggregate(x, ei, torch.nn.functional.linear(feat, W, b), aggr=aggr, **kw)
         assert torch.equal(a, a2)
         torch.testing.assert_close(a, u, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("aggr,kw", [("max", {}), ("softmax", dict(t=0.7)), ("power", dict(p=2.0))])
+def test_channels_at_the_relu_floor(aggr, kw):
+    """Channels whose pre-activation is negative on EVERY edge (m = eps everywhere): no gradient flows through them.
+    Max runs its backward without saved pre-activations there -- the forward writes arg-max id -1 for such channels
+    (csrc/gen_aggr_egemm.hip eg_finalize) -- so this is the case that would break if that marking were wrong."""
+    out = _run_case(synth.tricky_graph(), 257, 112, 224, aggr, dict(kw), seed=4, dead_channels=20)
+    assert out.shape == (257, 112)
