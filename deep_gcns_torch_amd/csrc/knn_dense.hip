@@ -282,7 +282,8 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
   if (K <= 64) sort_and_emit<1>(P, skey, sidx, lane, K, out_base, i);
   else if (K <= 128) sort_and_emit<2>(P, skey, sidx, lane, K, out_base, i);
   else if (K <= 256) sort_and_emit<4>(P, skey, sidx, lane, K, out_base, i);
-  else sort_and_emit<8>(P, skey, sidx, lane, K, out_base, i);
+  else if (K <= 512) sort_and_emit<8>(P, skey, sidx, lane, K, out_base, i);
+  else sort_and_emit<16>(P, skey, sidx, lane, K, out_base, i);     // deeper stacks than ResGCN-28 (k * d up to 1024)
 }
 
 // LDS layout (dynamic): q[C][TM] | sq[TM] | dist[TM][Npad] | selkey[TM][Kpad]
@@ -818,7 +819,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   if (!x || !nn_out) return DGCN_E_NULL;
   if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u)) return DGCN_E_ALIGN;
   if (B < 0 || C <= 0 || N <= 0 || K <= 0 || dilation <= 0) return DGCN_E_SHAPE;
-  if (K > N - (exclude_self ? 1 : 0) || K > 512) return DGCN_E_SHAPE;             // sorted winners: 8 u64 per lane
+  if (K > N - (exclude_self ? 1 : 0) || K > 1024) return DGCN_E_SHAPE;            // sorted winners: <= 16 u64 per lane
   if (N > kMaxPerLane * kWave) return DGCN_E_SHAPE;      // 64 keys per lane in the select phase: N <= 4096
   if (B == 0) return DGCN_OK;
 
@@ -840,7 +841,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.tau = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
   P.sample_rank = 0;
-  if (N >= 1024) {
+  if (N >= 1024 && K <= 512) {    // K > 512 (ResGCN-56's deep blocks): exact full-row selection only
     // Sample rank: the number of candidates below the r-th of 256 sample keys has mean r*N/256 and standard
     // deviation ~ sqrt(r)*N/256.  Aim 3.2 sigma above K, but no higher than the middle of [K, 1024] so that
     // both "too few" and "too many" (list capacity) stay rare; either way the exact path catches the row.

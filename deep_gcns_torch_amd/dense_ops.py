@@ -23,7 +23,8 @@ USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fa
 # kNN
 # ----------------------------------------------------------------------------------------
 KNN_MAX_POINTS = 4096        # one sample's distance strip lives in LDS (csrc/knn_dense.hip)
-KNN_MAX_NEIGHBOURS = 512     # k * dilation; sem_seg_dense's deepest block needs 16 * 27 = 432
+KNN_MAX_NEIGHBOURS = 1024    # k * dilation; ResGCN-28's deepest block needs 16 * 27 = 432 (candidate-filter kernel up to
+                             # 512), ResGCN-56's 16 * 55 = 880 (exact kernel)
 
 
 def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, ctr_out, exclude_self: bool = False):

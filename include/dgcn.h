@@ -305,7 +305,7 @@ int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edge
  *            (pre-pass: |x_j|^2 and a per-row sampled threshold; 16 rows per workgroup on the matrix cores; the
  *            rows it cannot finish are listed on the device and redone by the exact path);
  *            without it every row takes the exact full-row path.  Results are identical either way.
- * Limits: N <= 4096, K <= 512, K <= N. */
+ * Limits: N <= 4096, K <= 1024 (the candidate-filter fast path serves K <= 512), K <= N. */
 size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N);
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
                        int32_t N, int32_t K, int32_t dilation, int32_t exclude_self, int64_t* nn_out,

@@ -206,7 +206,8 @@ def test_vertex_gemm_is_an_exact_fma_chain():
 
 
 @pytest.mark.parametrize("N,C,K,kind", [(4096, 3, 16, "lattice"), (4096, 64, 432, "lattice"), (2048, 16, 64, "sorted"),
-                                        (1024, 3, 100, "duplicates"), (4096, 8, 512, "lattice"), (1536, 5, 1, "lattice")])
+                                        (1024, 3, 100, "duplicates"), (4096, 8, 512, "lattice"), (1536, 5, 1, "lattice"),
+                                        (4096, 64, 880, "lattice"), (2048, 8, 1024, "sorted"), (1100, 3, 600, "duplicates")])
 def test_dense_knn_large_n_sampled_select_vs_oracle(N, C, K, kind):
     """N >= 1024 takes the sample-pre-filtered select; its result must equal the exact top-K whatever the
     point order (sorted clouds defeat the sample -> exact fallback) and with heavy ties (duplicates)."""
@@ -299,5 +300,5 @@ def test_dense_limits_are_reported_not_silently_wrong():
     x = torch.randn(1, 3, 5000, 1, device=dev)
     with pytest.raises(NotImplementedError, match="at most 4096 points"):
         dense_ops.knn_edge_index(x, 4, 1)                      # N > 4096
-    with pytest.raises(NotImplementedError, match="k\\*dilation <= 512"):
-        dense_ops.knn_edge_index(x[:, :, :1024], 600, 1)       # K > 512
+    with pytest.raises(NotImplementedError, match="k\\*dilation <= 1024"):
+        dense_ops.knn_edge_index(x[:, :, :2048], 1100, 1)      # K > 1024
