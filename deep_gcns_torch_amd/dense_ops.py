@@ -32,11 +32,10 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
     lib = _lib.load()
     dev = _lib.require_device(x3)
     B, C, N = x3.shape
-    if N > KNN_MAX_POINTS or K > KNN_MAX_NEIGHBOURS or K > N - (1 if exclude_self else 0):
-        raise NotImplementedError(
-            f"dgcn_knn_dense_f32 serves clouds of at most {KNN_MAX_POINTS} points and k*dilation <= "
-            f"{KNN_MAX_NEIGHBOURS} (<= points available); got N={N}, k*dilation={K}. Larger or ragged clouds are "
-            f"not implemented (INTEGRATION.md, 'Limits').")
+    if K > N - (1 if exclude_self else 0):
+        raise ValueError(f"k*dilation = {K} neighbours asked of clouds with {N} points")
+    if N > KNN_MAX_POINTS or K > KNN_MAX_NEIGHBOURS:
+        return _knn_beyond_kernel_limits(x3, K, dilation, nn_out, ctr_out, exclude_self)
     ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N) if (N >= 1024 and USE_KNN_FILTER) else 0
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     with _lib.device_ctx(dev):
@@ -44,6 +43,26 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
                                     dilation, 1 if exclude_self else 0, nn_out.data_ptr(), _lib.ptr(ctr_out),
                                     _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_knn_dense_f32")
+
+
+def _knn_beyond_kernel_limits(x3, K, dilation, nn_out, ctr_out, exclude_self):
+    """Clouds larger than the kernel serves (N > 4096 points or k*dilation > 1024): the reference's own formulation
+    -- pairwise_distance, then the k*dilation smallest per row (gcn_lib/dense/torch_edge.py:27-76) -- on library ops,
+    one sample at a time with the reference's (N, N) distance matrix.  Ties go to the lower index (stable sort), as in
+    the kernel.  No reference configuration gets here (sem_seg_dense: 4096 points, k*d <= 432); it exists so that a
+    bigger cloud runs instead of raising."""
+    B, C, N = x3.shape
+    centre = torch.arange(N, device=x3.device).view(N, 1)
+    for b in range(B):
+        p = x3[b].t().contiguous()                                  # (N, C)
+        sq = (p * p).sum(1, keepdim=True)
+        d = (sq + (-2.0) * (p @ p.t())) + sq.t()                    # the reference's association
+        if exclude_self:
+            d.fill_diagonal_(float("inf"))
+        nn_out[b] = torch.sort(d, dim=1, stable=True).indices[:, :K:dilation]
+        if ctr_out is not None:
+            ctr_out[b] = centre
+        del d
 
 
 def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1, exclude_self: bool = False) -> torch.Tensor:

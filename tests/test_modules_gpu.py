@@ -294,11 +294,24 @@ def test_dense_knn_odd_shapes(B, C, N, k, d):
     assert torch.equal(ei[1].cpu(), torch.arange(N).view(1, N, 1).expand(B, N, k))
 
 
-def test_dense_limits_are_reported_not_silently_wrong():
+def test_clouds_beyond_the_kernel_limits_run_on_the_library_tier():
+    """N > 4096 points or k*dilation > 1024: the reference's formulation on library ops (dense_ops.
+    _knn_beyond_kernel_limits).  Same contract: ascending distance, ties by index, dilation, centre ids; the selected
+    distances equal the K smallest of the oracle's matrix to fp32 matmul rounding."""
     from deep_gcns_torch_amd import dense_ops
+    from oracle import dense_ref
     dev = _dev()
-    x = torch.randn(1, 3, 5000, 1, device=dev)
-    with pytest.raises(NotImplementedError, match="at most 4096 points"):
-        dense_ops.knn_edge_index(x, 4, 1)                      # N > 4096
-    with pytest.raises(NotImplementedError, match="k\\*dilation <= 1024"):
-        dense_ops.knn_edge_index(x[:, :, :2048], 1100, 1)      # K > 1024
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 6, 5000, 1, generator=g)
+    for K, d, excl in ((24, 3, False), (1100, 1, True)):
+        ei = dense_ops.knn_edge_index(x.to(dev), K // d, d, exclude_self=excl).cpu()
+        dist = dense_ref.pairwise_distance(x.transpose(2, 1).squeeze(-1))
+        if excl:
+            dist.diagonal(dim1=1, dim2=2).fill_(float("inf"))
+        want = torch.sort(dist, dim=2).values[:, :, :K:d]
+        torch.testing.assert_close(torch.gather(dist, 2, ei[0]), want, rtol=1e-5, atol=1e-5)
+        assert torch.equal(ei[1], torch.arange(5000).view(1, 5000, 1).expand_as(ei[1]))
+        if not excl:
+            assert torch.equal(ei[0][:, :, 0], torch.arange(5000).expand(2, 5000))      # self first
+    with pytest.raises(ValueError, match="neighbours asked"):
+        dense_ops.knn_edge_index(x[:, :, :100].to(dev), 101, 1)
