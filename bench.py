@@ -309,7 +309,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # a rank that dies inside a collective must surface as an error within minutes, not as the default 10-minute hang
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=240))
 
     s = synth.SHAPES[args.shape]
     C = args.channels or s["channels"]
