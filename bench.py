@@ -157,6 +157,28 @@ def extras(dev):
         edges_per_s=ei.size(1) * 28 / (ms * 1e-3), cpu_baseline=None)
     del m, opt, g, x, go
 
+    # ---- config 4 as the reference trains it: DeeperGCN-14 on one of 10 RANDOM node clusters of ogbn-products ---------
+    # (examples/ogb/ogbn_products/main.py:120-124: random_partition_graph + induced sub-graph: a tenth of the nodes keeps a
+    # hundredth of the edges)
+    sp = synth.SHAPES["products"]
+    n_c = sp["n"] // 10
+    ei_c = synth.undirected_random_graph(n_c, sp["n_undirected"] // 100, sp["seed"] + 1, device=dev)
+    m = arch_restated.DeeperGCN(num_layers=14, in_channels=100, hidden=128, num_tasks=47).to(dev).train()
+    xc = torch.randn(n_c, 100, device=dev)
+    yc = torch.randint(0, 47, (n_c,), device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def products_cluster_step():
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.nll_loss(m(xc, ei_c), yc).backward()
+        opt.step()
+    ms = gpu_timed(products_cluster_step, 5, 2)
+    out["deepergcn14_products_cluster_train_step"] = dict(
+        workload=f"DeeperGCN-14 GENConv softmax_sg hidden=128 (ogbn_products/model.py) on one random cluster of 10: "
+                 f"N={n_c} E={ei_c.size(1)}, fwd+bwd+Adam", ms_per_step=ms,
+        edges_per_s=ei_c.size(1) * 14 / (ms * 1e-3), cpu_baseline=None)
+    del m, opt, xc, yc, ei_c
+
     # ---- config 2 layer and model (B=8, N=4096, k=16, C=64) ------------------------------------------------------------
     B, N, C, k = 8, 4096, 64, 16
     xd = torch.randn(B, C, N, 1, device=dev)
