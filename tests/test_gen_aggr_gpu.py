@@ -274,6 +274,36 @@ def test_products_shape_properties():
         want = acc * (x[sidx] > 0).double()
         torch.testing.assert_close(xg.grad[sidx].double(), want, rtol=1e-4, atol=1e-6)
     assert torch.equal(ops.gen_aggregate(x, graph, aggr="softmax_sg", t=0.1), sm)
+    # max at full size: the bit-mask backward (the default here: the arg-max table is 1.25 GB) equals the row walk bit
+    # for bit, and sampled source rows equal  relu'(x_s) * sum over the (destination, channel) pairs this source wins
+    del out, sm
+    grads = {}
+    old_thr = ops.MAX_MASK_MIN_TABLE_BYTES
+    try:
+        for name, thr in (("mask", 0), ("rows", 1 << 60)):
+            ops.MAX_MASK_MIN_TABLE_BYTES = thr
+            xg = x.clone().requires_grad_(True)
+            omx = ops.gen_aggregate(xg, graph, aggr="max")
+            (omx * probe).sum().backward()
+            grads[name] = xg.grad
+            del xg
+    finally:
+        ops.MAX_MASK_MIN_TABLE_BYTES = old_thr
+    assert torch.equal(grads["mask"], grads["rows"])
+    ep = graph.eperm.long() if graph.eperm is not None else None
+    for sidx in rows[:8].tolist():
+        dsts = graph.t_col[trp[sidx]:trp[sidx + 1]].long()
+        eids = graph.t_eperm[trp[sidx]:trp[sidx + 1]].long()
+        acc = torch.zeros(C, device=dev, dtype=torch.float64)
+        for i, e in zip(dsts.tolist(), eids.tolist()):
+            nb = graph.col[rp[i]:rp[i + 1]].long()
+            ids = ep[rp[i]:rp[i + 1]] if ep is not None else torch.arange(rp[i], rp[i + 1], device=dev)
+            m = torch.relu(x[nb]) + 1e-7
+            best = m.max(0).values
+            first = torch.where(m == best, ids.unsqueeze(1).expand_as(m), torch.full_like(m, 1 << 40, dtype=torch.long)).min(0).values
+            acc += (first == e).double() * probe[i].double()              # ties: the first edge (lowest id) only
+        want = acc * (x[sidx] > 0).double()
+        torch.testing.assert_close(grads["mask"][sidx].double(), want, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("t,expect_shifted", [(0.1, True), (1.0, True), (40.0, False)])
