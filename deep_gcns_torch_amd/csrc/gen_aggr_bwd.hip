@@ -44,6 +44,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   const float eps = P.eps;
   const int msg = P.msg;
   const bool learn_t = P.learn_t != 0;
+  const bool p_is_one = p == 1.f;          // the reference's default exponent: u^(p-1) = 1, no log2 / exp2 per element
   const bool ea_is_z = (EA == 1) && P.ea_is_z != 0;
   // MAX without edge rows: per-edge arg-max bit masks (<= 4 words) travel with the column ids -- loaded one item ahead,
   // parked in LDS per block, read back per edge with one ds_read instead of a dependent global gather
@@ -207,7 +208,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
               } else if constexpr (MODE == DGCN_AGGR_POWER) {
                 const bool in = (m >= kPowLo) && (m <= kPowHi);
                 const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
-                k = in ? gc[u][j] * fast_pow(uu, p - 1.f) : 0.f;
+                k = in ? (p_is_one ? gc[u][j] : gc[u][j] * fast_pow(uu, p - 1.f)) : 0.f;
               } else if constexpr (MODE == DGCN_AGGR_MAX) {
                 k = (ai[u][j] == eid[u]) ? gc[u][j] : 0.f;
               } else {

@@ -175,6 +175,22 @@ __device__ __forceinline__ void accumulate(State<VEC>& st, const float (&v)[U][V
     }
     return;
   }
+  if constexpr (MODE == DGCN_AGGR_POWER && !WITH_D) {
+    // p == 1, the reference's default (args: --p 1.0 without --learn_p): u^1 = u exactly, no log2 / exp2 per element
+    if (p == 1.f) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (FULL || ok[u]) {
+            const float m = RELU ? vrelu(v[u][j]) + eps : v[u][j];
+            st.b[j] += fminf(fmaxf(m, kPowLo), kPowHi);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     if constexpr (MODE == DGCN_AGGR_POWER) {

@@ -92,7 +92,8 @@ def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=
 
 
 AGGRS = [("softmax", dict(t=0.7)), ("softmax", dict(t=0.9, learn_t=True)), ("softmax_sg", dict(t=0.1)),
-         ("power", dict(p=2.0)), ("power", dict(p=1.5, learn_p=True)), ("max", {}), ("add", {}), ("mean", {})]
+         ("power", dict(p=2.0)), ("power", dict(p=1.0)), ("power", dict(p=1.5, learn_p=True)), ("power", dict(p=1.0, learn_p=True)),
+         ("max", {}), ("add", {}), ("mean", {})]
 
 
 @pytest.mark.parametrize("aggr,kw", AGGRS, ids=lambda v: v if isinstance(v, str) else "-".join(f"{k}{x}" for k, x in v.items()))

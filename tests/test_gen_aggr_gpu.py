@@ -104,7 +104,8 @@ def test_known_answers_on_device():
 
 
 @pytest.mark.parametrize("C,with_ea", [(128, False), (64, True), (32, False), (32, True), (16, False), (16, True)])
-@pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.1)), ("power", dict(p=2.0)), ("max", {}), ("mean", {})])
+@pytest.mark.parametrize("aggr,kw", [("softmax_sg", dict(t=0.1)), ("power", dict(p=2.0)), ("power", dict(p=1.0)), ("max", {}),
+                                     ("mean", {})])
 def test_vs_oracle_powerlaw_graph(aggr, kw, C, with_ea):
     """Mid-size power-law graph (hubs on both sides -> split rows in both walks) vs the CPU oracle.
     C = 32 / 16 take the sub-group kernels (2 / 4 rows side by side in one wave), with and without edge features.
