@@ -110,6 +110,8 @@ def extras(dev):
     each timed like the headline (wall clock around K steps, synchronised) and with the CPU oracle beside it where a
     bounded CPU sample exists.  Model architectures: tests/arch_restated.py / tests/rev_restated.py (the reference's
     example files do not travel to the GPU box)."""
+    CPU_NOTE = ("whole-model steps are not replayed on the CPU oracle (minutes per step at these depths); the per-op CPU "
+                "baselines of this line (top-level cpu_baseline, extra.dense_layer.cpu_baseline) are the comparison")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
@@ -140,7 +142,8 @@ def extras(dev):
         ms_f = gpu_timed(lambda: ops.gen_aggregate(x, g, aggr="softmax_sg", t=0.1), 50, 10)
     out["arxiv_aggregation"] = dict(workload="GENConv softmax_sg t=0.1 aggregation fwd+bwd, N=169343 E=2484941 C=128",
                                     ms_fwd_bwd=ms, ms_fwd=ms_f, edges_per_s=g.n_edges / (ms * 1e-3),
-                                    graph_build_ms=build_ms)
+                                    graph_build_ms=build_ms,
+                                    cpu_baseline="this exact workload is the sample of the top-level cpu_baseline")
 
     m = arch_restated.DeeperGCN(num_layers=28, in_channels=128, hidden=128, num_tasks=40).to(dev).train()
     xa = torch.randn(s["n"], 128, device=dev)
@@ -154,7 +157,7 @@ def extras(dev):
     ms = gpu_timed(arxiv_step, 5, 2)
     out["deepergcn28_arxiv_train_step"] = dict(
         workload="DeeperGCN-28 GENConv softmax_sg 'res+' (ogbn_arxiv/model.py), full graph, fwd+bwd+Adam", ms_per_step=ms,
-        edges_per_s=ei.size(1) * 28 / (ms * 1e-3), cpu_baseline=None)
+        edges_per_s=ei.size(1) * 28 / (ms * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
     del m, opt, g, x, go
 
     # ---- config 4 as the reference trains it: DeeperGCN-14 on one of 10 RANDOM node clusters of ogbn-products ---------
@@ -176,7 +179,7 @@ def extras(dev):
     out["deepergcn14_products_cluster_train_step"] = dict(
         workload=f"DeeperGCN-14 GENConv softmax_sg hidden=128 (ogbn_products/model.py) on one random cluster of 10: "
                  f"N={n_c} E={ei_c.size(1)}, fwd+bwd+Adam", ms_per_step=ms,
-        edges_per_s=ei_c.size(1) * 14 / (ms * 1e-3), cpu_baseline=None)
+        edges_per_s=ei_c.size(1) * 14 / (ms * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
     del m, opt, xc, yc, ei_c
 
     # ---- config 2 layer and model (B=8, N=4096, k=16, C=64) ------------------------------------------------------------
@@ -231,7 +234,7 @@ def extras(dev):
     ms = gpu_timed(dense_step, 5, 2)
     out["resgcn28_train_step"] = dict(workload="sem_seg_dense ResGCN-28 (B=8 x 4096 points, k=16, dilation 1..27), "
                                                "fwd+bwd+Adam", ms_per_step=ms,
-                                      edges_per_s=8 * 4096 * 16 * 28 / (ms * 1e-3), cpu_baseline=None)
+                                      edges_per_s=8 * 4096 * 16 * 28 / (ms * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
     del m, opt
 
     # ---- config 5: RevGCN (hidden 224, group 2) on the ogbn-proteins cluster shape ----------------------------------
@@ -281,6 +284,7 @@ def extras(dev):
                        f"= the reference's inverse + recompute pattern on library GEMMs + (E,C) edge embeddings")
     rev["graph_build_ms"] = build_ms
     rev["cpu_baseline"] = None
+    rev["cpu_baseline_note"] = CPU_NOTE
     out["revgcn_proteins"] = rev
     return out
 
