@@ -16,7 +16,7 @@ import json
 import os
 import statistics
 
-KERNELS = ("gen_aggr_fwd_kernel", "gen_aggr_bwd_kernel", "egemm_fwd", "knn_dense", "edgeconv", "mr_aggr", "vertex_gemm",
+KERNELS = ("gen_aggr_fwd_kernel", "gen_aggr_bwd_kernel", "max_mask_build", "egemm_fwd", "knn_dense", "edgeconv", "mr_aggr", "vertex_gemm",
            "mrconv")
 
 
