@@ -58,16 +58,6 @@ _SIGNATURES = {
         C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
         C.c_void_p]),
-    "dgcn_gen_aggr_enc_fwd_f32": (C.c_int, [
-        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "dgcn_gen_aggr_enc_bwd_num_partials": (C.c_int32, [C.POINTER(DgcnGraph), C.c_int32]),
-    "dgcn_gen_aggr_enc_bwd_f32": (C.c_int, [
-        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_gen_aggr_egemm_supported": (C.c_int32, [C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_f32": (C.c_int, [
@@ -136,6 +126,27 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dgcn_rows_ln_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_bn_act_apply_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int64, C.c_int32,
+                                             C.c_void_p]),
+    "dgcn_rows_bn_act_bwd_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                 C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_bn_act_bwd_apply_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_ln_act_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dgcn_rows_ln_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                           C.c_void_p]),
+    "dgcn_rows_linear_supported": (C.c_int32, [C.c_int32, C.c_int32]),
+    "dgcn_rows_linear_num_partials": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32]),
+    "dgcn_rows_linear_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "dgcn_rows_msgnorm_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                             C.c_int64, C.c_int32, C.c_void_p]),
     "dgcn_rows_msgnorm_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,

@@ -1,0 +1,70 @@
+"""Model-level pre-activation residual layer of the reference's deep GENConv models, fused.
+
+The 'res+' layer loop is written in the reference's MODEL files, not in gcn_lib
+(examples/ogb/ogbn_arxiv/model.py:90-106, ogbn_products/model.py, ogbn_proteins/model.py:116-127, ogbg_*/model.py):
+
+    h1 = self.norms[layer - 1](h); h2 = F.relu(h1); h2 = F.dropout(h2, p=self.dropout, training=self.training)
+    h = self.gcns[layer](h2, edge_index) + h              # or: checkpoint(self.gcns[layer], h2, edge_index) + h
+
+Written that way it costs, besides the convolution: a statistics pass, an apply pass, a ReLU pass, a dropout pass
+(+ a stored mask) and a residual add, each a full read-modify-write of the (N, C) features.  ``res_plus_layer`` is the
+same arithmetic as three launches around the aggregation:
+
+    norm -> ReLU -> dropout   one apply pass (node_ops.pre_activation; statistics taken from the PREVIOUS layer's GEMM)
+    GENConv                   aggregation with x + m fused, then the MLP whose last Linear adds bias AND h in its epilogue
+                              and leaves the statistics of the new h for the next layer's BatchNorm
+
+The example's loop body becomes (INTEGRATION.md shows the diff):
+
+    h, stats = res_plus_layer(self.norms[layer - 1], self.gcns[layer], h, edge_index, p=self.dropout,
+                              training=self.training, stats=stats, use_checkpoint=...)
+"""
+from __future__ import annotations
+
+import torch
+from torch.utils.checkpoint import checkpoint
+
+from . import node_ops
+
+__all__ = ["res_plus_layer", "ResPlusLayer"]
+
+
+def _conv_res(conv, h2, edge_index, edge_attr, h, want_stats):
+    if edge_attr is None:
+        return conv(h2, edge_index, residual=h, want_stats=want_stats)
+    return conv(h2, edge_index, edge_attr, residual=h, want_stats=want_stats)
+
+
+def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, training: bool = True, stats=None,
+                   want_stats: bool = True, use_checkpoint: bool = False):
+    """``h + conv(dropout(relu(norm(h))), edge_index[, edge_attr])`` -> ``(h_new, stats_new)``.
+
+    norm: ``gcn_lib.sparse.torch_nn.norm_layer`` module; conv: ``gcn_lib.sparse.torch_vertex.GENConv``.
+    stats: what the previous call returned (BatchNorm statistics of ``h`` taken in the GEMM that produced it) or None.
+    use_checkpoint: wrap the convolution in ``torch.utils.checkpoint`` as the reference does for deep stacks
+    (ogbn_arxiv/model.py:101: only the aggregation + MLP is recomputed; ``h`` and ``h2`` stay alive)."""
+    h2 = node_ops.pre_activation(norm, h, p=p, training=training, stats=stats)
+    if use_checkpoint and torch.is_grad_enabled():
+        def run(h2_, h_):
+            out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
+            return out if want_stats else (out, None)
+        # the second output (statistics) is not differentiable; checkpoint hands it through
+        hn, st = checkpoint(run, h2, h, use_reentrant=True)
+    else:
+        out = _conv_res(conv, h2, edge_index, edge_attr, h, want_stats)
+        hn, st = out if want_stats else (out, None)
+    return hn, st
+
+
+class ResPlusLayer(torch.nn.Module):
+    """``res_plus_layer`` as a module owning ``norm`` and ``conv`` (attribute names as in the reference's ModuleLists are
+    the caller's business; this class is for code that builds the stack itself)."""
+
+    def __init__(self, norm, conv, dropout: float = 0.0, use_checkpoint: bool = False):
+        super().__init__()
+        self.norm, self.conv = norm, conv
+        self.dropout, self.use_checkpoint = dropout, use_checkpoint
+
+    def forward(self, h, edge_index, edge_attr=None, stats=None):
+        return res_plus_layer(self.norm, self.conv, h, edge_index, edge_attr, p=self.dropout, training=self.training,
+                              stats=stats, use_checkpoint=self.use_checkpoint)

@@ -46,6 +46,26 @@ constexpr int kEgMaxWaves = 8;
 constexpr int kEgLdsBytes = 160 * 1024;
 constexpr int kEgInfo = 4;      // int32 per item: head_row, tail_row, head_continues, unused
 
+// Tuning switches (DGCN_EG_GENERIC / _WPS / _WAVES / _DEBUG) exist only in builds with -DDGCN_EG_TUNING, where the
+// environment is read ONCE (thread-safe static); the product build has no mutable or environment-dependent state.
+struct EgTuning {
+  bool generic;   // force the generic fp32-MFMA kernel
+  int wps;        // 2: force the two-waves-per-SIMD register layout
+  int waves;      // waves per workgroup (0 = default)
+  int dbg;        // phase switches: 1 skip the walk, 2 skip the MFMA chain, 4 skip feature loads (results are wrong)
+};
+#ifdef DGCN_EG_TUNING
+inline const EgTuning& eg_tuning() {
+  static const EgTuning t = [] {
+    auto num = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : 0; };
+    return EgTuning{getenv("DGCN_EG_GENERIC") != nullptr, num("DGCN_EG_WPS"), num("DGCN_EG_WAVES"), num("DGCN_EG_DEBUG")};
+  }();
+  return t;
+}
+#else
+inline EgTuning eg_tuning() { return EgTuning{false, 0, 0, 0}; }
+#endif
+
 struct EgParams {
   int n_rows, n_edges, n_items, item_len;
   const int32_t* rowptr;
@@ -73,7 +93,7 @@ struct EgParams {
   float* z_save;            // [E][C] original edge order, or null
   float* part;              // [n_items][2][4][C]
   int32_t* info;            // [n_items][kEgInfo]
-  int dbg;                  // profiling builds only (DGCN_EG_DEBUG): 1 skip the walk, 2 skip the MFMA chain, 4 skip feature loads
+  int dbg;                  // tuning builds only (EgTuning::dbg); 0 in the product build
 };
 
 // ---- state -> result ------------------------------------------------------------------------------------------
@@ -706,204 +726,6 @@ __device__ __forceinline__ void egd_finish_item(const EgParams& P, EgWalk& wk, i
   if (ie >= P.n_edges) egd_empty_rows<MODE, NT>(P, wk.cur_row + 1, P.n_rows, n, writer, p);
 }
 
-#ifdef DGCN_EG_WITH_FP32_PIPE   // tuning builds only: the fp32-MFMA core behind the same fold, for A/B measurements
-template <int NT, int KC, int MODE>
-__global__ __launch_bounds__(kEgMaxWaves * kWave) void egemm_fwd_pipe_kernel(const EgParams P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int H = 2 * KC;                 // 16-float halves of a feature row
-  constexpr int D = kEgAhead < H ? kEgAhead : H;
-  constexpr int G0 = (NT + 1) / 2;          // channel tiles of the first B group
-  constexpr int G1 = NT - G0;
-  const int C = P.C, K = P.K;
-  constexpr int Kpad = KC * kEgChunk;       // == P.Kpad (the launcher picks KC from it)
-  constexpr int WS = Kpad + kEgWPad;        // compile-time stride: LDS offsets become immediates
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int nwaves = blockDim.x >> 6;
-  float* Wl = smem;
-  {
-    constexpr int q4 = Kpad / 4;
-    for (int idx = threadIdx.x; idx < NT * 16 * q4; idx += blockDim.x) {
-      const int r = idx / q4, c4 = (idx - r * q4) * 4;
-      f4v v = {0.f, 0.f, 0.f, 0.f};
-      if (r < C && c4 < K) v = *reinterpret_cast<const f4v*>(P.w + static_cast<int64_t>(r) * K + c4);
-      *reinterpret_cast<f4v*>(Wl + r * WS + c4) = v;
-    }
-  }
-  __syncthreads();
-
-  const int n = lane & 15;
-  const int kb = lane >> 4;                 // k slot of the A / B operands = row block q of the D tile
-  const bool writer = lane < 16;
-  const float t = P.t_dev ? *P.t_dev : P.t;
-  const float p = P.p_dev ? *P.p_dev : P.p;
-  const float eps = P.eps;
-  const float eps_r = eps;                  // this variant serves msg = relu(z) + eps only
-  const float t2 = t * 1.4426950408889634f;
-  const float c0s = t2 * eps_r;
-  const int E = P.n_edges;
-  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
-  const int istride = gridDim.x * nwaves;
-  const bool last_half_ok = (H - 1) * 16 < K;        // K % 32 == 16: the last half-chunk is padding
-
-  float bias[NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) bias[ct] = (P.b && ct * 16 + n < C) ? P.b[ct * 16 + n] : 0.f;
-
-  EgCoord cur;
-  cur.item = blockIdx.x * nwaves + wave;
-  if (cur.item >= P.n_items) return;
-  cur.b = cur.item * P.item_len;
-  cur.ie = min(cur.b + P.item_len, E);
-  auto next_coord = [&](const EgCoord& c, bool& valid) {
-    EgCoord x = c;
-    valid = true;
-    if (c.b + kEgM < c.ie) {
-      x.b = c.b + kEgM;
-    } else if (c.item + istride < P.n_items) {
-      x.item = c.item + istride;
-      x.b = x.item * P.item_len;
-      x.ie = min(x.b + P.item_len, E);
-    } else {
-      valid = false;          // x == c: loads issued for it are harmless duplicates
-    }
-    return x;
-  };
-  // x rows of the batch in the D layout (lane (n, q): edges 4 q + j, channels 16 ct + n); requested at the top of the
-  // MFMA chain and added to the tile after it, so their (L2) latency is covered by the chain
-  auto gather_x = [&](f4v (&xg)[NT], int srcv) {
-    int srcj[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) srcj[j] = __shfl(srcv, 4 * kb + j);
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-      const int ch = ct * 16 + n;
-      const bool chok = ch < C;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xg[ct][j] = chok ? row_ptr(P.x, srcj[j], xs32)[ch] : 0.f;
-    }
-  };
-  auto load_a = [&](const float* arow, int h) -> f4v {
-    if (P.dbg & 4) return f4v{1.f, 1.f, 1.f, 1.f};
-    if (h == H - 1 && !last_half_ok) return f4v{0.f, 0.f, 0.f, 0.f};
-    return *reinterpret_cast<const f4v*>(arow + h * 16);
-  };
-  const float* wl0 = Wl + n * WS + 4 * kb;
-
-  bool vn, vnn;
-  EgCoord nxt = next_coord(cur, vn);
-  EgMeta mc = eg_load_meta(P, cur, lane);
-  EgMeta mn = eg_load_meta(P, nxt, lane);
-  const float* arow_c = P.feat + static_cast<int64_t>(mc.eid) * P.feat_stride + 4 * kb;
-  f4v a[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) a[h] = f4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int h = 0; h < D; ++h) a[h] = load_a(arow_c, h);
-  f4v acc[NT];
-  f4v b0[G0], b1[G1 > 0 ? G1 : 1];
-#pragma unroll
-  for (int g = 0; g < G0; ++g) b0[g] = *reinterpret_cast<const f4v*>(wl0 + g * 16 * WS);
-
-  EgWalk wk;
-  State<NT> st;
-  wk.cur_row = -1; wk.cnt = 0; wk.head = 0; wk.head_row = -1; wk.head_cont = 0; wk.tail_row = -1;
-  state_init<MODE, NT>(st);
-
-  while (true) {
-    const EgCoord nn = next_coord(nxt, vnn);
-    const EgMeta mnn = eg_load_meta(P, nn, lane);
-    const float* arow_n = P.feat + static_cast<int64_t>(mn.eid) * P.feat_stride + 4 * kb;
-
-    // ---- tile = bias + F W^T (+ x after the chain) ----
-    f4v xg[NT];
-    gather_x(xg, mc.src);
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[ct] = f4v{bias[ct], bias[ct], bias[ct], bias[ct]};
-    if (!(P.dbg & 2))
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      // feature halves kEgAhead steps ahead (wrapping into the next batch's rows)
-      if (h + D < H) {
-        a[h + D] = load_a(arow_c, h + D);
-      } else if (H > D) {
-        a[h + D - H] = load_a(arow_n, h + D - H);       // ring slot consumed earlier in this batch
-      }
-      if constexpr (G1 > 0) {
-#pragma unroll
-        for (int g = 0; g < G1; ++g) b1[g] = *reinterpret_cast<const f4v*>(wl0 + (G0 + g) * 16 * WS + h * 16);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const f4v ah = a[h];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int g = 0; g < G0; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], b0[g][j], acc[g], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const int hn = (h + 1 < H) ? h + 1 : 0;      // the first group of the next half (of the next batch at the end)
-#pragma unroll
-        for (int g = 0; g < G0; ++g) b0[g] = *reinterpret_cast<const f4v*>(wl0 + g * 16 * WS + hn * 16);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (G1 > 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int g = 0; g < G1; ++g) {
-            acc[G0 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], b1[g][j], acc[G0 + g], 0, 0, 0);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (H <= D) {
-      // short rows: the ring holds a whole row; request the next batch's row now
-#pragma unroll
-      for (int h = 0; h < H; ++h) a[h] = load_a(arow_n, h);
-    }
-
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[ct] += xg[ct];
-
-    // ---- fold the tile (it stays in the accumulators) ----
-    const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
-    const int item = cur.item;
-    if (cur.b == cur.item * P.item_len) {       // first batch of an item: whose row comes in, which rows are empty
-      const int first_row = __builtin_amdgcn_readlane(mc.row, 0);
-      const int prev_row = cur.b > 0 ? __builtin_amdgcn_readlane(mc.row, kEgLanePrev) : -1;
-      wk.head_row = -1; wk.tail_row = -1; wk.head_cont = 0; wk.cnt = 0;
-      wk.head = (prev_row == first_row) ? 1 : 0;
-      wk.cur_row = first_row;
-      state_init<MODE, NT>(st);
-      if (!wk.head) egd_empty_rows<MODE, NT>(P, prev_row + 1, first_row, n, writer, p);
-    }
-    constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
-    if (CAN_D && P.with_d) {
-      egd_walk_batch<MODE, NT, CAN_D>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kb, writer, eps, eps_r, t2, c0s, p);
-    } else {
-      egd_walk_batch<MODE, NT, false>(P, wk, item, st, acc, nb, mc.row, mc.eid, n, kb, writer, eps, eps_r, t2, c0s, p);
-    }
-    if (cur.b + kEgM >= cur.ie) {               // last batch of the item
-      const int ie = cur.ie;
-      const int next_row = (ie < E) ? __builtin_amdgcn_readlane(mc.row, kEgLaneNext) : P.n_rows;
-      egd_finish_item<MODE, NT>(P, wk, item, ie, next_row, st, n, writer, eps_r, p);
-      if (lane == 0) {
-        int32_t* info = P.info + static_cast<int64_t>(item) * kEgInfo;
-        info[0] = wk.head_row;
-        info[1] = wk.tail_row;
-        info[2] = wk.head_cont;
-        info[3] = 0;
-      }
-    }
-    if (!vn) break;
-    cur = nxt; mc = mn; nxt = nn; mn = mnn; vn = vnn;
-    arow_c = arow_n;
-  }
-}
-
-#endif  // DGCN_EG_WITH_FP32_PIPE
 
 // ---- the same kernel with the GEMM on the bf16 matrix cores, fp32-faithful ("bf16x6") ----------------------------
 // fp32 MFMA runs on the vector ALU at the vector rate; v_mfma_f32_16x16x32_bf16 runs on the matrix pipe at 16x that
@@ -1302,8 +1124,7 @@ inline bool eg_pipelined_shape(int nt, int kc) {
          (nt == 4 && kc == 2);
 }
 inline int eg_wps(int nt, int mode) {
-  const char* e = getenv("DGCN_EG_WPS");
-  if (e && atoi(e) == 2) return 2;
+  if (eg_tuning().wps == 2) return 2;
   // the register-lean variant pays off where the fold state is small (max: 0.378 -> 0.347 ms at K = 224, C = 112);
   // the softmax / power folds spill in it and stay on the two-waves layout
   const bool small_state = mode == DGCN_AGGR_MAX || mode == DGCN_AGGR_ADD || mode == DGCN_AGGR_MEAN;
@@ -1333,7 +1154,7 @@ inline bool eg_layout(int n_feat, int channels, EgLayout* L) {
 
 inline int eg_waves_per_cu(const EgLayout& L, int msg, int mode) {
   const int kc = L.kpad / kEgChunk;
-  if (msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, kc) && !getenv("DGCN_EG_GENERIC")) {
+  if (msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, kc) && !eg_tuning().generic) {
     return eg_wps(L.nt, mode) == 3 ? 12 : kEgMaxWaves;
   }
   return L.nwaves;
@@ -1352,25 +1173,6 @@ int launch_egemm(const EgParams& P, const EgLayout& L, hipStream_t s) {
   return DGCN_OK;
 }
 
-#ifdef DGCN_EG_WITH_FP32_PIPE
-template <int NT, int KC, int MODE>
-int launch_egemm_pipe_mode(const EgParams& P, hipStream_t s) {
-  const size_t lds = static_cast<size_t>(NT) * 16 * (KC * kEgChunk + kEgWPad) * sizeof(float);   // weights only
-  const void* fn = reinterpret_cast<const void*>(egemm_fwd_pipe_kernel<NT, KC, MODE>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  if (e != hipSuccess) return static_cast<int>(e);
-  int nwaves = kEgMaxWaves;
-  {
-    const char* w = getenv("DGCN_EG_WAVES");
-    if (w && atoi(w) >= 1 && atoi(w) <= kEgMaxWaves) nwaves = atoi(w);
-  }
-  int grid = (P.n_items + nwaves - 1) / nwaves;
-  if (grid > kNumCU) grid = kNumCU;                 // VGPR-bound: one workgroup of 8 waves per CU
-  hipLaunchKernelGGL((egemm_fwd_pipe_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);
-  return DGCN_OK;
-}
-
-#endif
 
 template <int NT, int KC, int MODE>
 int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
@@ -1386,10 +1188,7 @@ int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
   int nwaves = w3 ? 12 : kEgMaxWaves;
-  {
-    const char* w = getenv("DGCN_EG_WAVES");
-    if (w && atoi(w) >= 1 && atoi(w) <= nwaves) nwaves = atoi(w);
-  }
+  if (const int w = eg_tuning().waves; w >= 1 && w <= nwaves) nwaves = w;
   int grid = (P.n_items + nwaves - 1) / nwaves;
   if (grid > kNumCU) grid = kNumCU;                 // the weight planes fill the LDS: one workgroup per CU
   if constexpr (kHasW3) {
@@ -1413,35 +1212,14 @@ int launch_egemm_bf16(const EgParams& P, hipStream_t s) {
   }
 }
 
-#ifdef DGCN_EG_WITH_FP32_PIPE
-template <int NT, int KC>
-int launch_egemm_pipe(const EgParams& P, hipStream_t s) {
-  switch (P.mode) {
-    case DGCN_AGGR_ADD: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_ADD>(P, s);
-    case DGCN_AGGR_MEAN: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_MEAN>(P, s);
-    case DGCN_AGGR_MAX: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_MAX>(P, s);
-    case DGCN_AGGR_SOFTMAX: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_SOFTMAX>(P, s);
-    default: return launch_egemm_pipe_mode<NT, KC, DGCN_AGGR_POWER>(P, s);
-  }
-}
-
-#endif
 
 // (channel tiles, feature chunks) of the reference's models get the pipelined kernel; every other supported shape
 // (and the identity message) takes the generic one.  hidden/group: 224/2, 64/2, 80/2 (RevGNN-Deep), 128/2; ungrouped
 // hidden 64 and 128 (examples/ogb/ogbn_proteins/model.py, ogbg_ppa/model.py).
 int launch_egemm_any(const EgParams& P, const EgLayout& L, hipStream_t s) {
   const int kc = L.kpad / kEgChunk;
-  const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !getenv("DGCN_EG_GENERIC") && eg_pipelined_shape(L.nt, kc);
-#ifdef DGCN_EG_WITH_FP32_PIPE
-  const bool fp32_mfma = getenv("DGCN_EG_FP32") != nullptr;    // the fp32-MFMA variant of the same kernel
-#define DGCN_EG_CASE(NTV, KCV)                                                    \
-  if (pipe_ok && L.nt == NTV && kc == KCV) {                                      \
-    return fp32_mfma ? launch_egemm_pipe<NTV, KCV>(P, s) : launch_egemm_bf16<NTV, KCV>(P, s); \
-  }
-#else
+  const bool pipe_ok = P.msg == DGCN_MSG_RELU_EPS && !eg_tuning().generic && eg_pipelined_shape(L.nt, kc);
 #define DGCN_EG_CASE(NTV, KCV) if (pipe_ok && L.nt == NTV && kc == KCV) return launch_egemm_bf16<NTV, KCV>(P, s);
-#endif
   DGCN_EG_CASE(7, 7)
   DGCN_EG_CASE(2, 2)
   DGCN_EG_CASE(3, 3)
@@ -1522,16 +1300,13 @@ extern "C" int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* e
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
   P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
   P.z_save = z_save;
-  {
-    const char* e = getenv("DGCN_EG_DEBUG");
-    P.dbg = e ? atoi(e) : 0;
-  }
+  P.dbg = eg_tuning().dbg;
   P.part = static_cast<float*>(workspace);
   P.info = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                       static_cast<size_t>(P.n_items) * 2u * 4u * channels * sizeof(float));
   hipStream_t s = static_cast<hipStream_t>(stream);
   P.xg = x; P.xg_stride = x_stride;
-  if (enc_bias && msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, L.kpad / kEgChunk) && !getenv("DGCN_EG_GENERIC")) {
+  if (enc_bias && msg == DGCN_MSG_RELU_EPS && eg_pipelined_shape(L.nt, L.kpad / kEgChunk) && !eg_tuning().generic) {
     // gather source with the bias folded in, behind the partial-state area of the workspace
     const size_t n_items12 = static_cast<size_t>(eg_num_items(g->n_edges, 12));
     const size_t part = n_items12 * (2u * 4u * static_cast<size_t>(channels) * sizeof(float) + kEgInfo * sizeof(int32_t));

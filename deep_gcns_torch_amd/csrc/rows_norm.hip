@@ -13,11 +13,63 @@
 //              rows_bn_bwd_finalize                 dgamma, dbeta, the two batch-mean coefficients
 //              rows_bn_bwd_apply (read g, x[, y], write dx)   dx = scale*(g' - c1 - xhat*c2)
 // Sums are accumulated per workgroup in a fixed order and combined in fp64: deterministic.
+//
+// The pre-activation run  norm -> ReLU -> dropout  of the 'res+' blocks (examples/ogb/ogbn_arxiv/model.py:90-106) and of
+// the reversible BasicBlock (eff_gcn_modules/rev/rev_layer.py:35-51) is ONE apply pass here: the dropout mask is either a
+// counter hash of (seed, element index) -- regenerated, never stored -- or the shared mask tensor the reversible model
+// hands to every layer; the backward recomputes the ReLU mask from x and the saved coefficients instead of reading y,
+// and can add the gradient of a skip connection in its apply pass.
 
 #include "dgcn_common.h"
 
 namespace dgcn {
 namespace {
+
+// ---- dropout inside the row kernels ------------------------------------------------------------------------------
+// mode 0: none.  mode 1: keep element i iff u16(i) >= thr, u16 = 16 bits of a murmur-style hash of (seed, i >> 2)
+// (four elements per hash pair; keep probability 1 - thr / 65536, kept values scaled by inv_keep).  mode 2: multiply by
+// mask[i] (SharedDropout: the model's own mask tensor, already scaled).
+struct DropArgs {
+  int mode;
+  const float* mask;
+  int64_t mld;          // row stride of mask (floats): a chunk view of the model's (N, hidden) mask is used in place
+  uint32_t s0, s1, thr;
+  float inv_keep;
+};
+
+__device__ __forceinline__ uint32_t drop_mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+// the four 16-bit draws of element group q (elements 4q .. 4q+3 of the flattened (rows, C) array)
+__device__ __forceinline__ void drop_rand4(uint64_t q, uint32_t s0, uint32_t s1, uint32_t (&r)[4]) {
+  const uint32_t lo = static_cast<uint32_t>(q), hi = static_cast<uint32_t>(q >> 32);
+  uint32_t h0 = drop_mix32(lo ^ s0);
+  h0 = drop_mix32(h0 + hi * 0x9E3779B1u + s1);
+  const uint32_t h1 = drop_mix32(h0 ^ 0x68E31DA4u);
+  r[0] = h0 & 0xffffu; r[1] = h0 >> 16; r[2] = h1 & 0xffffu; r[3] = h1 >> 16;
+}
+
+// factor[j] = what element (r, c + j) of the (rows, C) array is multiplied with; (r * C + c) % VEC == 0
+template <int VEC>
+__device__ __forceinline__ void drop_factors(const DropArgs& D, int64_t r, int c, int C, float (&f)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) f[j] = 1.f;
+  const int64_t base = r * C + c;
+  if (D.mode == 1) {
+    uint32_t r[4];
+    drop_rand4(static_cast<uint64_t>(base) >> 2, D.s0, D.s1, r);
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = (r[j] >= D.thr) ? D.inv_keep : 0.f;
+    } else {
+      f[0] = (r[base & 3] >= D.thr) ? D.inv_keep : 0.f;
+    }
+  } else if (D.mode == 2) {
+    load_vec<VEC>(f, D.mask + r * D.mld + c);
+  }
+}
 
 constexpr int kMaxParts = 512;
 constexpr int kFinThreads = 1024;
@@ -87,7 +139,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_stats_kernel(const float* __r
 template <int VEC, bool RELU>
 __global__ __launch_bounds__(kWgThreads) void rows_bn_apply_kernel(const float* __restrict__ x, int64_t ld,
                                                                   const float* __restrict__ bnbuf,
-                                                                  float* __restrict__ y, int64_t rows, int C) {
+                                                                  float* __restrict__ y, int64_t rows, int C,
+                                                                  const DropArgs D) {
   const RowsGeom G = rows_geom(C, VEC);
   const int cgi = threadIdx.x % G.cg;
   const int rl = threadIdx.x / G.cg;
@@ -104,50 +157,66 @@ __global__ __launch_bounds__(kWgThreads) void rows_bn_apply_kernel(const float* 
       o[j] = fmaf(a[j], sc[j], sh[j]);
       if (RELU) o[j] = fmaxf(o[j], 0.f);
     }
+    if (D.mode) {
+      float f[VEC];
+      drop_factors<VEC>(D, r, cgi * VEC, C, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] *= f[j];
+    }
     store_vec<VEC>(y + r * C + cgi * VEC, o);
   }
 }
 
 // ---- backward statistics: partial[wg][0][c] = sum g', partial[wg][1][c] = sum g'*xhat
-template <int VEC, bool RELU>
+// g' = g * (dropout factor) * [ReLU mask].  RELU: 0 none, 1 mask = [y > 0] read from the forward output,
+// 2 mask = [scale*x + shift > 0] recomputed from x (nothing but g and x is read).
+template <int VEC, int RELU>
 __global__ __launch_bounds__(kWgThreads) void rows_bn_bwd_stats_kernel(const float* __restrict__ g,
                                                                       const float* __restrict__ x, int64_t ld,
                                                                       const float* __restrict__ y,
                                                                       const float* __restrict__ bnbuf, int64_t rows,
                                                                       int C, float* __restrict__ partial,
-                                                                      int64_t slab) {
+                                                                      int64_t slab, const DropArgs D) {
   __shared__ float red[2][kWgThreads * VEC];
   const RowsGeom G = rows_geom(C, VEC);
   const int cgi = threadIdx.x % G.cg;
   const int rl = threadIdx.x / G.cg;
   const int64_t r0 = blockIdx.x * slab;
   const int64_t r1 = min(rows, r0 + slab);
-  float s[VEC], q[VEC], mean[VEC], istd[VEC];
+  float s[VEC], q[VEC], mean[VEC], istd[VEC], sc[VEC], sh[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; mean[j] = 0.f; istd[j] = 0.f; }
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; mean[j] = 0.f; istd[j] = 0.f; sc[j] = 0.f; sh[j] = 0.f; }
   if (rl < G.rpp) {
     load_vec<VEC>(mean, bnbuf + 2 * C + cgi * VEC);
     load_vec<VEC>(istd, bnbuf + 3 * C + cgi * VEC);
+    if (RELU == 2) {
+      load_vec<VEC>(sc, bnbuf + cgi * VEC);
+      load_vec<VEC>(sh, bnbuf + C + cgi * VEC);
+    }
     for (int64_t r = r0 + rl; r < r1; r += 2 * G.rpp) {
-      float gg[2][VEC], xx[2][VEC], yy[2][VEC];
+      float gg[2][VEC], xx[2][VEC], yy[2][VEC], ff[2][VEC];
       bool ok[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int64_t rr = r + static_cast<int64_t>(u) * G.rpp;
         ok[u] = rr < r1;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { gg[u][j] = 0.f; xx[u][j] = 0.f; yy[u][j] = 1.f; }
+        for (int j = 0; j < VEC; ++j) { gg[u][j] = 0.f; xx[u][j] = 0.f; yy[u][j] = 1.f; ff[u][j] = 1.f; }
         if (ok[u]) {
           load_vec<VEC>(gg[u], g + rr * C + cgi * VEC);
           load_vec<VEC>(xx[u], x + rr * ld + cgi * VEC);
-          if (RELU) load_vec<VEC>(yy[u], y + rr * C + cgi * VEC);
+          if (RELU == 1) load_vec<VEC>(yy[u], y + rr * C + cgi * VEC);
+          if (D.mode) drop_factors<VEC>(D, rr, cgi * VEC, C, ff[u]);
         }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float gp = (RELU && !(yy[u][j] > 0.f)) ? 0.f : gg[u][j];
+          bool dead = false;
+          if (RELU == 1) dead = !(yy[u][j] > 0.f);
+          if (RELU == 2) dead = !(fmaf(xx[u][j], sc[j], sh[j]) > 0.f);
+          const float gp = dead ? 0.f : gg[u][j] * ff[u][j];
           const float xh = (xx[u][j] - mean[j]) * istd[j];
           s[j] += gp;
           q[j] = fmaf(gp, xh, q[j]);
@@ -201,37 +270,45 @@ __global__ __launch_bounds__(kFinThreads) void rows_bn_bwd_finalize_kernel(const
   }
 }
 
-// ---- backward apply: dx = scale*(g' - c1 - xhat*c2)
-template <int VEC, bool RELU>
+// ---- backward apply: dx = scale*(g' - c1 - xhat*c2) [+ gadd]   (gadd: the gradient of a skip connection around the block)
+template <int VEC, int RELU>
 __global__ __launch_bounds__(kWgThreads) void rows_bn_bwd_apply_kernel(const float* __restrict__ g,
                                                                       const float* __restrict__ x, int64_t ld,
                                                                       const float* __restrict__ y,
                                                                       const float* __restrict__ bnbuf,
                                                                       const float* __restrict__ coef,
-                                                                      float* __restrict__ dx, int64_t rows, int C) {
+                                                                      float* __restrict__ dx, int64_t rows, int C,
+                                                                      const DropArgs D,
+                                                                      const float* __restrict__ gadd) {
   const RowsGeom G = rows_geom(C, VEC);
   const int cgi = threadIdx.x % G.cg;
   const int rl = threadIdx.x / G.cg;
   if (rl >= G.rpp) return;
-  float sc[VEC], mean[VEC], istd[VEC], c1[VEC], c2[VEC];
+  float sc[VEC], sh[VEC], mean[VEC], istd[VEC], c1[VEC], c2[VEC];
   load_vec<VEC>(sc, bnbuf + cgi * VEC);
+  load_vec<VEC>(sh, bnbuf + C + cgi * VEC);
   load_vec<VEC>(mean, bnbuf + 2 * C + cgi * VEC);
   load_vec<VEC>(istd, bnbuf + 3 * C + cgi * VEC);
   load_vec<VEC>(c1, coef + 2 * C + cgi * VEC);
   load_vec<VEC>(c2, coef + 3 * C + cgi * VEC);
   const int64_t step = static_cast<int64_t>(gridDim.x) * G.rpp;
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * G.rpp + rl; r < rows; r += step) {
-    float gg[VEC], xx[VEC], yy[VEC], o[VEC];
+    float gg[VEC], xx[VEC], yy[VEC], ff[VEC], ga[VEC], o[VEC];
     load_vec<VEC>(gg, g + r * C + cgi * VEC);
     load_vec<VEC>(xx, x + r * ld + cgi * VEC);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) yy[j] = 1.f;
-    if (RELU) load_vec<VEC>(yy, y + r * C + cgi * VEC);
+    for (int j = 0; j < VEC; ++j) { yy[j] = 1.f; ff[j] = 1.f; ga[j] = 0.f; }
+    if (RELU == 1) load_vec<VEC>(yy, y + r * C + cgi * VEC);
+    if (gadd) load_vec<VEC>(ga, gadd + r * C + cgi * VEC);
+    if (D.mode) drop_factors<VEC>(D, r, cgi * VEC, C, ff);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float gp = (RELU && !(yy[j] > 0.f)) ? 0.f : gg[j];
+      bool dead = false;
+      if (RELU == 1) dead = !(yy[j] > 0.f);
+      if (RELU == 2) dead = !(fmaf(xx[j], sc[j], sh[j]) > 0.f);
+      const float gp = dead ? 0.f : gg[j] * ff[j];
       const float xh = (xx[j] - mean[j]) * istd[j];
-      o[j] = sc[j] * (gp - c1[j] - xh * c2[j]);
+      o[j] = sc[j] * (gp - c1[j] - xh * c2[j]) + ga[j];
     }
     store_vec<VEC>(dx + r * C + cgi * VEC, o);
   }
@@ -278,44 +355,136 @@ extern "C" int dgcn_rows_stats_f32(const float* x, int64_t ld, int64_t rows, int
   return launch_status();
 }
 
-extern "C" int dgcn_rows_bn_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu, float* y,
-                                      int64_t rows, int32_t C, void* stream) {
+namespace dgcn {
+namespace {
+
+inline DropArgs drop_none() { return DropArgs{0, nullptr, 0, 0u, 0u, 0u, 1.f}; }
+
+// drop_mode 1: seed = (s0, s1), thr in [0, 65535] (drop probability thr / 65536); drop_mode 2: mask (rows, C), row stride mld
+inline int drop_make(int32_t drop_mode, const float* mask, int64_t mld, uint32_t s0, uint32_t s1, uint32_t thr,
+                     int32_t C, DropArgs* D) {
+  *D = drop_none();
+  if (drop_mode == 0) return DGCN_OK;
+  if (drop_mode == 1) {
+    if (thr > 65535u) return DGCN_E_SHAPE;
+    D->mode = 1; D->s0 = s0; D->s1 = s1; D->thr = thr;
+    D->inv_keep = 65536.f / static_cast<float>(65536u - thr);
+    return DGCN_OK;
+  }
+  if (drop_mode == 2) {
+    if (!mask) return DGCN_E_NULL;
+    if (mld < C) return DGCN_E_SHAPE;
+    D->mode = 2; D->mask = mask; D->mld = mld;
+    return DGCN_OK;
+  }
+  return DGCN_E_MODE;
+}
+
+int rows_bn_apply_impl(const float* x, int64_t ld, const float* bnbuf, int32_t relu, float* y, int64_t rows,
+                       int32_t C, const DropArgs& D, void* stream) {
   if (!x || !bnbuf || !y) return DGCN_E_NULL;
   if (rows < 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
   if (rows == 0) return DGCN_OK;
-  const int vec = pick_vec(C, ld, x, y, bnbuf, nullptr);
+  int vec = pick_vec(C, ld, x, y, bnbuf, D.mask);
+  if (vec == 4 && D.mode == 2 && D.mld % 4 != 0) vec = 1;
   if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
   const RowsGeom G = rows_geom(C, vec);
   const int grid = stream_grid(rows, G.rpp);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (vec == 4) {
-    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<4, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
-    else hipLaunchKernelGGL((rows_bn_apply_kernel<4, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<4, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C, D);
+    else hipLaunchKernelGGL((rows_bn_apply_kernel<4, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C, D);
   } else {
-    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<1, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
-    else hipLaunchKernelGGL((rows_bn_apply_kernel<1, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C);
+    if (relu) hipLaunchKernelGGL((rows_bn_apply_kernel<1, true>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C, D);
+    else hipLaunchKernelGGL((rows_bn_apply_kernel<1, false>), dim3(grid), dim3(kWgThreads), 0, s, x, ld, bnbuf, y, rows, C, D);
   }
   return launch_status();
+}
+
+// relu_mode: 0 none, 1 from y, 2 recomputed from x
+int rows_bn_bwd_stats_impl(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
+                           float* partial, int64_t rows, int32_t C, int relu_mode, const DropArgs& D, void* stream) {
+  if (!g || !x || !bnbuf || !partial || (relu_mode == 1 && !y)) return DGCN_E_NULL;
+  if (rows <= 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  int vec = pick_vec(C, ld, x, g, y, bnbuf);
+  if (vec == 4 && D.mask && ((reinterpret_cast<uintptr_t>(D.mask) & 15u) || D.mld % 4 != 0)) vec = 1;
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const int nparts = dgcn_rows_num_partials(rows, C);
+  const int64_t slab = (rows + nparts - 1) / nparts;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DGCN_BN_STATS(V, R) hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<V, R>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab, D)
+  if (vec == 4) {
+    if (relu_mode == 1) DGCN_BN_STATS(4, 1); else if (relu_mode == 2) DGCN_BN_STATS(4, 2); else DGCN_BN_STATS(4, 0);
+  } else {
+    if (relu_mode == 1) DGCN_BN_STATS(1, 1); else if (relu_mode == 2) DGCN_BN_STATS(1, 2); else DGCN_BN_STATS(1, 0);
+  }
+#undef DGCN_BN_STATS
+  return launch_status();
+}
+
+int rows_bn_bwd_apply_impl(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
+                           const float* coef, float* dx, int64_t rows, int32_t C, int relu_mode, const DropArgs& D,
+                           const float* gadd, void* stream) {
+  if (!g || !x || !bnbuf || !coef || !dx || (relu_mode == 1 && !y)) return DGCN_E_NULL;
+  if (rows < 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
+  if (rows == 0) return DGCN_OK;
+  int vec = pick_vec(C, ld, x, g, y, dx);
+  auto mis = [](const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15u); };
+  if (vec == 4 && (mis(bnbuf) || mis(coef) || mis(D.mask) || mis(gadd) || (D.mode == 2 && D.mld % 4 != 0))) vec = 1;
+  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
+  const RowsGeom G = rows_geom(C, vec);
+  const int grid = stream_grid(rows, G.rpp);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DGCN_BN_APPLY(V, R) hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<V, R>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C, D, gadd)
+  if (vec == 4) {
+    if (relu_mode == 1) DGCN_BN_APPLY(4, 1); else if (relu_mode == 2) DGCN_BN_APPLY(4, 2); else DGCN_BN_APPLY(4, 0);
+  } else {
+    if (relu_mode == 1) DGCN_BN_APPLY(1, 1); else if (relu_mode == 2) DGCN_BN_APPLY(1, 2); else DGCN_BN_APPLY(1, 0);
+  }
+#undef DGCN_BN_APPLY
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace dgcn
+
+extern "C" int dgcn_rows_bn_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu, float* y,
+                                      int64_t rows, int32_t C, void* stream) {
+  return rows_bn_apply_impl(x, ld, bnbuf, relu, y, rows, C, drop_none(), stream);
 }
 
 extern "C" int dgcn_rows_bn_bwd_stats_f32(const float* g, const float* x, int64_t ld, const float* y,
                                           const float* bnbuf, float* partial, int64_t rows, int32_t C,
                                           void* stream) {
-  if (!g || !x || !bnbuf || !partial) return DGCN_E_NULL;
-  if (rows <= 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
-  const int vec = pick_vec(C, ld, x, g, y, bnbuf);
-  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
-  const int nparts = dgcn_rows_num_partials(rows, C);
-  const int64_t slab = (rows + nparts - 1) / nparts;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec == 4) {
-    if (y) hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<4, true>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
-    else hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<4, false>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
-  } else {
-    if (y) hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<1, true>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
-    else hipLaunchKernelGGL((rows_bn_bwd_stats_kernel<1, false>), dim3(nparts), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, rows, C, partial, slab);
-  }
-  return launch_status();
+  return rows_bn_bwd_stats_impl(g, x, ld, y, bnbuf, partial, rows, C, y ? 1 : 0, drop_none(), stream);
+}
+
+// ---- norm -> [ReLU] -> [dropout] in one apply pass, and its backward (ReLU mask recomputed from x) ----
+extern "C" int dgcn_rows_bn_act_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu,
+                                          int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1,
+                                          uint32_t drop_thr, float* y, int64_t rows, int32_t C, void* stream) {
+  DropArgs D;
+  if (const int rc = drop_make(drop_mode, drop_mask, drop_mask_ld, seed0, seed1, drop_thr, C, &D)) return rc;
+  return rows_bn_apply_impl(x, ld, bnbuf, relu, y, rows, C, D, stream);
+}
+
+extern "C" int dgcn_rows_bn_act_bwd_stats_f32(const float* g, const float* x, int64_t ld, const float* bnbuf,
+                                              int32_t relu, int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld,
+                                              uint32_t seed0, uint32_t seed1, uint32_t drop_thr, float* partial,
+                                              int64_t rows, int32_t C, void* stream) {
+  DropArgs D;
+  if (const int rc = drop_make(drop_mode, drop_mask, drop_mask_ld, seed0, seed1, drop_thr, C, &D)) return rc;
+  return rows_bn_bwd_stats_impl(g, x, ld, nullptr, bnbuf, partial, rows, C, relu ? 2 : 0, D, stream);
+}
+
+extern "C" int dgcn_rows_bn_act_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* bnbuf,
+                                              const float* coef, int32_t relu, int32_t drop_mode,
+                                              const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1,
+                                              uint32_t drop_thr, const float* gadd, float* dx, int64_t rows,
+                                              int32_t C, void* stream) {
+  DropArgs D;
+  if (const int rc = drop_make(drop_mode, drop_mask, drop_mask_ld, seed0, seed1, drop_thr, C, &D)) return rc;
+  return rows_bn_bwd_apply_impl(g, x, ld, nullptr, bnbuf, coef, dx, rows, C, relu ? 2 : 0, D, gadd, stream);
 }
 
 extern "C" int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t C, double count,
@@ -330,23 +499,7 @@ extern "C" int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t npart
 extern "C" int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* y,
                                           const float* bnbuf, const float* coef, float* dx, int64_t rows,
                                           int32_t C, void* stream) {
-  if (!g || !x || !bnbuf || !coef || !dx) return DGCN_E_NULL;
-  if (rows < 0 || C <= 0 || ld < C) return DGCN_E_SHAPE;
-  if (rows == 0) return DGCN_OK;
-  int vec = pick_vec(C, ld, x, g, y, dx);
-  if (vec == 4 && ((reinterpret_cast<uintptr_t>(bnbuf) | reinterpret_cast<uintptr_t>(coef)) & 15u)) vec = 1;
-  if (vec == 1 && C > kWgThreads) return DGCN_E_SHAPE;
-  const RowsGeom G = rows_geom(C, vec);
-  const int grid = stream_grid(rows, G.rpp);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (vec == 4) {
-    if (y) hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<4, true>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
-    else hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<4, false>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
-  } else {
-    if (y) hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<1, true>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
-    else hipLaunchKernelGGL((rows_bn_bwd_apply_kernel<1, false>), dim3(grid), dim3(kWgThreads), 0, s, g, x, ld, y, bnbuf, coef, dx, rows, C);
-  }
-  return launch_status();
+  return rows_bn_bwd_apply_impl(g, x, ld, y, bnbuf, coef, dx, rows, C, y ? 1 : 0, drop_none(), nullptr, stream);
 }
 
 // =====================================================================================================
@@ -393,7 +546,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_fwd_kernel(const float* __
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps,
                                                                 float* __restrict__ y, float* __restrict__ mean_out,
-                                                                float* __restrict__ rstd_out, int64_t rows, int C) {
+                                                                float* __restrict__ rstd_out, int64_t rows, int C,
+                                                                const DropArgs D) {
   constexpr int RPW = kWave / LPR;
   const int lane = lane_id();
   const int sub = lane / LPR, li = lane % LPR;
@@ -444,6 +598,12 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_fwd_kernel(const float* __
             o[j] = fmaf((v[k][j] - mean) * rstd, gm[k][j], bt[k][j]);
             if (RELU) o[j] = fmaxf(o[j], 0.f);
           }
+          if (D.mode) {
+            float f[4];
+            drop_factors<4>(D, r, (li + k * LPR) * 4, C, f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] *= f[j];
+          }
           store_vec<4>(y + r * C + (li + k * LPR) * 4, o);
         }
       }
@@ -452,6 +612,8 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_fwd_kernel(const float* __
   }
 }
 
+// RELU here: true = some ReLU mask applies; it is [y > 0] when y is given, else [xhat*gamma + beta > 0] recomputed
+// from x (beta may be null = 0).  D: dropout factors multiplied into g.  gadd: gradient of a skip connection.
 template <int LPR, int Q, bool RELU>
 __global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __restrict__ g,
                                                                 const float* __restrict__ x, int64_t ld,
@@ -460,7 +622,9 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __
                                                                 const float* __restrict__ mean_in,
                                                                 const float* __restrict__ rstd_in,
                                                                 float* __restrict__ dx, float* __restrict__ partial,
-                                                                int64_t rows, int C) {
+                                                                int64_t rows, int C,
+                                                                const float* __restrict__ beta, const DropArgs D,
+                                                                const float* __restrict__ gadd) {
   constexpr int RPW = kWave / LPR;
   __shared__ float red[kWavesPerWg][2][LPR * Q * 4];
   const int lane = lane_id();
@@ -468,15 +632,16 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __
   const int wv = threadIdx.x >> 6;
   const int64_t wave = static_cast<int64_t>(blockIdx.x) * kWavesPerWg + wv;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerWg;
-  float gm[Q][4], dg[Q][4], db[Q][4];
+  float gm[Q][4], bt[Q][4], dg[Q][4], db[Q][4];
   bool ok[Q];
 #pragma unroll
   for (int k = 0; k < Q; ++k) {
     const int c = (li + k * LPR) * 4;
     ok[k] = c < C;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { gm[k][j] = 1.f; dg[k][j] = 0.f; db[k][j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { gm[k][j] = 1.f; bt[k][j] = 0.f; dg[k][j] = 0.f; db[k][j] = 0.f; }
     if (ok[k] && gamma) load_vec<4>(gm[k], gamma + c);
+    if (RELU && !y && ok[k] && beta) load_vec<4>(bt[k], beta + c);
   }
   const float inv_c = 1.f / static_cast<float>(C);
   for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwaves * RPW) {
@@ -495,12 +660,21 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __
         const int c = (li + k * LPR) * 4;
         load_vec<4>(gp[k], g + r * C + c);
         load_vec<4>(xv, x + r * ld + c);
-        if (RELU) load_vec<4>(yv, y + r * C + c);
+        if (RELU && y) load_vec<4>(yv, y + r * C + c);
+        if (D.mode) {
+          float f[4];
+          drop_factors<4>(D, r, c, C, f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gp[k][j] *= f[j];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (RELU && !(yv[j] > 0.f)) gp[k][j] = 0.f;
         xh[k][j] = (live && ok[k]) ? (xv[j] - mean) * rstd : 0.f;
+        if (RELU) {
+          const bool pos = y ? (yv[j] > 0.f) : (fmaf(xh[k][j], gm[k][j], bt[k][j]) > 0.f);
+          if (!pos) gp[k][j] = 0.f;
+        }
         const float gh = gp[k][j] * gm[k][j];
         s1 += gh;
         s2 = fmaf(gh, xh[k][j], s2);
@@ -514,9 +688,10 @@ __global__ __launch_bounds__(kWgThreads) void rows_ln_bwd_kernel(const float* __
 #pragma unroll
       for (int k = 0; k < Q; ++k) {
         if (ok[k]) {
-          float o[4];
+          float o[4], ga[4] = {0.f, 0.f, 0.f, 0.f};
+          if (gadd) load_vec<4>(ga, gadd + r * C + (li + k * LPR) * 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = rstd * (gp[k][j] * gm[k][j] - m1 - xh[k][j] * m2);
+          for (int j = 0; j < 4; ++j) o[j] = rstd * (gp[k][j] * gm[k][j] - m1 - xh[k][j] * m2) + ga[j];
           store_vec<4>(dx + r * C + (li + k * LPR) * 4, o);
         }
       }
@@ -592,27 +767,70 @@ extern "C" int32_t dgcn_rows_ln_num_partials(int64_t rows, int32_t C) {
   return ln_grid(rows, ln_geom(C).lpr);
 }
 
+namespace dgcn {
+namespace {
+
+int rows_ln_fwd_impl(const float* x, int64_t ld, const float* gamma, const float* beta, float eps, int32_t relu,
+                     float* y, float* mean, float* rstd, int64_t rows, int32_t C, const DropArgs& D, void* stream) {
+  if (!x || !y || !mean || !rstd) return DGCN_E_NULL;
+  if (rows < 0) return DGCN_E_SHAPE;
+  if (!ln_ok(C, ld, x, y, gamma, beta, D.mask) || (D.mode == 2 && D.mld % 4 != 0)) {
+    return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  }
+  if (rows == 0) return DGCN_OK;
+  if (relu) DGCN_LN_DISPATCH(rows_ln_fwd_kernel, true, x, ld, gamma, beta, eps, y, mean, rstd, rows, C, D);
+  else DGCN_LN_DISPATCH(rows_ln_fwd_kernel, false, x, ld, gamma, beta, eps, y, mean, rstd, rows, C, D);
+  return launch_status();
+}
+
+int rows_ln_bwd_impl(const float* g, const float* x, int64_t ld, const float* y, const float* gamma,
+                     const float* beta, const float* mean, const float* rstd, int32_t relu, const DropArgs& D,
+                     const float* gadd, float* dx, float* partial, int64_t rows, int32_t C, void* stream) {
+  if (!g || !x || !mean || !rstd || (!dx && !partial)) return DGCN_E_NULL;
+  if (rows <= 0) return DGCN_E_SHAPE;
+  auto mis = [](const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15u); };
+  if (!ln_ok(C, ld, x, g, y, gamma, dx) || mis(beta) || mis(D.mask) || mis(gadd) || (D.mode == 2 && D.mld % 4 != 0)) {
+    return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
+  }
+  if (relu) DGCN_LN_DISPATCH(rows_ln_bwd_kernel, true, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C, beta, D, gadd);
+  else DGCN_LN_DISPATCH(rows_ln_bwd_kernel, false, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C, beta, D, gadd);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace dgcn
+
 extern "C" int dgcn_rows_ln_fwd_f32(const float* x, int64_t ld, const float* gamma, const float* beta, float eps,
                                     int32_t relu, float* y, float* mean, float* rstd, int64_t rows, int32_t C,
                                     void* stream) {
-  if (!x || !y || !mean || !rstd) return DGCN_E_NULL;
-  if (rows < 0) return DGCN_E_SHAPE;
-  if (!ln_ok(C, ld, x, y, gamma, beta, nullptr)) return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
-  if (rows == 0) return DGCN_OK;
-  if (relu) DGCN_LN_DISPATCH(rows_ln_fwd_kernel, true, x, ld, gamma, beta, eps, y, mean, rstd, rows, C);
-  else DGCN_LN_DISPATCH(rows_ln_fwd_kernel, false, x, ld, gamma, beta, eps, y, mean, rstd, rows, C);
-  return launch_status();
+  return rows_ln_fwd_impl(x, ld, gamma, beta, eps, relu, y, mean, rstd, rows, C, drop_none(), stream);
 }
 
 extern "C" int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, const float* y, const float* gamma,
                                     const float* mean, const float* rstd, float* dx, float* partial, int64_t rows,
                                     int32_t C, void* stream) {
-  if (!g || !x || !mean || !rstd || (!dx && !partial)) return DGCN_E_NULL;
-  if (rows <= 0) return DGCN_E_SHAPE;
-  if (!ln_ok(C, ld, x, g, y, gamma, dx)) return (C > 0 && C % 4 == 0 && C <= 1024 && ld >= C) ? DGCN_E_ALIGN : DGCN_E_SHAPE;
-  if (y) DGCN_LN_DISPATCH(rows_ln_bwd_kernel, true, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C);
-  else DGCN_LN_DISPATCH(rows_ln_bwd_kernel, false, g, x, ld, y, gamma, mean, rstd, dx, partial, rows, C);
-  return launch_status();
+  return rows_ln_bwd_impl(g, x, ld, y, gamma, nullptr, mean, rstd, y ? 1 : 0, drop_none(), nullptr, dx, partial, rows,
+                          C, stream);
+}
+
+// ---- LayerNorm -> [ReLU] -> [dropout] in one pass; the backward recomputes the ReLU mask from x ----
+extern "C" int dgcn_rows_ln_act_fwd_f32(const float* x, int64_t ld, const float* gamma, const float* beta, float eps,
+                                        int32_t relu, int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0,
+                                        uint32_t seed1, uint32_t drop_thr, float* y, float* mean, float* rstd,
+                                        int64_t rows, int32_t C, void* stream) {
+  DropArgs D;
+  if (const int rc = drop_make(drop_mode, drop_mask, drop_mask_ld, seed0, seed1, drop_thr, C, &D)) return rc;
+  return rows_ln_fwd_impl(x, ld, gamma, beta, eps, relu, y, mean, rstd, rows, C, D, stream);
+}
+
+extern "C" int dgcn_rows_ln_act_bwd_f32(const float* g, const float* x, int64_t ld, const float* gamma,
+                                        const float* beta, const float* mean, const float* rstd, int32_t relu,
+                                        int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1,
+                                        uint32_t drop_thr, const float* gadd, float* dx, float* partial,
+                                        int64_t rows, int32_t C, void* stream) {
+  DropArgs D;
+  if (const int rc = drop_make(drop_mode, drop_mask, drop_mask_ld, seed0, seed1, drop_thr, C, &D)) return rc;
+  return rows_ln_bwd_impl(g, x, ld, nullptr, gamma, beta, mean, rstd, relu, D, gadd, dx, partial, rows, C, stream);
 }
 
 // =====================================================================================================

@@ -18,8 +18,16 @@ What is different ("reversible-aware fusion"):
   (examples/ogb_eff/ogbn_proteins/model_rev.py:98-107); the reference returns an (E, hidden*group) gradient per
   layer and lets autograd add them up (three passes over 1.4 GB per layer at the ogbn-proteins cluster shape).
   Here the layers of one backward pass share one accumulation buffer per such tensor (GENConv adds its
-  ``dz @ W`` straight into the right column block, ``ops.edge_grad_sink``); only the layer whose backward runs last
-  hands the buffer to autograd.
+  ``dz @ W`` straight into the right column block, ``ops.edge_grad_sink``).  No forward-side bookkeeping: the first
+  layer whose backward runs in a backward pass (identified by autograd's graph-task id) creates the buffer and returns
+  a memory-free placeholder gradient, every later layer adds in place and returns nothing, and a tensor hook on the
+  shared argument -- which autograd runs once ALL its users have run -- swaps the placeholder for the finished sum
+  (or adds the sum to whatever other consumers contributed).  Forward passes under ``no_grad``, forwards that are
+  never followed by a backward, aborted backward passes and leaf (Parameter) arguments therefore cannot leave stale
+  state behind.
+* The fused path is taken only for wrapped modules without training-mode BatchNorm: the reference evaluates every
+  ``Fm_i`` three times per step (forward, inverse, recompute), this path twice, so BatchNorm running statistics would
+  receive two momentum updates instead of three.  Such modules take the generic path (= the reference's algorithm).
 """
 import numpy as np
 import torch
@@ -29,8 +37,40 @@ from ... import ops
 
 __all__ = ["InvertibleCheckpointFunction", "InvertibleModuleWrapper", "get_device_states", "set_device_states"]
 
-_USES = "_dgcn_rev_uses"        # attribute on a shared argument tensor: layers whose backward is still to come
-_ACC = "_dgcn_rev_grad"         # attribute on a shared argument tensor: the running gradient sum
+_STATE = "_dgcn_rev_state"      # attribute on a shared argument tensor: its _SharedArgState
+
+
+class _SharedArgState:
+    """Running gradient sum of a tensor every reversible layer receives, valid for ONE backward pass (graph task)."""
+    __slots__ = ("task", "acc", "finish", "ph_ptr")
+
+    def __init__(self):
+        self.task, self.acc, self.finish, self.ph_ptr = -1, None, None, 0
+
+
+def _graph_task_id() -> int:
+    return torch._C._current_graph_task_id()
+
+
+def _deliver_hook(st: _SharedArgState):
+    def hook(grad):
+        if st.acc is None or st.task != _graph_task_id():
+            return None                               # nothing accumulated in this backward pass
+        total = st.finish(st.acc)
+        st.acc, st.task = None, -1
+        if grad.data_ptr() == st.ph_ptr and all(s == 0 for s in grad.stride()):
+            return total                              # only the placeholder arrived: hand over the sum itself
+        return grad + total                           # other consumers of the tensor contributed as well
+    return hook
+
+
+def _ensure_state(t) -> _SharedArgState:
+    st = getattr(t, _STATE, None)
+    if st is None:
+        st = _SharedArgState()
+        setattr(t, _STATE, st)
+        t.register_hook(_deliver_hook(st))            # runs when autograd has the TOTAL gradient of t
+    return st
 
 
 def get_device_states(*args):
@@ -91,11 +131,10 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
         # tensors every layer receives (edge embedding): count the layers whose backward will contribute
         module = getattr(fn, "__self__", None)
         ctx.fused = (hasattr(module, "fused_backward") and getattr(fn, "__name__", "") == "forward"
-                     and not keep_input and not preserve_rng_state)
-        if ctx.fused:
-            for t in inputs[2:]:
-                if _is_shared_arg(t):
-                    setattr(t, _USES, getattr(t, _USES, 0) + 1)
+                     and not keep_input and not preserve_rng_state
+                     and all(hasattr(t, _STATE) and module.arg_sink_ok(t) for t in inputs[2:] if _is_shared_arg(t))
+                     and not any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training
+                                 for m in module.modules()))
         ctx.inputs = [inputs] * num_bwd_passes
         ctx.outputs = [outputs] * num_bwd_passes
         return outputs
@@ -150,14 +189,18 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
         """One grad-enabled evaluation per coupling function: rebuilds the input AND yields the gradients."""
         module = ctx.fn.__self__
         y = outputs[0]
-        shared = [t for t in inputs[2:] if _is_shared_arg(t)]
-        sinks = []
-        for t in shared:                              # running gradient sums of the tensors all layers share
-            acc = getattr(t, _ACC, None)
-            if acc is None:
-                acc = module.make_arg_sink(t)
-                setattr(t, _ACC, acc)
-            sinks.append(acc)
+        tid = _graph_task_id()
+        sinks, first = [], []
+        for t in inputs[2:]:
+            if not _is_shared_arg(t):
+                continue
+            st = getattr(t, _STATE)
+            fresh = st.acc is None or st.task != tid          # first layer of THIS backward pass (stale sums are dropped)
+            if fresh:
+                st.acc, st.task = module.make_arg_sink(t), tid
+                st.finish = (lambda buf, t=t, m=module: m.finish_arg_sink(buf, t))
+            sinks.append(st.acc)
+            first.append(fresh)
         x, grad_x, weight_grads = module.fused_backward(y, grad_outputs[0], inputs[1], inputs[2:], ctx.weights,
                                                         sinks, ops.edge_grad_sink)
         _release(y)
@@ -168,18 +211,18 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
             if not _is_shared_arg(t):
                 arg_grads.append(None)
                 continue
-            left = getattr(t, _USES, 1) - 1
-            if left > 0:
-                setattr(t, _USES, left)
-                arg_grads.append(None)                # a layer further down the backward pass hands the sum over
+            if first[k]:
+                # a stride-0 zero "gradient": autograd then waits for every user of t before it runs t's hook, which
+                # replaces it by the finished sum (the layers that follow add into the buffer in place)
+                st = getattr(t, _STATE)
+                ph = torch.zeros((), device=t.device, dtype=t.dtype).expand(t.shape)
+                st.ph_ptr = ph.data_ptr()
+                arg_grads.append(ph)
             else:
-                arg_grads.append(module.finish_arg_sink(sinks[k], t))
-                for name in (_USES, _ACC):
-                    if hasattr(t, name):
-                        delattr(t, name)
+                arg_grads.append(None)
             k += 1
-        first = grad_x if ctx.input_requires_grad[0] else None
-        return (first, None) + tuple(arg_grads) + tuple(weight_grads)
+        first_in = grad_x if ctx.input_requires_grad[0] else None
+        return (first_in, None) + tuple(arg_grads) + tuple(weight_grads)
 
 
 class InvertibleModuleWrapper(nn.Module):
@@ -201,6 +244,10 @@ class InvertibleModuleWrapper(nn.Module):
 
     def _apply_reversible(self, f, f_inv, keep, args):
         weights = tuple(p for p in self._fn.parameters() if p.requires_grad)
+        if torch.is_grad_enabled() and hasattr(self._fn, "fused_backward"):
+            for t in args[2:]:                        # tensors every layer receives: one delivery hook per tensor
+                if _is_shared_arg(t):
+                    _ensure_state(t)
         out = InvertibleCheckpointFunction.apply(f, f_inv, keep, self.num_bwd_passes, self.preserve_rng_state,
                                                  len(args), *(args + weights))
         return out[0] if isinstance(out, tuple) and len(out) == 1 else out

@@ -48,6 +48,11 @@ class GroupAdditiveCoupling(torch.nn.Module):
         return torch.cat(xs, dim=self.split_dim)
 
     # ------------------------------------------------------------------------------------------------------------
+    def arg_sink_ok(self, t) -> bool:
+        """Whether ``make_arg_sink`` can serve ``t`` (decided in the wrapper's forward: the fused backward is only taken
+        when every shared argument qualifies)."""
+        return t.dim() == 2 and self.split_dim in (-1, 1) and t.size(-1) % self.group == 0
+
     def make_arg_sink(self, t):
         """Running gradient sum of a tensor argument every layer receives: one CONTIGUOUS (rows, width / group) block
         per group (GENConv's ``dz @ W`` is accumulated into it by a plain GEMM with beta = 1, no strided output)."""

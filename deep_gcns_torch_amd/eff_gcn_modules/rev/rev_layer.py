@@ -4,6 +4,7 @@ PyG convolutions and exist only when torch_geometric is installed)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import node_ops
 from ...gcn_lib.sparse.torch_nn import norm_layer
 from ...gcn_lib.sparse.torch_vertex import GENConv
 
@@ -28,7 +29,9 @@ class SharedDropout(nn.Module):
 
 
 class BasicBlock(nn.Module):
-    """norm -> ReLU -> shared dropout -> graph convolution."""
+    """norm -> ReLU -> shared dropout -> graph convolution.  On device rows the first three are ONE row kernel
+    (node_ops.pre_activation: LayerNorm / BatchNorm1d apply pass with the ReLU and the mask multiply folded in; the
+    backward recomputes the ReLU mask from x instead of keeping the activated tensor)."""
 
     def __init__(self, norm, in_channels):
         super().__init__()
@@ -36,10 +39,16 @@ class BasicBlock(nn.Module):
         self.dropout = SharedDropout()
 
     def forward(self, x, edge_index, dropout_mask=None, edge_emb=None):
-        out = F.relu(self.norm(x))
-        if isinstance(self.dropout, SharedDropout) and dropout_mask is not None:
+        shared = isinstance(self.dropout, SharedDropout)
+        if shared and dropout_mask is not None:
             self.dropout.set_mask(dropout_mask)
-        out = self.dropout(out)
+        if shared and x.is_cuda and isinstance(self.norm, (node_ops.BatchNorm1d, node_ops.LayerNorm)):
+            if self.training:
+                assert self.dropout.mask is not None
+            out = node_ops.pre_activation(self.norm, x, training=self.training,
+                                          mask=self.dropout.mask if self.training else None)
+        else:
+            out = self.dropout(F.relu(self.norm(x)))
         if edge_emb is not None:
             return self.gcn(out, edge_index, edge_emb)
         return self.gcn(out, edge_index)

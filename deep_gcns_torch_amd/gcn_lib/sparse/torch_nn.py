@@ -73,20 +73,41 @@ class MLP(nn.Sequential):
         self.m = stages
         super().__init__(*stages)
 
-    def forward(self, x):
-        # same stage order as nn.Sequential; BatchNorm1d / LayerNorm directly followed by ReLU runs with the ReLU fused
+    def forward(self, x, residual=None, want_stats: bool = False):
+        """Same stage order as nn.Sequential.  Fused on device rows: BatchNorm1d / LayerNorm directly followed by ReLU is
+        one kernel; a Linear in front of a training-mode BatchNorm1d hands it the statistics of its own output (no
+        separate statistics pass); ``residual`` (extension) is added in the LAST Linear's epilogue and ``want_stats``
+        (extension) returns ``(y, stats)`` with the last Linear's output statistics for the caller's next BatchNorm1d."""
         mods = list(self._modules.values())
+        last_lin = max((i for i, m in enumerate(mods) if isinstance(m, TallLinear)), default=-1)
+        ext = residual is not None or want_stats
+        if ext and last_lin != len(mods) - 1:
+            raise ValueError("residual / want_stats need the MLP to end with its Linear (last_lin=True)")
+        stats = None
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, (BatchNorm1d, LayerNorm)) and i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                    and isinstance(x, torch.Tensor) and x.dim() == 2):
-                x = m(x, fuse_relu=True)
-                i += 2
+            rows2d = isinstance(x, torch.Tensor) and x.dim() == 2
+            if isinstance(m, TallLinear) and rows2d:
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if i == last_lin and ext:
+                    out = m(x, residual=residual, want_stats=want_stats)
+                    x, stats = out if want_stats else (out, None)
+                elif isinstance(nxt, BatchNorm1d) and nxt.training and x.is_cuda:
+                    x, stats = m(x, want_stats=True)
+                else:
+                    x, stats = m(x), None
+                i += 1
+            elif isinstance(m, (BatchNorm1d, LayerNorm)) and rows2d:
+                relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                x = m(x, fuse_relu=relu, stats=stats)
+                stats = None
+                i += 2 if relu else 1
             else:
                 x = m(x)
+                stats = None
                 i += 1
-        return x
+        return (x, stats) if want_stats else x
 
 
 class _SumOfEmbeddings(nn.Module):

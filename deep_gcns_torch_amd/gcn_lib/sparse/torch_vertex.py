@@ -39,23 +39,32 @@ class GENConv(GenMessagePassing):
         if encode_edge:
             self.edge_encoder = BondEncoder(emb_dim=in_dim) if bond_encoder else TallLinear(edge_feat_dim, in_dim)
 
-    def forward(self, x, edge_index, edge_attr=None):
+    def forward(self, x, edge_index, edge_attr=None, residual=None, want_stats=False):
+        """``residual`` (extension): returns ``conv(x) + residual`` with the add folded into the last Linear's epilogue --
+        the 'res+' skip connection ``h = conv(h2) + h`` (examples/ogb/ogbn_arxiv/model.py:104).  ``want_stats``
+        (extension): returns ``(out, stats)`` where ``stats`` are the partial column sums of ``out`` that the next
+        layer's BatchNorm1d takes (None when the row kernel did not run): its statistics pass disappears."""
         root = self.msg_norm is None and self.fusable_root() and x.dim() == 2      # h = x + m inside the kernel
         enc = None
         if self.encode_edge and edge_attr is not None:
             lin = self.edge_encoder
             if isinstance(lin, nn.Linear) and x.is_cuda and ops.encoder_fusable(x, edge_attr, lin.weight):
-                enc, edge_emb = (lin.weight, lin.bias), edge_attr              # Linear(8 -> C) inside the kernels
+                enc, edge_emb = (lin.weight, lin.bias), edge_attr              # Linear(hidden -> C) inside the kernels
             else:
                 edge_emb = lin(edge_attr)
         else:
             edge_emb = edge_attr
         if root:
-            return self.mlp(self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True, edge_encoder=enc))
-        m = self.propagate(edge_index, x=x, edge_attr=edge_emb, edge_encoder=enc)
-        if self.msg_norm is not None:
-            return self.mlp(self.msg_norm(x, m, add_x=True))        # x + MsgNorm(x, m) in one row kernel
-        return self.mlp(x + m)
+            h = self.propagate(edge_index, x=x, edge_attr=edge_emb, add_root=True, edge_encoder=enc)
+        else:
+            m = self.propagate(edge_index, x=x, edge_attr=edge_emb, edge_encoder=enc)
+            if self.msg_norm is not None:
+                h = self.msg_norm(x, m, add_x=True)                 # x + MsgNorm(x, m) in one row kernel
+            else:
+                h = x + m
+        if residual is None and not want_stats:
+            return self.mlp(h)
+        return self.mlp(h, residual=residual, want_stats=want_stats)
 
     def message(self, x_j, edge_attr=None):
         """Reference semantics of one message (torch_vertex.py:78-85); the fused kernel computes

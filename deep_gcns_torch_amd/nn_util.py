@@ -1,10 +1,14 @@
-"""Node-wise helpers around the hot path (plain library GEMMs, no custom kernels).
+"""Node-wise Linear layers around the hot path.
 
-``TallLinear`` is an ``nn.Linear`` (same parameters, same ``state_dict`` keys, ``isinstance`` still holds)
-whose weight gradient ``g^T x`` -- a GEMM with a 10^5..10^6-long reduction and a 128x128 result when the rows
-are graph nodes or edges -- is computed as a batched split-K product plus a fixed-order sum.  hipBLASLt runs
-the un-split shape on a handful of CUs (measured 412 us for 169,343 x 128 x 128, ~13 TFLOP/s); the split
-form uses the whole chip.  Forward and input gradient are the stock GEMMs.
+``TallLinear`` is an ``nn.Linear`` (same parameters, same ``state_dict`` keys, ``isinstance`` still holds) for inputs
+whose rows are graph nodes or edges (10^4 .. 10^6 of them, 16 .. 256 columns):
+
+* forward and input gradient run on ``node_ops.rows_linear`` (csrc/rows_linear.hip: fp32-faithful on the bf16 matrix
+  pipe, bias / 'res+' residual / the next BatchNorm's statistics / the bias gradient folded into the same sweep) when
+  the shape is one the kernel takes, else on the library GEMM;
+* the weight gradient ``g^T x`` -- a GEMM with a 10^5..10^6-long reduction and a 128x128 result -- is a batched split-K
+  product plus a fixed-order sum.  hipBLASLt runs the un-split shape on a handful of CUs (measured 412 us for
+  169,343 x 128 x 128, ~13 TFLOP/s); the split form uses the whole chip.
 """
 import torch
 from torch import nn
@@ -48,9 +52,22 @@ class _TallLinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+ROWS_KERNEL = True      # False: library GEMMs everywhere (A/B measurements)
+
+
 class TallLinear(nn.Linear):
-    def forward(self, x):
+    def forward(self, x, residual=None, want_stats: bool = False):
+        """``residual`` (extension): added to the result in the GEMM epilogue -- the 'res+' skip connection
+        (examples/ogb/ogbn_arxiv/model.py:104).  ``want_stats`` (extension): also return the (parts, 2, C) partial sums
+        of the result that ``BatchNorm1d(stats=...)`` takes, or None when the row kernel did not run."""
+        from . import node_ops
+        if ROWS_KERNEL and node_ops.rows_linear_supported(x, self.weight):
+            return node_ops.rows_linear(x, self.weight, self.bias, residual, want_stats)
         if x.is_cuda and x.dim() == 2 and x.size(0) >= _MIN_ROWS and torch.is_grad_enabled() \
                 and x.dtype == self.weight.dtype and not torch.is_autocast_enabled():
-            return _TallLinearFn.apply(x, self.weight, self.bias)
-        return super().forward(x)
+            y = _TallLinearFn.apply(x, self.weight, self.bias)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return (y, None) if want_stats else y

@@ -7,19 +7,100 @@ of the ogbn-proteins / ogbg-ppa / RevGCN configurations), same kernels file, opt
 optional fused ReLU, as HIP streaming kernels (csrc/rows_norm.hip).  ``BatchNorm1d`` is the drop-in module that
 ``gcn_lib.sparse.torch_nn.norm_layer('batch', C)`` returns: an ``nn.BatchNorm1d`` subclass (same parameters,
 buffers, ``state_dict`` keys; ``isinstance`` still holds), reference: gcn_lib/sparse/torch_nn.py:23-34.
+
+``pre_activation`` = the ``norm -> ReLU -> dropout`` run in front of every convolution of the 'res+' models
+(examples/ogb/ogbn_arxiv/model.py:90-106) and of the reversible BasicBlock (eff_gcn_modules/rev/rev_layer.py:35-51) as
+ONE apply pass: the dropout mask is a counter hash of (seed, element index) regenerated in the backward (nothing stored)
+or the shared mask tensor of the reversible model; the backward recomputes the ReLU mask from the input.
+
+``rows_linear`` / ``RowsLinear`` = ``nn.Linear`` over node rows on the bf16 matrix pipe (fp32-faithful six-product
+split, csrc/rows_linear.hip) with bias, the 'res+' residual and the NEXT BatchNorm's statistics folded into the same
+sweep (gcn_lib/sparse/torch_nn.py:50-71, gcn_lib/sparse/torch_vertex.py:70-76).
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 from torch import nn
 
 from . import _lib
 
+# ---- dropout inside the row kernels (csrc/rows_norm.hip: drop_rand4) ------------------------------------------------
+DROP_NONE, DROP_HASH, DROP_MASK = 0, 1, 2
+
+
+class DropSpec:
+    """How the fused pre-activation drops: ``mode`` (DROP_*), the shared ``mask`` tensor or the hash ``seed`` words and
+    16-bit threshold (drop probability thr / 65536; kept values are scaled by 65536 / (65536 - thr))."""
+    __slots__ = ("mode", "mask", "s0", "s1", "thr")
+
+    def __init__(self, mode=DROP_NONE, mask=None, s0=0, s1=0, thr=0):
+        self.mode, self.mask, self.s0, self.s1, self.thr = mode, mask, s0, s1, thr
+
+    @staticmethod
+    def none():
+        return DropSpec()
+
+    @staticmethod
+    def hashed(p: float, seed=None):
+        """Bernoulli(1 - p) keep mask from a fresh seed (drawn from torch's CPU generator: reproducible under
+        torch.manual_seed; a step replayed as a HIP graph replays the same mask)."""
+        thr = int(round(float(p) * 65536.0))
+        if thr <= 0:
+            return DropSpec()
+        thr = min(thr, 65535)
+        if seed is None:
+            w = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64)
+            seed = (int(w[0]), int(w[1]))
+        return DropSpec(DROP_HASH, None, int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF, thr)
+
+    @staticmethod
+    def shared(mask: torch.Tensor):
+        return DropSpec(DROP_MASK, mask)
+
+    def args(self):
+        return (self.mode, _lib.ptr(self.mask), self.mask.stride(0) if self.mask is not None else 0, self.s0, self.s1,
+                self.thr)
+
+
+def hash_keep_factors(rows: int, C: int, s0: int, s1: int, thr: int) -> torch.Tensor:
+    """Host replica of the kernels' hash dropout: the (rows, C) factor array (0 or 65536 / (65536 - thr)).  For tests and
+    for callers that need the mask itself; the kernels never materialise it."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def mix(h):
+        h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x85ebca6b)) & M
+        h = h ^ (h >> np.uint64(13)); h = (h * np.uint64(0xc2b2ae35)) & M
+        return h ^ (h >> np.uint64(16))
+
+    n = rows * C
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    lo, hi = q & M, q >> np.uint64(32)
+    h0 = mix(lo ^ np.uint64(s0))
+    h0 = mix((h0 + ((hi * np.uint64(0x9E3779B1)) & M) + np.uint64(s1)) & M)
+    h1 = mix(h0 ^ np.uint64(0x68E31DA4))
+    r = np.stack([h0 & np.uint64(0xffff), h0 >> np.uint64(16), h1 & np.uint64(0xffff), h1 >> np.uint64(16)], 1).reshape(-1)[:n]
+    keep = r >= np.uint64(thr)
+    return torch.from_numpy(np.where(keep, np.float32(65536.0 / (65536 - thr)), np.float32(0.0)).astype(np.float32)).view(rows, C)
+
+
+def _mask_rows(drop: DropSpec, rows: int, C: int, dev):
+    """The shared mask as fp32 (rows, C) rows with unit column stride on ``dev`` (a torch.chunk view of the model-level
+    (N, hidden) mask is used in place: its row stride goes to the kernel)."""
+    if drop.mode != DROP_MASK:
+        return drop
+    m = drop.mask
+    if m.shape != (rows, C) or m.device != dev:
+        raise ValueError(f"dropout mask must be a ({rows}, {C}) tensor on {dev}")
+    if m.dtype != torch.float32 or m.stride(1) != 1 or (rows > 1 and m.stride(0) < C):
+        m = m.float().contiguous()
+    return DropSpec(DROP_MASK, m)
+
 
 class _BatchNormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, use_batch_stats: bool, momentum: float,
-                eps: float, relu: bool, track: bool):
+                eps: float, relu: bool, track: bool, drop: DropSpec = None, stats=None):
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
@@ -27,33 +108,42 @@ class _BatchNormRows(torch.autograd.Function):
             x = x.contiguous()     # the float4 row layout needs 16-byte aligned rows (a sliced view may not be)
         rows, C = x.shape
         ld = x.stride(0) if rows > 1 else C
+        drop = _mask_rows(drop or DropSpec.none(), rows, C, dev)
         y = torch.empty(rows, C, device=dev, dtype=torch.float32)
         bnbuf = torch.empty(4, C, device=dev, dtype=torch.float32)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         with _lib.device_ctx(dev):
-            nparts, stats = 0, None
+            nparts = 0
             if use_batch_stats:
-                nparts = lib.dgcn_rows_num_partials(rows, C)
-                stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
-                _lib.check(lib.dgcn_rows_stats_f32(x.data_ptr(), ld, rows, C, stats.data_ptr(), stream),
-                           "dgcn_rows_stats_f32")
+                if stats is not None:
+                    # per-workgroup sum x | sum x^2 partials that the producing kernel (rows_linear) already wrote
+                    if stats.dim() != 3 or stats.shape[1:] != (2, C) or stats.dtype != torch.float32 or not stats.is_contiguous():
+                        raise ValueError("stats must be contiguous fp32 (parts, 2, C) partial sums")
+                    nparts = stats.size(0)
+                else:
+                    nparts = lib.dgcn_rows_num_partials(rows, C)
+                    stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
+                    _lib.check(lib.dgcn_rows_stats_f32(x.data_ptr(), ld, rows, C, stats.data_ptr(), stream),
+                               "dgcn_rows_stats_f32")
+            else:
+                stats = None
             _lib.check(lib.dgcn_bn_finalize_f32(
                 _lib.ptr(stats), nparts, C, float(rows), _lib.ptr(w), _lib.ptr(b), _lib.ptr(running_mean),
                 _lib.ptr(running_var), _lib.ptr(num_batches), 1 if use_batch_stats else 0, float(momentum),
                 float(eps), bnbuf.data_ptr(), stream), "dgcn_bn_finalize_f32")
-            _lib.check(lib.dgcn_rows_bn_apply_f32(x.data_ptr(), ld, bnbuf.data_ptr(), 1 if relu else 0,
-                                                  y.data_ptr(), rows, C, stream), "dgcn_rows_bn_apply_f32")
+            _lib.check(lib.dgcn_rows_bn_act_apply_f32(x.data_ptr(), ld, bnbuf.data_ptr(), 1 if relu else 0, *drop.args(),
+                                                      y.data_ptr(), rows, C, stream), "dgcn_rows_bn_act_apply_f32")
         if track and any(ctx.needs_input_grad[:3]):
-            ctx.save_for_backward(x, bnbuf, y if relu else None)
-            ctx.cfg = (use_batch_stats, weight is not None, bias is not None, relu)
+            ctx.save_for_backward(x, bnbuf, drop.mask)
+            ctx.cfg = (use_batch_stats, weight is not None, bias is not None, relu, drop)
         return y
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x, bnbuf, y = ctx.saved_tensors
-        use_batch_stats, has_w, has_b, relu = ctx.cfg
+        x, bnbuf, mask = ctx.saved_tensors
+        use_batch_stats, has_w, has_b, relu, drop = ctx.cfg
         dev = x.device
         stream = _lib.current_stream_handle(dev)
         rows, C = x.shape
@@ -64,18 +154,21 @@ class _BatchNormRows(torch.autograd.Function):
         coef = torch.empty(4, C, device=dev, dtype=torch.float32)
         dx = torch.empty(rows, C, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         with _lib.device_ctx(dev):
-            _lib.check(lib.dgcn_rows_bn_bwd_stats_f32(g.data_ptr(), x.data_ptr(), ld, _lib.ptr(y), bnbuf.data_ptr(),
-                                                      partial.data_ptr(), rows, C, stream), "dgcn_rows_bn_bwd_stats_f32")
+            # the ReLU mask is recomputed from x and the saved coefficients, the hash mask from its seed
+            _lib.check(lib.dgcn_rows_bn_act_bwd_stats_f32(g.data_ptr(), x.data_ptr(), ld, bnbuf.data_ptr(),
+                                                          1 if relu else 0, *drop.args(), partial.data_ptr(), rows, C,
+                                                          stream), "dgcn_rows_bn_act_bwd_stats_f32")
             _lib.check(lib.dgcn_rows_bn_bwd_finalize_f32(partial.data_ptr(), nparts, C, float(rows),
                                                          1 if use_batch_stats else 0, coef.data_ptr(), stream),
                        "dgcn_rows_bn_bwd_finalize_f32")
             if dx is not None:
-                _lib.check(lib.dgcn_rows_bn_bwd_apply_f32(g.data_ptr(), x.data_ptr(), ld, _lib.ptr(y), bnbuf.data_ptr(),
-                                                          coef.data_ptr(), dx.data_ptr(), rows, C, stream),
-                           "dgcn_rows_bn_bwd_apply_f32")
+                _lib.check(lib.dgcn_rows_bn_act_bwd_apply_f32(g.data_ptr(), x.data_ptr(), ld, bnbuf.data_ptr(),
+                                                              coef.data_ptr(), 1 if relu else 0, *drop.args(), None,
+                                                              dx.data_ptr(), rows, C, stream),
+                           "dgcn_rows_bn_act_bwd_apply_f32")
         gw = coef[0] if (has_w and ctx.needs_input_grad[1]) else None      # rows of a fresh tensor: no copy needed
         gb = coef[1] if (has_b and ctx.needs_input_grad[2]) else None
-        return dx, gw, gb, None, None, None, None, None, None, None, None
+        return (dx, gw, gb) + (None,) * 10
 
 
 def _supported(x: torch.Tensor) -> bool:
@@ -85,11 +178,13 @@ def _supported(x: torch.Tensor) -> bool:
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, num_batches, training: bool, momentum: float,
-                    eps: float, relu: bool = False) -> torch.Tensor:
-    """BatchNorm1d over the rows of ``x`` (rows, C) [+ ReLU]; ``training`` selects batch statistics (and updates the
-    running buffers in place when given)."""
+                    eps: float, relu: bool = False, drop: DropSpec = None, stats=None) -> torch.Tensor:
+    """BatchNorm1d over the rows of ``x`` (rows, C) [+ ReLU] [+ dropout]; ``training`` selects batch statistics (and
+    updates the running buffers in place when given).  ``stats``: (parts, 2, C) partial sums of x and x^2 that the
+    producer of ``x`` already computed (``rows_linear(..., want_stats=True)``): the statistics pass is skipped."""
     return _BatchNormRows.apply(x, weight, bias, running_mean, running_var, num_batches, bool(training),
-                                float(momentum), float(eps), bool(relu), torch.is_grad_enabled())
+                                float(momentum), float(eps), bool(relu), torch.is_grad_enabled(), drop,
+                                stats if training else None)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -112,18 +207,30 @@ class BatchNorm1d(nn.BatchNorm1d):
         rv = self.running_var if (not self.training or self.track_running_stats) else None
         return use_batch, momentum, nb, rm, rv
 
-    def forward(self, x, fuse_relu: bool = False):
+    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None):
         a = self._hip_args(x)
         if a is None:
-            y = super().forward(x)
-            return torch.relu(y) if fuse_relu else y
+            return _stock_tail(super().forward(x), fuse_relu, drop)
         use_batch, momentum, nb, rm, rv = a
-        return batch_norm_rows(x, self.weight, self.bias, rm, rv, nb, use_batch, momentum, self.eps, relu=fuse_relu)
+        return batch_norm_rows(x, self.weight, self.bias, rm, rv, nb, use_batch, momentum, self.eps, relu=fuse_relu,
+                               drop=drop, stats=stats if use_batch else None)
+
+
+def _stock_tail(y, relu: bool, drop: DropSpec):
+    """ReLU / dropout after a stock norm (inputs the row kernels do not take: CPU tensors, other dtypes, 3-D)."""
+    if relu:
+        y = torch.relu(y)
+    if drop is not None and drop.mode == DROP_MASK:
+        y = y * drop.mask
+    elif drop is not None and drop.mode == DROP_HASH:
+        f = hash_keep_factors(y.numel() // y.size(-1), y.size(-1), drop.s0, drop.s1, drop.thr).to(y.device)
+        y = y * f.view(y.shape).to(y.dtype)
+    return y
 
 
 class _LayerNormRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float, relu: bool, track: bool):
+    def forward(ctx, x, weight, bias, eps: float, relu: bool, track: bool, drop: DropSpec = None):
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
@@ -133,25 +240,29 @@ class _LayerNormRows(torch.autograd.Function):
             x2 = x2.contiguous()
         rows, C = x2.shape
         ld = x2.stride(0) if rows > 1 else C
+        drop = drop or DropSpec.none()
+        if drop.mode == DROP_MASK and drop.mask.dim() != 2:
+            drop = DropSpec.shared(drop.mask.reshape(rows, C))
+        drop = _mask_rows(drop, rows, C, dev)
         y = torch.empty(rows, C, device=dev, dtype=torch.float32)
         mean = torch.empty(rows, device=dev, dtype=torch.float32)
         rstd = torch.empty(rows, device=dev, dtype=torch.float32)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
         with _lib.device_ctx(dev):
-            _lib.check(lib.dgcn_rows_ln_fwd_f32(x2.data_ptr(), ld, _lib.ptr(w), _lib.ptr(b), float(eps), 1 if relu else 0,
-                                                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C, stream),
-                       "dgcn_rows_ln_fwd_f32")
+            _lib.check(lib.dgcn_rows_ln_act_fwd_f32(x2.data_ptr(), ld, _lib.ptr(w), _lib.ptr(b), float(eps),
+                                                    1 if relu else 0, *drop.args(), y.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), rows, C, stream), "dgcn_rows_ln_act_fwd_f32")
         if track and any(ctx.needs_input_grad[:3]):
-            ctx.save_for_backward(x2, w, mean, rstd, y if relu else None)
-            ctx.cfg = (weight is not None, bias is not None, tuple(shape))
+            ctx.save_for_backward(x2, w, b, mean, rstd, drop.mask)
+            ctx.cfg = (weight is not None, bias is not None, tuple(shape), relu, drop)
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        x2, w, mean, rstd, y = ctx.saved_tensors
-        has_w, has_b, shape = ctx.cfg
+        x2, w, b, mean, rstd, mask = ctx.saved_tensors
+        has_w, has_b, shape, relu, drop = ctx.cfg
         dev = x2.device
         stream = _lib.current_stream_handle(dev)
         rows, C = x2.shape
@@ -165,14 +276,15 @@ class _LayerNormRows(torch.autograd.Function):
             if need_p:
                 nparts = lib.dgcn_rows_ln_num_partials(rows, C)
                 partial = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
-            _lib.check(lib.dgcn_rows_ln_bwd_f32(g2.data_ptr(), x2.data_ptr(), ld, _lib.ptr(y), _lib.ptr(w), mean.data_ptr(),
-                                                rstd.data_ptr(), _lib.ptr(dx), _lib.ptr(partial), rows, C, stream),
-                       "dgcn_rows_ln_bwd_f32")
+            _lib.check(lib.dgcn_rows_ln_act_bwd_f32(g2.data_ptr(), x2.data_ptr(), ld, _lib.ptr(w), _lib.ptr(b),
+                                                    mean.data_ptr(), rstd.data_ptr(), 1 if relu else 0, *drop.args(),
+                                                    None, _lib.ptr(dx), _lib.ptr(partial), rows, C, stream),
+                       "dgcn_rows_ln_act_bwd_f32")
             if need_p:
                 psum = partial.sum(0)                 # (2, C): sum g' | sum g' xhat over <= 1024 workgroup partials
         gw = psum[1] if (has_w and ctx.needs_input_grad[1]) else None
         gb = psum[0] if (has_b and ctx.needs_input_grad[2]) else None
-        return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None
+        return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None, None
 
 
 def _ln_supported(x: torch.Tensor, C: int) -> bool:
@@ -180,20 +292,122 @@ def _ln_supported(x: torch.Tensor, C: int) -> bool:
             and x.numel() > 0 and not torch.is_autocast_enabled())
 
 
-def layer_norm_rows(x, weight, bias, eps: float = 1e-5, relu: bool = False) -> torch.Tensor:
-    """LayerNorm over the last dimension of ``x`` (..., C) [+ ReLU]."""
-    return _LayerNormRows.apply(x, weight, bias, float(eps), bool(relu), torch.is_grad_enabled())
+def layer_norm_rows(x, weight, bias, eps: float = 1e-5, relu: bool = False, drop: DropSpec = None) -> torch.Tensor:
+    """LayerNorm over the last dimension of ``x`` (..., C) [+ ReLU] [+ dropout]."""
+    return _LayerNormRows.apply(x, weight, bias, float(eps), bool(relu), torch.is_grad_enabled(), drop)
 
 
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (normalised over the last dimension only) whose fp32 device inputs run on the HIP row kernels; other
     shapes / dtypes take the stock implementation.  Same parameters and ``state_dict`` keys."""
 
-    def forward(self, x, fuse_relu: bool = False):
+    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None):
         if len(self.normalized_shape) == 1 and _ln_supported(x, self.normalized_shape[0]):
-            return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu)
-        y = super().forward(x)
-        return torch.relu(y) if fuse_relu else y
+            return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu, drop=drop)
+        return _stock_tail(super().forward(x), fuse_relu, drop)
+
+
+def pre_activation(norm: nn.Module, x: torch.Tensor, p: float = 0.0, training: bool = True, mask: torch.Tensor = None,
+                   stats=None) -> torch.Tensor:
+    """``dropout(relu(norm(x)))`` -- the run in front of every convolution of the 'res+' models
+    (examples/ogb/ogbn_arxiv/model.py:96-99: ``norm -> F.relu -> F.dropout(p, training)``) and of the reversible
+    BasicBlock (eff_gcn_modules/rev/rev_layer.py:38-46: ``norm -> relu -> x * shared mask``) in ONE row kernel when
+    ``norm`` is this package's BatchNorm1d / LayerNorm; any other module runs the three steps.
+    ``mask``: the shared dropout mask (already scaled) -- used as is, ``p`` is ignored.  ``stats``: see batch_norm_rows."""
+    if mask is not None:
+        drop = DropSpec.shared(mask) if training else None
+    else:
+        drop = DropSpec.hashed(p) if (training and p > 0.0) else None
+    if isinstance(norm, (BatchNorm1d, LayerNorm)):
+        return norm(x, fuse_relu=True, drop=drop, stats=stats)
+    y = torch.relu(norm(x))
+    if mask is not None:
+        return y * mask if training else y
+    return torch.nn.functional.dropout(y, p=p, training=training)
+
+
+# ---- Linear over node rows ------------------------------------------------------------------------------------------
+ROWS_LINEAR_MIN_ROWS = 2048     # below this the library GEMM is as good (launch-bound either way)
+
+
+def rows_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.size(0) >= ROWS_LINEAR_MIN_ROWS and not torch.is_autocast_enabled()):
+        return False
+    C, K = weight.shape
+    return x.size(1) == K and bool(_lib.load().dgcn_rows_linear_supported(K, C))
+
+
+def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum):
+    """y = x @ (w^T | w) + bias + res on the matrix pipe; returns (y, stats or None, xsum partials or None)."""
+    lib = _lib.load()
+    dev = x.device
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    rows, K = x.shape
+    C = w.size(1) if w_trans else w.size(0)
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    if res is not None and (res.stride(1) != 1 or res.dtype != torch.float32):
+        res = res.float().contiguous()
+    y = torch.empty(rows, C, device=dev, dtype=torch.float32)
+    nparts = lib.dgcn_rows_linear_num_partials(rows, K, C)
+    stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32) if want_stats else None
+    xsum = torch.empty(nparts, K, device=dev, dtype=torch.float32) if want_xsum else None
+    with _lib.device_ctx(dev):
+        _lib.check(lib.dgcn_rows_linear_f32(x.data_ptr(), x.stride(0), rows, w.data_ptr(), w.stride(0), 1 if w_trans else 0,
+                                            _lib.ptr(bias), _lib.ptr(res), res.stride(0) if res is not None else 0,
+                                            y.data_ptr(), C, K, C, 1 if relu else 0, _lib.ptr(stats), _lib.ptr(xsum),
+                                            _lib.current_stream_handle(dev)), "dgcn_rows_linear_f32")
+    return y, stats, xsum
+
+
+class _RowsLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, want_stats: bool):
+        w = weight.detach()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y, stats, _ = _rl_launch(x, w, False, b, residual, False, want_stats, False)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        from .nn_util import splitk_xt_g
+        x, weight = ctx.saved_tensors
+        g = g.float()
+        if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
+            g = g.contiguous()
+        C, K = weight.shape
+        gx = gw = gb = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0]:
+            # dX = G W on the same kernel (reduction over C); its sweep over G also yields the bias gradient
+            fuse_b = need_b and C <= 128 and bool(_lib.load().dgcn_rows_linear_supported(C, K))
+            if _lib.load().dgcn_rows_linear_supported(C, K):
+                gx, _, xsum = _rl_launch(g, weight.detach(), True, None, None, False, False, fuse_b)
+                if fuse_b:
+                    gb = xsum.sum(0)
+            else:
+                gx = g @ weight
+        if ctx.needs_input_grad[1]:
+            gw = splitk_xt_g(g.contiguous(), x.contiguous())
+        if need_b and gb is None:
+            gb = g.sum(0)
+        gres = g if ctx.needs_input_grad[3] else None
+        return gx, gw, gb, gres, None
+
+
+def rows_linear(x, weight, bias=None, residual=None, want_stats: bool = False):
+    """``x @ weight.T + bias [+ residual]`` for (rows, K) node features; with ``want_stats`` also the per-workgroup
+    partial sums (parts, 2, C) of the result and its square (hand them to the following BatchNorm1d as ``stats``).
+    Returns ``y`` or ``(y, stats)``."""
+    y, stats = _RowsLinear.apply(x, weight, bias, residual, bool(want_stats))
+    return (y, stats) if want_stats else y
 
 
 class _MsgNormRows(torch.autograd.Function):

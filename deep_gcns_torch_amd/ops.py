@@ -22,7 +22,6 @@ _MODES = {
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
-ENC_FEATURES = 8                   # raw edge features of the fused edge encoder (kEncF in csrc/gen_aggr_common.h)
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
@@ -85,31 +84,30 @@ def _splitk_tn(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
 # ---- in-place accumulation of edge-feature gradients ------------------------------------------------------------------
 # The reference's deep models hand ONE (E, hidden) edge embedding to every layer (ogbn_proteins/model.py:116-127,
 # ogb_eff/ogbn_proteins/model_rev.py:98-107); autograd then materialises an (E, hidden) gradient per layer and adds
-# them up.  A caller that owns a running sum can register it for the duration of a backward step: the fused edge-GEMM
-# backward then ADDS its ``dz @ W`` into the registered buffer (one GEMM with beta = 1) and reports no gradient.
-_EDGE_GRAD_SINKS = {}
-
-
-def _sink_key(t: torch.Tensor):
-    return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
+# them up.  A caller that owns a running sum can attach it to the feature tensor it is about to push through a layer:
+# the fused edge-GEMM backward of that call then ADDS its ``dz @ W`` into the buffer (one GEMM with beta = 1) and reports
+# no gradient.  The buffer travels on the tensor OBJECT and is captured by the autograd context of the call: no
+# module-level state, safe with one host thread per GPU.
+_SINK_ATTR = "_dgcn_grad_sink"
 
 
 class edge_grad_sink:
-    """``with edge_grad_sink(feat, buffer): ...``: while active, gradients of ``feat`` (an (E, F) edge-feature tensor,
-    identified by storage pointer + geometry) produced by the fused edge-GEMM backward are accumulated into ``buffer``
-    (same shape, fp32) instead of being returned to autograd."""
+    """``with edge_grad_sink(feat, buffer): out = layer(..., feat, ...); autograd.grad(out, ...)``: gradients of ``feat``
+    (the very tensor object handed to the layer, an (E, F) edge-feature tensor) produced by the fused edge-GEMM backward
+    are accumulated into ``buffer`` (same shape, fp32) instead of being returned to autograd."""
 
     def __init__(self, feat: torch.Tensor, buffer: torch.Tensor):
         if buffer.shape != feat.shape or buffer.dtype != torch.float32 or not buffer.is_contiguous():
             raise ValueError("edge_grad_sink: buffer must be a contiguous fp32 tensor with the shape of the feature tensor")
-        self._key, self._buf = _sink_key(feat), buffer
+        self._feat, self._buf = feat, buffer
 
     def __enter__(self):
-        _EDGE_GRAD_SINKS[self._key] = self._buf
+        setattr(self._feat, _SINK_ATTR, self._buf)
         return self
 
     def __exit__(self, *exc):
-        _EDGE_GRAD_SINKS.pop(self._key, None)
+        if hasattr(self._feat, _SINK_ATTR):
+            delattr(self._feat, _SINK_ATTR)
         return False
 
 
@@ -150,6 +148,7 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError("edge_attr must be (E, C) matching x's channels")
         enc = enc_feat is not None
         egemm = False
+        grad_sink = getattr(enc_feat, _SINK_ATTR, None) if enc else None     # see edge_grad_sink
         if enc:
             if edge_attr is not None:
                 raise ValueError("pass either edge_attr (E, C) or the raw features + encoder, not both")
@@ -158,9 +157,7 @@ class _GenAggregate(torch.autograd.Function):
             enc_b = None if enc_b is None else enc_b.float().contiguous()
             if enc_feat.dim() != 2 or enc_feat.size(0) != graph.n_edges or enc_w.shape != (C, n_feat):
                 raise ValueError("fused edge encoder: features (E, F), weight (C, F)")
-            if n_feat == ENC_FEATURES:
-                enc_feat = enc_feat.float().contiguous()
-            elif graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
+            if graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
                 egemm = True
                 enc_feat = _feat_rows(enc_feat)
             else:
@@ -199,24 +196,18 @@ class _GenAggregate(torch.autograd.Function):
                     enc_feat.stride(0), enc_w.data_ptr(), _lib.ptr(enc_b), n_feat, C, mode, msg, flags, t_val, p_val,
                     eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2),
                     _lib.ptr(range_flag), _lib.ptr(z_save), ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
-            elif enc:
-                rc = lib.dgcn_gen_aggr_enc_fwd_f32(
-                    graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
-                    ENC_FEATURES, C, mode, msg, flags, t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
-                    out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
-                    _lib.current_stream_handle(dev))
             else:
                 rc = lib.dgcn_gen_aggr_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
                     t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
                     _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
-        _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
-                   ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
+        _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else "dgcn_gen_aggr_fwd_f32")
         if need_grad:
             ctx.range_flag = range_flag
             ctx.enc = (enc_feat, enc_w, enc_b) if enc else None
             ctx.egemm = egemm
+            ctx.grad_sink = grad_sink
             # fused edge GEMM: the backward reads the saved pre-activations z_e instead of x[src] + edge rows
             ctx.save_for_backward(x, z_save if egemm else edge_attr, t_param, p_param, aux1, aux2, out)
             ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
@@ -261,10 +252,8 @@ class _GenAggregate(torch.autograd.Function):
 
         grad_x = grad_ea = grad_w = grad_b = grad_feat = None
         egemm = ctx.egemm
-        enc = None if egemm else ctx.enc
         need_dz = egemm and any(ctx.needs_input_grad[14:17])
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
-                (enc is not None and any(ctx.needs_input_grad[15:17])):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz:
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
             if (edge_attr is not None or egemm) and (ctx.needs_input_grad[1] or need_dz):
@@ -287,17 +276,7 @@ class _GenAggregate(torch.autograd.Function):
                                                        _lib.current_stream_handle(dev))
                 _lib.check(rc, "dgcn_softmax_bwd_prep_f32")
             with _lib.device_ctx(dev):
-                if enc is not None:
-                    feat, w_enc, b_enc = enc
-                    nparts = lib.dgcn_gen_aggr_enc_bwd_num_partials(graph.c_struct, C)
-                    gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
-                    rc = lib.dgcn_gen_aggr_enc_bwd_f32(
-                        graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
-                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
-                        _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
-                        _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
-                        grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
-                elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
+                if mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
                         graph.n_dst * C * 4 >= MAX_MASK_MIN_TABLE_BYTES and graph.n_edges > 0:
                     # arg-max bit masks per edge instead of gathered arg-max rows (big graphs: the table misses the caches)
                     mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
@@ -314,20 +293,14 @@ class _GenAggregate(torch.autograd.Function):
                         gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
                         _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
                         _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
-            _lib.check(rc, "dgcn_gen_aggr_enc_bwd_f32" if enc is not None else "dgcn_gen_aggr_bwd_f32")
-            if enc is not None:
-                gsum = gpart.sum(0)                      # fixed-order partials -> (C, 9) = dW | db
-                if ctx.needs_input_grad[15]:
-                    grad_w = gsum[:, :ENC_FEATURES].contiguous()
-                if b_enc is not None and ctx.needs_input_grad[16]:
-                    grad_b = gsum[:, ENC_FEATURES].contiguous()
+            _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
             if egemm:
                 # dz = dL/dz_e (E, C), original edge order = the gradient of the never-materialised edge embedding
                 feat, w_enc, b_enc = ctx.enc
                 dz, grad_ea = grad_ea, None
                 if dz is not None:
                     if ctx.needs_input_grad[14]:
-                        sink = _EDGE_GRAD_SINKS.get(_sink_key(feat)) if _EDGE_GRAD_SINKS else None
+                        sink = ctx.grad_sink
                         if sink is not None:
                             torch.addmm(sink, dz, w_enc, out=sink)       # running sum owned by the caller
                         else:
@@ -357,8 +330,9 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
     read on the device, no host synchronisation).  ``relu_eps=False`` aggregates raw rows.
     ``add_root`` returns ``x + out`` (the ``h = x + m`` of GENConv.forward) from the same kernel: the root row is
     added in the epilogue and the upstream gradient in the backward's, saving two elementwise passes per layer.
-    ``edge_encoder=(weight, bias)`` with ``edge_attr`` = the RAW (E, 8) edge features fuses GENConv's
-    ``Linear(edge_feat_dim -> C)`` edge encoder into the kernels (``encoder_fusable``): no (E, C) tensor at all.
+    ``edge_encoder=(weight, bias)`` with ``edge_attr`` = the (E, hidden) features the layer's ``edge_encoder`` would be
+    applied to fuses GENConv's ``Linear(edge_feat_dim -> C)`` into the aggregation (``encoder_fusable``): no (E, C)
+    tensor at all.
     """
     if aggr not in _MODES:
         raise NotImplementedError("To be implemented")  # torch_message.py:85
@@ -382,17 +356,16 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
 
 
 def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels:
-    * 8 raw features per edge (C % 4 == 0, C <= 256): every edge recomputes its row in registers;
-    * wide features, F % 16 == 0, F <= 256, C % 4 == 0, C <= 128 (``Linear(hidden -> C)`` of the reference's
-      ogbn-proteins / ogbg-ppa / RevGCN models): E x F x C GEMM on the fp32 matrix cores inside the aggregation."""
+    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernel: F % 16 == 0, F <= 256, C % 4 == 0,
+    C <= 128 -- the ``Linear(hidden -> C)`` every reference model with edge features puts in its GENConv layers
+    (ogbn-proteins / ogbg-ppa / RevGCN: ``edge_feat_dim = hidden_channels``): an E x F x C GEMM on the matrix cores
+    inside the aggregation.  (A narrower encoder -- no reference call site has one -- takes the stock Linear + (E, C)
+    path.)"""
     if edge_feat is None or edge_feat.dim() != 2 or x.dim() != 2 or not edge_feat.is_floating_point():
         return False
     C, F = x.size(-1), edge_feat.size(1)
     if tuple(weight.shape) != (C, F) or torch.is_autocast_enabled():
         return False
-    if F == ENC_FEATURES:
-        return C % 4 == 0 and C <= 256 and edge_feat.dtype == torch.float32
     if not FUSED_EDGE_GEMM or edge_feat.size(0) == 0:
         return False
     return bool(_lib.load().dgcn_gen_aggr_egemm_supported(F, C))

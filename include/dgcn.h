@@ -184,35 +184,6 @@ int dgcn_gen_aggr_max_bwd_f32(const dgcn_graph* g, const int32_t* t_cpos, const 
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * The same aggregation with the edge encoder of GENConv(encode_edge=True) fused in
- * (gcn_lib/sparse/torch_vertex.py:56-66: edge_emb = Linear(edge_feat_dim -> C)(edge_attr), then
- * message = relu(x_j + edge_emb) + eps): the (E, C) edge embedding is never built; every edge recomputes its row
- * e_e = enc_weight f_e + enc_bias from n_feat raw features.
- *   enc_feat    [E, n_feat] fp32 contiguous, ORIGINAL edge order; n_feat must be 8 (ogbn-proteins)
- *   enc_weight  [channels, n_feat] (nn.Linear.weight), enc_bias [channels] or NULL
- *   channels % 4 == 0, channels <= 256, 16-byte aligned pointers; anything else returns DGCN_E_SHAPE / _ALIGN and the
- *   caller materialises the embedding and uses dgcn_gen_aggr_{fwd,bwd}_f32.
- * Backward: grad_x as above; the encoder gradients come out as per-workgroup partials
- *   enc_grad_partials [dgcn_gen_aggr_enc_bwd_num_partials(g, channels)][channels][n_feat + 1]
- * whose sum over the first axis is (d enc_weight | d enc_bias); every block is fully written.
- */
-int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
-                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
-                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
-                              const float* t_dev, const float* p_dev, float* out, void* aux1, float* aux2,
-                              int32_t* range_flag, void* workspace, size_t workspace_bytes, void* stream);
-
-int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels);
-
-int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
-                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
-                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
-                              const float* t_dev, const float* p_dev, const float* gcoef, const void* aux1,
-                              const float* out, const float* gshift, const float* kshift,
-                              const int32_t* shift_ok, const float* groot, float* grad_x,
-                              float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
-
-/*
  * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE
  * (E, hidden) edge embedding and every GENConv owns edge_encoder = Linear(edge_feat_dim = hidden -> C)
  * (gcn_lib/sparse/torch_vertex.py:56-66; examples/ogb_eff/ogbn_proteins/model_rev.py:45-55,98-107;
@@ -442,6 +413,28 @@ int dgcn_rows_bn_bwd_finalize_f32(const float* partial, int32_t nparts, int32_t 
 int dgcn_rows_bn_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* y, const float* bnbuf,
                                const float* coef, float* dx, int64_t rows, int32_t C, void* stream);
 
+/* The pre-activation run  norm -> ReLU -> dropout  of the 'res+' blocks (examples/ogb/ogbn_arxiv/model.py:90-106) and of
+ * the reversible BasicBlock (eff_gcn_modules/rev/rev_layer.py:35-51) as ONE apply pass, and its backward.
+ *   drop_mode 0: no dropout.
+ *   drop_mode 1: element i of the flattened (rows, C) array is kept iff u16(i) >= drop_thr, where u16 are 16 bits of a
+ *                murmur-style hash of (seed0, seed1, i >> 2) (csrc/rows_norm.hip: drop_rand4); drop probability
+ *                drop_thr / 65536, kept values are scaled by 65536 / (65536 - drop_thr).  The mask is regenerated from
+ *                the seed in the backward: nothing is stored.
+ *   drop_mode 2: multiply by drop_mask (rows, C), row stride drop_mask_ld floats -- SharedDropout's mask tensor
+ *                (rev_layer.py:12-24); a per-group chunk view of the model-level (N, hidden) mask is used in place.
+ * The backward recomputes the ReLU mask [scale*x + shift > 0] from x and bnbuf (the forward output is not read);
+ * gadd (rows, C) or NULL is added to dx (gradient of a skip connection around the block). */
+int dgcn_rows_bn_act_apply_f32(const float* x, int64_t ld, const float* bnbuf, int32_t relu, int32_t drop_mode,
+                               const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1, uint32_t drop_thr, float* y,
+                               int64_t rows, int32_t C, void* stream);
+int dgcn_rows_bn_act_bwd_stats_f32(const float* g, const float* x, int64_t ld, const float* bnbuf, int32_t relu,
+                                   int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1,
+                                   uint32_t drop_thr, float* partial, int64_t rows, int32_t C, void* stream);
+int dgcn_rows_bn_act_bwd_apply_f32(const float* g, const float* x, int64_t ld, const float* bnbuf, const float* coef,
+                                   int32_t relu, int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0,
+                                   uint32_t seed1, uint32_t drop_thr, const float* gadd, float* dx, int64_t rows,
+                                   int32_t C, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channels of row-major (rows, C) features, optional fused ReLU  (SURVEY.md §8 f1).
  * Replaces nn.LayerNorm from norm_layer('layer', C) (gcn_lib/sparse/torch_nn.py:23-34: the default norm of the
@@ -462,6 +455,17 @@ int dgcn_rows_ln_bwd_f32(const float* g, const float* x, int64_t ld, const float
                          const float* mean, const float* rstd, float* dx, float* partial, int64_t rows, int32_t C,
                          void* stream);
 
+/* LayerNorm -> [ReLU] -> [dropout] in one pass (drop_mode as above); the backward recomputes the ReLU mask
+ * [xhat*gamma + beta > 0] from x, adds gadd (or NULL) to dx. */
+int dgcn_rows_ln_act_fwd_f32(const float* x, int64_t ld, const float* gamma, const float* beta, float eps, int32_t relu,
+                             int32_t drop_mode, const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1,
+                             uint32_t drop_thr, float* y, float* mean, float* rstd, int64_t rows, int32_t C,
+                             void* stream);
+int dgcn_rows_ln_act_bwd_f32(const float* g, const float* x, int64_t ld, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, int32_t relu, int32_t drop_mode,
+                             const float* drop_mask, int64_t drop_mask_ld, uint32_t seed0, uint32_t seed1, uint32_t drop_thr,
+                             const float* gadd, float* dx, float* partial, int64_t rows, int32_t C, void* stream);
+
 /* MsgNorm (gcn_lib/sparse/torch_message.py:88-99) fused with GENConv's residual (torch_vertex.py:70-74):
  *   y_r = [x_r +] m_r / max(||m_r||_2, 1e-12) * ||x_r||_2 * (*scale)      rows independent, C % 4 == 0, C <= 1024
  * backward: dx, dm (either may be NULL) and ds_partial [dgcn_rows_ln_num_partials(rows, C)] whose sum is d scale. */
@@ -471,6 +475,28 @@ int dgcn_rows_msgnorm_fwd_f32(const float* x, int64_t ldx, const float* m, const
 int dgcn_rows_msgnorm_bwd_f32(const float* g, const float* x, int64_t ldx, const float* m, const float* scale,
                               int32_t add_x, float* dx, float* dm, float* ds_partial, int64_t rows, int32_t C,
                               void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Node-wise Linear with the neighbouring row passes folded in  (csrc/rows_linear.hip).
+ * Replaces the Linear stages of MLP (gcn_lib/sparse/torch_nn.py:50-71), mlp(x + m) with the 'res+' residual
+ * h = conv(h2) + h (gcn_lib/sparse/torch_vertex.py:70-76, examples/ogb/ogbn_arxiv/model.py:90-106), the statistics pass
+ * of the following BatchNorm and, in the backward launch, the bias gradient:
+ *     y[r, c] = [relu]( sum_k x[r, k] * W[c, k] + bias[c] + res[r, c] )        rows >> K, C
+ * fp32-faithful on the bf16 matrix pipe (six-product split, csrc/bf16x6.h: max error / sum|x||w| = 1.7e-7).
+ *   x (rows, K) row stride ldx (16-byte aligned rows); K % 4 == 0, 16 <= K <= 256; 1 <= C <= 2048
+ *   w_trans 0: w is the nn.Linear weight (C, K), row stride ldw;  1: w is (K, C), row stride ldw -- the input
+ *              gradient dX = G W of a Linear(C_in = C here ... ) is this call with x = G and w = its weight
+ *   bias (C) or NULL; res (rows, C) row stride ldr or NULL; y (rows, C) row stride ldy
+ *   col_stats NULL or [dgcn_rows_linear_num_partials][2][C]: per-workgroup sum y | sum y^2 (what dgcn_bn_finalize_f32
+ *              takes as `partial`, count = rows)
+ *   xcol_sum  NULL or [dgcn_rows_linear_num_partials][K]: per-workgroup column sums of x (K <= 128, no res / col_stats):
+ *              the bias gradient when x is the upstream gradient
+ * ------------------------------------------------------------------------------------ */
+int32_t dgcn_rows_linear_supported(int32_t K, int32_t C);
+int32_t dgcn_rows_linear_num_partials(int64_t rows, int32_t K, int32_t C);
+int dgcn_rows_linear_f32(const float* x, int64_t ldx, int64_t rows, const float* w, int64_t ldw, int32_t w_trans,
+                         const float* bias, const float* res, int64_t ldr, float* y, int64_t ldy, int32_t K, int32_t C,
+                         int32_t relu, float* col_stats, float* xcol_sum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,12 +38,19 @@ class DenseDeepGCN(torch.nn.Module):
 
 
 class DeeperGCN(torch.nn.Module):
+    """'res+' DeeperGCN (ogbn_arxiv/model.py:10-140).  ``dropout``: the reference's ``F.dropout`` after every norm + ReLU
+    (args default 0.5; 0.0 here keeps the parity tests deterministic).  ``fused_layers``: the layer loop through
+    ``deep_gcns_torch_amd.blocks.res_plus_layer`` (same arithmetic, same parameters and state_dict) -- what the example's
+    model.py looks like after the change INTEGRATION.md shows."""
+
     def __init__(self, num_layers=8, in_channels=32, hidden=64, num_tasks=10, aggr="softmax_sg", t=0.1,
-                 norm="batch", mlp_layers=1, **gen_kw):
+                 norm="batch", mlp_layers=1, dropout=0.0, fused_layers=False, **gen_kw):
         super().__init__()
         from gcn_lib.sparse.torch_nn import norm_layer
         from gcn_lib.sparse.torch_vertex import GENConv
         self.num_layers = num_layers
+        self.dropout = dropout
+        self.fused_layers = fused_layers
         self.checkpoint_grad = aggr in ("softmax_sg", "softmax", "power") and num_layers > 7
         self.ckp_k = num_layers // 2
         self.gcns = torch.nn.ModuleList()
@@ -56,14 +63,24 @@ class DeeperGCN(torch.nn.Module):
 
     def forward(self, x, edge_index):
         h = self.node_features_encoder(x)
+        if self.fused_layers:
+            from deep_gcns_torch_amd import blocks, node_ops
+            h, stats = self.gcns[0](h, edge_index, want_stats=True)
+            for layer in range(1, self.num_layers):
+                h, stats = blocks.res_plus_layer(self.norms[layer - 1], self.gcns[layer], h, edge_index, p=self.dropout,
+                                                 training=self.training, stats=stats,
+                                                 use_checkpoint=self.checkpoint_grad and layer % self.ckp_k != 0)
+            h = node_ops.pre_activation(self.norms[self.num_layers - 1], h, p=self.dropout, training=self.training,
+                                        stats=stats)
+            return torch.log_softmax(self.node_pred_linear(h), dim=-1)
         h = self.gcns[0](h, edge_index)
         for layer in range(1, self.num_layers):
-            h2 = F.relu(self.norms[layer - 1](h))
+            h2 = F.dropout(F.relu(self.norms[layer - 1](h)), p=self.dropout, training=self.training)
             if self.checkpoint_grad and layer % self.ckp_k != 0:
                 h = checkpoint(self.gcns[layer], h2, edge_index, use_reentrant=True) + h
             else:
                 h = self.gcns[layer](h2, edge_index) + h
-        h = F.relu(self.norms[self.num_layers - 1](h))
+        h = F.dropout(F.relu(self.norms[self.num_layers - 1](h)), p=self.dropout, training=self.training)
         return torch.log_softmax(self.node_pred_linear(h), dim=-1)
 
 

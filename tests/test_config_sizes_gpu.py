@@ -184,21 +184,92 @@ def test_resgcn28_full_depth_forward():
         assert bool((torch.sort(ei[0].cpu(), dim=2).values.diff(dim=2) != 0).all())     # no neighbour emitted twice
 
 
+def test_resgcn_three_blocks_b8_forward_backward():
+    """A 3-block slice of sem_seg_dense ResGCN (head with d = 1 + two ResDynBlock2d with d = 1, 2; fusion + prediction head) at the FULL config-2 batch B = 8 x N = 4096, k = 16, training mode: logits, the
+    input gradient and every parameter gradient against oracle/dense_ref.py on the same graphs (the oracle's graphs are
+    replayed on the GPU so that fp32 near-ties in the kNN cannot make the two stacks diverge; the kNN itself is checked
+    by test_resgcn28_full_depth_forward and tests/test_modules_gpu.py)."""
+    _install()
+    from gcn_lib.dense import torch_edge, torch_vertex
+    from oracle import dense_ref
+    dev = _dev()
+    B, N = 8, 4096
+    g = torch.Generator().manual_seed(8)
+    inputs = torch.cat([torch.rand(B, 3, N, 1, generator=g), torch.rand(B, 6, N, 1, generator=g)], dim=1)
+    target = torch.randint(0, 13, (B, N), generator=g)
+    torch.manual_seed(8)
+    mc = arch_restated.DenseDeepGCN(n_blocks=3, channels=64, k=16)
+    sd = {kk: v.clone() for kk, v in mc.state_dict().items()}
+    md = arch_restated.DenseDeepGCN(n_blocks=3, channels=64, k=16)
+    md.load_state_dict(sd)
+    md.to(dev).train()
+
+    graphs = []
+    saved_knn = torch_edge.DenseDilatedKnnGraph.forward
+    saved_edge = torch_vertex.EdgeConv2d.forward
+
+    def knn_oracle(self, x):
+        with torch.no_grad():
+            ei = dense_ref.dilate(dense_ref.dense_knn_matrix(x, self.k * self.dilation), self.dilation).contiguous()
+        graphs.append(ei)
+        return ei
+
+    torch_edge.DenseDilatedKnnGraph.forward = knn_oracle
+    torch_vertex.EdgeConv2d.forward = lambda self, x, edge_index: dense_ref.edgeconv2d(x, edge_index, self.nn)
+    try:
+        mc.train()
+        xin_c = inputs.clone().requires_grad_(True)
+        ref = mc(xin_c)
+        torch.nn.functional.cross_entropy(ref, target).backward()
+    finally:
+        torch_edge.DenseDilatedKnnGraph.forward = saved_knn
+        torch_vertex.EdgeConv2d.forward = saved_edge
+    assert len(graphs) == 3
+
+    feed = iter(graphs)
+    torch_edge.DenseDilatedKnnGraph.forward = lambda self, x: next(feed).to(x.device)
+    try:
+        xin_d = inputs.to(dev).requires_grad_(True)
+        out = md(xin_d)
+        torch.nn.functional.cross_entropy(out, target.to(dev)).backward()
+    finally:
+        torch_edge.DenseDilatedKnnGraph.forward = saved_knn
+    assert _rel_l2(out.detach().cpu(), ref.detach()) < 1e-4
+    _close_but(xin_d.grad, xin_c.grad, 1e-3, 1e-4, "grad_input", max_bad=1e-3, l2=1e-3)
+    gp_ref = dict(mc.named_parameters())
+    for name, p in md.named_parameters():
+        r = gp_ref[name].grad
+        err = _rel_l2(p.grad.cpu(), r)
+        assert err < 2e-3, f"{name}: gradient relative L2 error {err:.3e}"
+    for (kk, a), (_, r) in zip(md.state_dict().items(), mc.state_dict().items()):
+        if "running" in kk:
+            _close(a.float(), r.float(), 1e-4, 1e-5, kk)
+
+
 def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False, edge_encoder=None):
     from oracle import sparse_ref
     m = sparse_ref.gen_propagate(x, edge_index, edge_attr, aggr=self.aggr, t=getattr(self, "t", 1.0))
     return x + m if add_root else m
 
 
-def test_deepergcn28_full_depth_forward():
+@pytest.mark.parametrize("size", ["quarter_powerlaw", "full_arxiv"])
+def test_deepergcn28_full_depth_forward(size):
     """ogbn-arxiv DeeperGCN-28 (examples/ogb/ogbn_arxiv/model.py 'res+', README: 28 layers, 128 channels, softmax_sg
-    t=0.1, BatchNorm, mlp_layers=1) on a quarter-scale arxiv-shaped power-law graph (N=42,336, ~620 k edges)."""
+    t=0.1, BatchNorm, mlp_layers=1): a quarter-scale arxiv-shaped power-law graph (N=42,336, ~620 k edges) and the FULL
+    BASELINE config-3 size (N=169,343, E=2,484,941, the bench's graph), forward parity of the whole stack against the
+    oracle's aggregation on this box's host cores."""
     _install()
     from deep_gcns_torch_amd import synth
     from gcn_lib.sparse import torch_message
     dev = _dev()
-    n = 42336
-    ei = synth.powerlaw_graph(n, 289_000, seed=3)                   # symmetrised + self loops: E = 620,336
+    if size == "full_arxiv":
+        sh = synth.SHAPES["arxiv"]
+        n = sh["n"]
+        ei = synth.undirected_random_graph(n, sh["n_undirected"], sh["seed"])
+        assert ei.size(1) == 2_484_941
+    else:
+        n = 42336
+        ei = synth.powerlaw_graph(n, 289_000, seed=3)               # symmetrised + self loops: E = 620,336
     g = torch.Generator().manual_seed(33)
     x = torch.randn(n, 128, generator=g)
     torch.manual_seed(33)
@@ -223,3 +294,13 @@ def test_deepergcn28_full_depth_forward():
     err = _rel_l2(out, ref)
     assert err < 1e-4, f"DeeperGCN-28 log-probabilities, relative L2 error {err:.3e}"
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-3)
+    if size == "quarter_powerlaw":
+        # the same stack with the layer loop through blocks.res_plus_layer (fused pre-activation, residual in the GEMM
+        # epilogue, statistics handed from GEMM to BatchNorm) against the same oracle result
+        mf = arch_restated.DeeperGCN(fused_layers=True, **kw)
+        mf.load_state_dict(sd)
+        mf.to(dev).train()
+        with torch.no_grad():
+            outf = mf(x.to(dev), ei.to(dev)).cpu()
+        assert _rel_l2(outf, ref) < 1e-4
+        torch.testing.assert_close(outf, ref, rtol=1e-3, atol=1e-3)

@@ -173,3 +173,54 @@ def test_channels_at_the_relu_floor(aggr, kw):
     (csrc/gen_aggr_egemm.hip eg_finalize) -- so this is the case that would break if that marking were wrong."""
     out = _run_case(synth.tricky_graph(), 257, 112, 224, aggr, dict(kw), seed=4, dead_channels=20)
     assert out.shape == (257, 112)
+
+
+@pytest.mark.parametrize("aggr,kw", [("max", {}), ("power", dict(p=1.0, learn_p=True)), ("softmax", dict(t=1.0))],
+                         ids=["max", "power-p1-learn_p", "softmax"])
+def test_config5_layer_at_the_cluster_shape_against_the_oracle(aggr, kw):
+    """One GENConv aggregation of BASELINE config 5 at its real size -- ogbn-proteins cluster N = 13,253, E = 791,225
+    (power-law), hidden 224 / group 2: K = 224 features read as the strided per-group view of the (E, 448) model-level
+    embedding, C = 112 channels -- against oracle/sparse_ref.py on this box's host cores (the reference's
+    edge_encoder -> message -> aggregate chain, gcn_lib/sparse/torch_vertex.py:56-68): output and the gradients of
+    x, the edge features, the encoder weight and bias (and p)."""
+    s = synth.SHAPES["proteins_cluster"]
+    ei = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"])
+    assert ei.size(1) == 791225 and s["n"] == 13253
+    _run_case(ei, s["n"], 112, 224, aggr, dict(kw), seed=5, strided=True)
+
+
+def test_non_finite_and_tiny_operands_contract():
+    """The six-product bf16 split (csrc/bf16x6.h) on special values.  Contract:
+    * finite operands of any magnitude, down to 1e-30-scale features and weights, give the fp32 result (the bf16 matrix
+      pipe keeps denormal fragments: nothing is flushed);
+    * non-finite features or weights are OUTSIDE the contract.  What happens is defined and tested here so that nobody
+      has to guess: inf - top16(inf) = NaN in the split, so the pre-activation z of an affected edge is NaN in every
+      channel, relu (v_max_f32, IEEE maxNum) turns it into 0 and the edge contributes m = eps -- where the reference's
+      fp32 GEMM gives z = +-inf, i.e. m = inf or eps per channel.  Edges that do not touch the value are unaffected."""
+    from deep_gcns_torch_amd import ops
+    dev = _dev()
+    ei = synth.tricky_graph(n=64, e=700, hub_deg=300, seed=7)
+    n, C, K, E = 64, 32, 64, ei.size(1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, C, generator=g)
+    feat = torch.randn(E, K, generator=g)
+    W = torch.randn(C, K, generator=g) / 8
+    b = torch.randn(C, generator=g)
+    # tiny: scale features by 1e-30 and one weight row by 1e-8 -> z = x + (tiny) exactly as in fp32
+    feat_t = feat * 1e-30
+    W_t = W.clone()
+    W_t[3] *= 1e-8
+    ref = _ref(x, ei, feat_t, W_t, b, n, "add", {})
+    out = ops.gen_aggregate(x.to(dev), ei.to(dev), feat_t.to(dev), aggr="add", edge_encoder=(W_t.to(dev), b.to(dev)), dim_size=n)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # non-finite: one edge's feature row carries +inf -> that edge's message is eps in every channel
+    bad_edge = 10
+    feat_i = feat.clone()
+    feat_i[bad_edge, 5] = float("inf")
+    out = ops.gen_aggregate(x.to(dev), ei.to(dev), feat_i.to(dev), aggr="add", edge_encoder=(W.to(dev), b.to(dev)), dim_size=n).cpu()
+    keep = torch.ones(E, dtype=torch.bool)
+    keep[bad_edge] = False
+    expect = _ref(x, ei[:, keep], feat[keep], W, b, n, "add", {})
+    expect[int(ei[1, bad_edge])] += 1e-7
+    torch.testing.assert_close(out, expect, rtol=1e-4, atol=1e-5)
+    assert not torch.isfinite(_ref(x, ei, feat_i, W, b, n, "add", {})).all()      # the reference: inf in that row

@@ -1,0 +1,265 @@
+"""GPU: the fused node-wise layer pieces of SURVEY.md 8 f1 against float64 torch on the CPU.
+
+  rows_linear            csrc/rows_linear.hip   Linear over node rows on the bf16 matrix pipe (fp32-faithful six-product
+                                                split) with bias, residual, next-BatchNorm statistics, bias gradient
+                                                  gcn_lib/sparse/torch_nn.py:50-71, torch_vertex.py:70-76
+  pre_activation         csrc/rows_norm.hip     norm -> ReLU -> dropout in one apply pass (hash mask regenerated in the
+                                                backward, or the reversible model's shared mask), ReLU mask recomputed
+                                                  examples/ogb/ogbn_arxiv/model.py:96-99, eff_gcn_modules/rev/rev_layer.py:38-46
+  res_plus_layer         blocks.py              h + conv(dropout(relu(norm(h)))) with the statistics handed from GEMM to norm
+                                                  examples/ogb/ogbn_arxiv/model.py:90-106
+Tolerances: fp32 results against fp64 references, 2e-5 relative to the natural scale of the terms (written at each check).
+"""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,K,C", [(5000, 128, 128), (3001, 112, 224), (4100, 224, 112), (2500, 64, 64),
+                                      (2049, 100, 128), (3000, 256, 128), (3000, 128, 256), (2304, 16, 40),
+                                      (169343, 128, 128)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_rows_linear_forward_backward(rows, K, C, with_res):
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + 7 * K + 13 * C)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(C, K, generator=g) / K ** 0.5
+    b = torch.randn(C, generator=g)
+    res = torch.randn(rows, C, generator=g) if with_res else None
+    probe = torch.randn(rows, C, generator=g)
+    assert node_ops.rows_linear_supported(x.to(dev), w.to(dev))
+
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    yr = xr @ wr.t() + br + (rr if with_res else 0.0)
+    (yr * probe.double()).sum().backward()
+
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    rd = res.to(dev).requires_grad_(True) if with_res else None
+    y, stats = node_ops.rows_linear(xd, wd, bd, rd, want_stats=True)
+    (y * probe.to(dev)).sum().backward()
+
+    # |error| <= ~2e-7 * sum_k |x||w| per element (six-product split) + fp32 accumulation: compare on that scale
+    nat = float((x.double().abs() @ w.double().abs().t()).max())
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-5, atol=2e-6 * nat)
+    natg = float((probe.double().abs() @ w.double().abs()).max())
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=2e-6 * natg)
+    torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=2e-5, atol=1e-5 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=2e-5, atol=1e-5 * float(br.grad.abs().max()))
+    if with_res:
+        torch.testing.assert_close(rd.grad.cpu().double(), rr.grad, rtol=0, atol=0)
+    # statistics partials: sum y | sum y^2 over all workgroups
+    tot = stats.double().sum(0).cpu()
+    torch.testing.assert_close(tot[0], yr.detach().sum(0), rtol=1e-5, atol=1e-5 * nat * rows ** 0.5)
+    torch.testing.assert_close(tot[1], (yr.detach() ** 2).sum(0), rtol=2e-5, atol=1e-6 * nat * nat * rows)
+
+
+def test_rows_linear_strided_input_and_no_bias():
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(4000, 256, generator=g).to(dev)
+    x = big[:, 128:]                                       # row stride 256, 16-byte aligned rows
+    w = (torch.randn(96, 128, generator=g) / 11.0).to(dev)
+    y = node_ops.rows_linear(x, w)
+    ref = x.double().cpu() @ w.double().cpu().t()
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_rows_linear_special_values():
+    """Contract of the six-product split (csrc/bf16x6.h): finite inputs of any magnitude behave like fp32 (tiny values
+    included -- the bf16 pipe keeps denormals); a non-finite input makes its whole output ROW non-finite (inf - inf in
+    the split is NaN where a plain GEMM would give +-inf)."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2048, 64, generator=g)
+    x[5] *= 1e-30
+    x[6] *= 1e30
+    w = torch.randn(64, 64, generator=g)
+    y = node_ops.rows_linear(x.to(dev), w.to(dev)).cpu().double()
+    ref = x.double() @ w.double().t()
+    nat = x.double().abs() @ w.double().abs().t()
+    assert torch.all((y - ref).abs() <= 1e-5 * nat + 1e-37)
+    x[7, 3] = float("inf")
+    y = node_ops.rows_linear(x.to(dev), w.to(dev)).cpu()
+    assert not torch.isfinite(y[7]).any() and torch.isfinite(y[8]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _load(ours, ref):
+    ours.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+
+
+@pytest.mark.parametrize("kind", ["batch", "layer"])
+@pytest.mark.parametrize("rows,C", [(3000, 128), (1025, 112), (777, 64), (513, 50)])
+@pytest.mark.parametrize("drop", ["none", "hash", "mask", "mask_strided"])
+def test_pre_activation_matches_reference_composition(kind, rows, C, drop):
+    """norm -> relu -> dropout fused vs the three stock modules in float64 (the mask comes from the host replica of
+    the kernels' hash, or is the shared tensor)."""
+    from deep_gcns_torch_amd import node_ops
+    if kind == "layer" and C % 4:
+        pytest.skip("LayerNorm rows kernel: C % 4 == 0")
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 1.3 + 0.2
+    probe = torch.randn(rows, C, generator=g)
+    ref = (nn.BatchNorm1d(C) if kind == "batch" else nn.LayerNorm(C)).double().train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, generator=g).double())
+        ref.bias.copy_(torch.randn(C, generator=g).double() * 0.3)
+    ours = (node_ops.BatchNorm1d(C) if kind == "batch" else node_ops.LayerNorm(C))
+    _load(ours, ref)
+    ours = ours.to(dev).train()
+
+    spec, factors = None, torch.ones(rows, C)
+    if drop == "hash":
+        spec = node_ops.DropSpec.hashed(0.3, seed=(12345, 678))
+        factors = node_ops.hash_keep_factors(rows, C, spec.s0, spec.s1, spec.thr)
+        assert abs(float((factors == 0).float().mean()) - 0.3) < 0.02          # the hash is a fair coin
+        assert float(factors.max()) == pytest.approx(65536.0 / (65536 - spec.thr))
+    elif drop in ("mask", "mask_strided"):
+        factors = torch.zeros(rows, C).bernoulli_(0.8, generator=g) / 0.8
+        if drop == "mask_strided":
+            wide = torch.zeros(rows, 2 * C)
+            wide[:, C:] = factors
+            spec = node_ops.DropSpec.shared(wide.to(dev)[:, C:])               # a chunk view, row stride 2C
+        else:
+            spec = node_ops.DropSpec.shared(factors.to(dev))
+
+    xr = x.double().requires_grad_(True)
+    yr = torch.relu(ref(xr)) * factors.double()
+    (yr * probe.double()).sum().backward()
+
+    xd = x.to(dev).requires_grad_(True)
+    y = ours(xd, fuse_relu=True, drop=spec)
+    (y * probe.to(dev)).sum().backward()
+    scale = max(1.0, float(yr.abs().max()))
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=2e-5, atol=2e-6 * scale)
+    if kind == "batch":
+        var = x.double().var(0, unbiased=False)
+        nat = float(probe.abs().max() * factors.max() * ref.weight.detach().abs().max() * (1.0 / torch.sqrt(var + ref.eps)).max())
+    else:
+        var = x.double().var(1, unbiased=False)
+        nat = float(probe.abs().max() * factors.max() * ref.weight.detach().abs().max() * (1.0 / torch.sqrt(var + ref.eps)).max())
+    # a pre-activation within fp32 rounding of zero may land on the other side of the ReLU than in float64: allow a
+    # handful of such elements (each is off by one whole term)
+    err = (xd.grad.cpu().double() - xr.grad).abs()
+    bad = err > (2e-5 * xr.grad.abs() + 1e-5 * max(1.0, float(xr.grad.abs().max())) + 4e-6 * nat)
+    assert int(bad.sum()) <= max(2, rows * C // 200000), f"{int(bad.sum())} gradient elements off"
+    gw = max(1.0, float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(ours.weight.grad.cpu().double(), ref.weight.grad, rtol=1e-4, atol=2e-5 * gw)
+    torch.testing.assert_close(ours.bias.grad.cpu().double(), ref.bias.grad, rtol=1e-4, atol=2e-5 * gw)
+
+
+def test_batchnorm_takes_statistics_from_the_gemm():
+    """Lin -> BatchNorm1d(train): the BN finalize consumes the GEMM's per-workgroup partials; same output, same running
+    statistics as with its own statistics pass."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    torch.manual_seed(3)
+    x = torch.randn(20000, 128, device=dev)
+    w = torch.randn(256, 128, device=dev) / 11.0
+    b = torch.randn(256, device=dev)
+    y, stats = node_ops.rows_linear(x, w, b, want_stats=True)
+    bn1, bn2 = node_ops.BatchNorm1d(256).to(dev).train(), node_ops.BatchNorm1d(256).to(dev).train()
+    o1 = bn1(y, fuse_relu=True, stats=stats)
+    o2 = bn2(y, fuse_relu=True)
+    torch.testing.assert_close(o1, o2, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(bn1.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn1.running_var, bn2.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn1.num_batches_tracked) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("norm", ["batch", "layer"])
+@pytest.mark.parametrize("use_checkpoint", [False, True])
+def test_res_plus_layer_equals_the_reference_loop_body(norm, use_checkpoint):
+    """blocks.res_plus_layer == norm -> relu -> (dropout p = 0) -> GENConv -> + h written with separate modules
+    (examples/ogb/ogbn_arxiv/model.py:96-104), outputs and every gradient, two stacked layers so that the statistics
+    hand-over is exercised."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import blocks, synth
+    from gcn_lib.sparse.torch_nn import norm_layer
+    from gcn_lib.sparse.torch_vertex import GENConv
+    dev = _dev()
+    torch.manual_seed(11)
+    N, C = 6000, 128
+    ei = synth.undirected_random_graph(N, 20000, seed=2, device=dev)
+    norms = nn.ModuleList([norm_layer(norm, C) for _ in range(2)]).to(dev).train()
+    convs = nn.ModuleList([GENConv(C, C, aggr="softmax_sg", t=0.1, norm=norm, mlp_layers=1 + i) for i in range(2)]).to(dev).train()
+    h0 = torch.randn(N, C, device=dev)
+    probe = torch.randn(N, C, device=dev)
+
+    def run(fused):
+        for m in list(norms) + list(convs):
+            m.zero_grad(set_to_none=True)
+        for m in norms:
+            if hasattr(m, "reset_running_stats"):
+                m.reset_running_stats()
+        h = h0.clone().requires_grad_(True)
+        x = h * 1.0
+        stats = None
+        for i in range(2):
+            if fused:
+                x, stats = blocks.res_plus_layer(norms[i], convs[i], x, ei, p=0.0, training=True, stats=stats,
+                                                 use_checkpoint=use_checkpoint)
+            else:
+                h2 = torch.relu(norms[i](x))
+                x = convs[i](h2, ei) + x
+        (x * probe).sum().backward()
+        grads = [p.grad.clone() for m in list(norms) + list(convs) for p in m.parameters()]
+        return x.detach(), h.grad.clone(), grads
+
+    y1, gh1, gp1 = run(True)
+    y0, gh0, gp0 = run(False)
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-4 * float(y0.abs().max()))
+    torch.testing.assert_close(gh1, gh0, rtol=1e-4, atol=1e-4 * float(gh0.abs().max()))
+    for a, b in zip(gp1, gp0):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(1e-3, float(b.abs().max())))
+
+
+def test_deepergcn_fused_layers_equal_the_plain_model():
+    """The restated DeeperGCN ('res+', BatchNorm, checkpointing) with its layer loop through blocks.res_plus_layer
+    against the reference-shaped loop: same parameters, same outputs / gradients / running statistics (dropout off)."""
+    import os
+    import sys
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import arch_restated
+    from deep_gcns_torch_amd import synth
+    dev = _dev()
+    torch.manual_seed(5)
+    N = 9000
+    ei = synth.undirected_random_graph(N, 40000, seed=7, device=dev)
+    plain = arch_restated.DeeperGCN(num_layers=9, in_channels=32, hidden=64, num_tasks=10).to(dev).train()
+    fused = arch_restated.DeeperGCN(num_layers=9, in_channels=32, hidden=64, num_tasks=10, fused_layers=True).to(dev).train()
+    fused.load_state_dict(plain.state_dict())
+    x = torch.randn(N, 32, device=dev)
+    y = torch.randint(0, 10, (N,), device=dev)
+    o0 = plain(x, ei)
+    torch.nn.functional.nll_loss(o0, y).backward()
+    o1 = fused(x, ei)
+    torch.nn.functional.nll_loss(o1, y).backward()
+    torch.testing.assert_close(o1, o0, rtol=1e-3, atol=1e-4)
+    for (n0, p0), (n1, p1) in zip(plain.named_parameters(), fused.named_parameters()):
+        assert n0 == n1
+        torch.testing.assert_close(p1.grad, p0.grad, rtol=2e-3, atol=2e-3 * max(1e-4, float(p0.grad.abs().max())), msg=n0)
+    for (n0, b0), (n1, b1) in zip(plain.named_buffers(), fused.named_buffers()):
+        torch.testing.assert_close(b1.float(), b0.float(), rtol=1e-4, atol=1e-5, msg=n0)
+    # with dropout: runs, finite, and about the right fraction of the pre-activations is dropped
+    drop = arch_restated.DeeperGCN(num_layers=3, in_channels=32, hidden=64, num_tasks=10, dropout=0.5, fused_layers=True).to(dev).train()
+    out = drop(x, ei)
+    assert torch.isfinite(out).all()
+    torch.nn.functional.nll_loss(out, y).backward()
+    assert all(torch.isfinite(p.grad).all() for p in drop.parameters())

@@ -90,3 +90,60 @@ def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
     # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge
     # on another device, so the gradient gate is relative to each tensor's scale (not elementwise)
     _check(case, hn, grads, 2e-4, 2e-3)
+
+
+def test_shared_leaf_argument_survives_eval_passes_and_aborted_backwards():
+    """the fused reversible backward accumulates the gradient of a tensor that EVERY layer receives.  With a
+    persistent leaf (a learnable edge embedding handed to all layers) the bookkeeping must not depend on how many
+    forwards ran before: a no_grad evaluation pass, a grad-enabled forward that is never differentiated and a second
+    training step all have to leave ``emb.grad`` equal to what the generic (reference) algorithm gives."""
+    _install()
+    from eff_gcn_modules.rev import memgcn, rev_layer
+    from gcn_lib.sparse import torch_message
+    saved = torch_message.GenMessagePassing.propagate
+    torch_message.GenMessagePassing.propagate = _oracle_propagate
+    try:
+        torch.manual_seed(0)
+        N, E, H, G = 40, 300, 32, 2
+        ei = torch.randint(0, N, (2, E))
+        layers = torch.nn.ModuleList()
+        for _ in range(3):
+            fms = torch.nn.ModuleList([rev_layer.GENBlock(H // G, H // G, aggr="softmax", encode_edge=True, edge_feat_dim=H,
+                                                          norm="layer", mlp_layers=1) for _ in range(G)])
+            layers.append(memgcn.InvertibleModuleWrapper(memgcn.GroupAdditiveCoupling(fms, group=G), keep_input=False))
+        layers.train()
+        emb = torch.nn.Parameter(torch.randn(E, H * G))            # a LEAF every layer receives
+        mask = torch.ones(N, H)
+        x0 = torch.randn(N, H)
+
+        def forward():
+            h = x0.clone().requires_grad_(True) * 1.0
+            for layer in layers:
+                h = layer(h, ei, mask, emb)
+            return h
+
+        def reference_grad():
+            for layer in layers:
+                layer.disable = True                               # plain autograd through the same modules
+            try:
+                emb.grad = None
+                forward().square().sum().backward()
+                return emb.grad.clone()
+            finally:
+                for layer in layers:
+                    layer.disable = False
+
+        want = reference_grad()
+        with torch.no_grad():
+            forward()                                              # evaluation pass
+        forward()                                                  # a forward nobody differentiates
+        for _ in range(2):                                         # two training steps in a row
+            emb.grad = None
+            forward().square().sum().backward()
+            torch.testing.assert_close(emb.grad, want, rtol=1e-4, atol=1e-5)
+        # a second consumer of the same leaf outside the reversible stack
+        emb.grad = None
+        (forward().square().sum() + (emb * 0.5).sum()).backward()
+        torch.testing.assert_close(emb.grad, want + 0.5, rtol=1e-4, atol=1e-5)
+    finally:
+        torch_message.GenMessagePassing.propagate = saved
