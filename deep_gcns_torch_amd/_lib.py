@@ -69,8 +69,15 @@ _SIGNATURES = {
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_void_p]),
     "dgcn_graph_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "dgcn_graph_csr_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_graph_csr_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
+    "dgcn_graph_work_list_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "dgcn_graph_work_list": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_graph_coalesce_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "dgcn_graph_coalesce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_subgraph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "dgcn_subgraph_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -89,13 +89,13 @@ class Graph:
             rowptr = torch.empty(n_rows + 1, **i32)
             col, eperm = torch.empty(E, **i32), torch.empty(E, **i32)
             erow = torch.empty(E, **i32) if want_erow else None
-            status = torch.empty(4, **i32)
+            status = torch.empty(8, **i32)
             ws_bytes = lib.dgcn_graph_csr_workspace_bytes(E, n_rows)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
             with _lib.device_ctx(dev):
-                rc = lib.dgcn_graph_csr_build(key.data_ptr(), other.data_ptr(), E, n_rows, n_other, rowptr.data_ptr(),
-                                              _lib.ptr(col), _lib.ptr(eperm), _lib.ptr(erow), status.data_ptr(),
-                                              ws.data_ptr(), ws_bytes, stream)
+                rc = lib.dgcn_graph_csr_build(key.data_ptr(), other.data_ptr(), E, n_rows, n_other, hub_chunk,
+                                              rowptr.data_ptr(), _lib.ptr(col), _lib.ptr(eperm), _lib.ptr(erow),
+                                              status.data_ptr(), ws.data_ptr(), ws_bytes, stream)
             _lib.check(rc, "dgcn_graph_csr_build")
             return rowptr, col, eperm, erow, status
 
@@ -110,11 +110,30 @@ class Graph:
         self.rowptr, self.col, self._erow = rowptr, col, erow
         self.eperm = eperm if flags[0][2] else None               # already destination-sorted: identity permutation
         self.deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)   # in-degree, float like PyG degree()
-        self.work = _work_list(self.rowptr, hub_chunk) if flags[0][1] > 2 * hub_chunk else None
+        self.work = self._work_list_on_device(rowptr, self.n_dst, hub_chunk, flags[0])
         if need_transpose:
             self.t_rowptr, self.t_col, self.t_eperm = t_rowptr, t_col, t_eperm
             self.out_deg = (t_rowptr[1:] - t_rowptr[:-1]).to(torch.float32)
-            self.t_work = _work_list(self.t_rowptr, hub_chunk) if flags[1][1] > 2 * hub_chunk else None
+            self.t_work = self._work_list_on_device(t_rowptr, self.n_src, hub_chunk, flags[1])
+
+    def _work_list_on_device(self, rowptr, n_rows, hub_chunk, status):
+        """Hub work list from csrc/graph_build.hip; its sizes arrived with the status block (no further host read)."""
+        if status[1] <= 2 * hub_chunk or n_rows == 0:
+            return None
+        lib = _lib.load()
+        dev = self.device
+        n_work, n_slots, n_split = status[3], status[4], status[5]
+        i32 = dict(device=dev, dtype=torch.int32)
+        row, beg, end, slot = (torch.empty(n_work, **i32) for _ in range(4))
+        split = torch.empty(n_split, **i32)
+        ws_bytes = lib.dgcn_graph_work_list_workspace_bytes(n_rows)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with _lib.device_ctx(dev):
+            rc = lib.dgcn_graph_work_list(rowptr.data_ptr(), n_rows, hub_chunk, row.data_ptr(), beg.data_ptr(),
+                                          end.data_ptr(), slot.data_ptr(), split.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          _lib.current_stream_handle(dev))
+        _lib.check(rc, "dgcn_graph_work_list")
+        return n_work, n_slots, row, beg, end, slot, split
 
     def _build_with_torch(self, src, dst, need_transpose, hub_chunk):
         """The same structure from torch ops (CPU tensors: host-logic and gloo tests)."""

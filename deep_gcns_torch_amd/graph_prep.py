@@ -19,15 +19,44 @@ from typing import List, Optional, Tuple
 import torch
 
 
+def _coalesce_device(edge_index: torch.Tensor, num_nodes: int, both: bool) -> torch.Tensor:
+    """dgcn_graph_coalesce (csrc/graph_build.hip): one radix sort of compact row * 2^b + col keys, first-of-run flags,
+    scan, compaction; one host read of (count, bad-id flag)."""
+    from . import _lib
+    lib = _lib.load()
+    dev = edge_index.device
+    ei = edge_index.long().contiguous()
+    E = ei.size(1)
+    n_keys = E * (2 if both else 1)
+    out = torch.empty(2, max(n_keys, 1), device=dev, dtype=torch.long)
+    counts = torch.empty(2, device=dev, dtype=torch.long)
+    ws_bytes = lib.dgcn_graph_coalesce_workspace_bytes(E, num_nodes, 1 if both else 0)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_graph_coalesce(ei[0].data_ptr(), ei[1].data_ptr(), E, num_nodes, 1 if both else 0, out.data_ptr(),
+                                     out.stride(0), counts.data_ptr(), ws.data_ptr(), ws_bytes,
+                                     _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_graph_coalesce")
+    n_out, bad = counts.tolist()                          # the one host read
+    if bad:
+        raise ValueError("edge_index out of range")
+    return out[:, :n_out].clone() if n_out * 2 < n_keys else out[:, :n_out]
+
+
 def coalesce(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     """Sort by (row, col) and drop duplicate edges (torch_sparse.coalesce on indices only)."""
+    if edge_index.is_cuda and num_nodes > 0:
+        return _coalesce_device(edge_index, num_nodes, both=False)
     key = edge_index[0] * num_nodes + edge_index[1]
     key = torch.unique(key, sorted=True)
     return torch.stack([key // num_nodes, key % num_nodes])
 
 
 def to_undirected(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
-    """Both directions of every edge, coalesced (sorted by source, duplicates removed): PyG ``to_undirected``."""
+    """Both directions of every edge, coalesced (sorted by source, duplicates removed): PyG ``to_undirected``
+    (examples/ogb/ogbn_arxiv/main.py:72-75)."""
+    if edge_index.is_cuda and num_nodes > 0:
+        return _coalesce_device(edge_index, num_nodes, both=True)
     both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
     return coalesce(both, num_nodes)
 
@@ -79,7 +108,7 @@ def _induced_subgraph_device(edge_index, parts, cluster, num_nodes):
     nodes = torch.empty(num_nodes, **i64)
     sub = torch.empty(2, E, **i64)
     eids = torch.empty(E, **i64)
-    counts = torch.empty(2, **i64)
+    counts = torch.empty(3, **i64)
     ws_bytes = lib.dgcn_subgraph_workspace_bytes(E, num_nodes)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     with _lib.device_ctx(dev):
@@ -87,8 +116,11 @@ def _induced_subgraph_device(edge_index, parts, cluster, num_nodes):
                                        nodes.data_ptr(), sub[0].data_ptr(), sub[1].data_ptr(), eids.data_ptr(),
                                        counts.data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_subgraph_extract")
-    n_sub, e_sub = counts.tolist()                       # the one host read
-    return nodes[:n_sub], sub[:, :e_sub], eids[:e_sub]
+    n_sub, e_sub, bad = counts.tolist()                  # the one host read
+    if bad:
+        raise ValueError("edge_index out of range")
+    # trimmed COPIES: a caller that keeps one sub-graph per cluster must not pin the full-size (E) scratch arrays
+    return nodes[:n_sub].clone(), sub[:, :e_sub].clone(), eids[:e_sub].clone()
 
 
 def generate_sub_graphs(edge_index: torch.Tensor, parts: torch.Tensor, num_nodes: int, cluster_number: int = 10,

@@ -40,7 +40,7 @@ def generate_sub_graphs(adj, parts, cluster_number=10, batch_size=1):
     nodes with ``parts == c`` for c in range(cluster_number // batch_size) -- ``batch_size`` only changes how
     many batches are produced.  Edge order = scipy's ``tocoo()`` of the sliced CSR (row-major), which is what
     ``torch_geometric.utils.from_scipy_sparse_matrix`` returns.  For the device-side equivalent on an
-    ``edge_index`` see ``deep_gcns_torch_amd.graph_prep.induced_subgraphs``."""
+    ``edge_index`` see ``deep_gcns_torch_amd.graph_prep.induced_subgraph``."""
     if hasattr(adj, "to_scipy"):
         adj = adj.to_scipy(layout='csr')
     else:

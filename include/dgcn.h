@@ -239,20 +239,37 @@ int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshif
  *   the backward CSC), `other` = the opposite endpoint:
  *     rowptr [n_rows+1], col [E] = other endpoint of CSR position p, eperm [E] = original edge id of position p,
  *     erow [E] or NULL = key of position p (the sorted keys)
- *   status [4] int32 (device): [0] != 0 an id was out of range (such edges are dropped from the counts: treat the
- *   structure as invalid), [1] maximum row length, [2] != 0 the keys were NOT already non-decreasing, [3] reserved.
- *   One host read of `status` replaces the min / max / is-sorted / bincount synchronisations of a host-driven build.
+ *   status [8] int32 (device): [0] != 0 an id was out of range (such edges are dropped from the counts: treat the
+ *   structure as invalid), [1] maximum row length, [2] != 0 the keys were NOT already non-decreasing, and -- for
+ *   hub_chunk > 0 -- the sizes of the hub work list: [3] work items, [4] partial-result slots, [5] split rows.
+ *   One host read of `status` replaces the min / max / is-sorted / bincount synchronisations of a host-driven build
+ *   AND sizes the work-list arrays.
+ * dgcn_graph_work_list: the work list of dgcn_graph (rows longer than 2 * hub_chunk edges cut into hub_chunk-edge items:
+ *     work_row / work_beg / work_end / work_slot [status[3]], split_item [status[5]] = first item of every split row);
+ *     slots are numbered in item order, work_slot = -1 for an item that covers its whole row.  No host read.
+ * dgcn_graph_coalesce: the sorted (by row, then col), duplicate-free pairs of an edge list -- torch_sparse.coalesce on
+ *     indices -- or, with both_directions != 0, of the list and its reverse: PyG to_undirected
+ *     (examples/ogb/ogbn_arxiv/main.py:72-75).  out [2][out_stride] int64 (rows, then cols), out_stride >= number of keys
+ *     (E or 2 E); counts [2] int64 (device) = {#pairs written, != 0 when an id was outside [0, n_nodes)}.
  * dgcn_subgraph_extract: the sub-graph induced by the nodes with parts[i] == cluster:
  *     node_ids [<= n_nodes] ascending, (sub_src, sub_dst) [<= E] relabelled to positions in node_ids, original edge
- *     order, edge_ids [<= E] = kept original edge ids (to slice edge_attr); counts [2] int64 (device) = {#nodes, #edges}.
- *   edge endpoints must be valid ids (0 <= id < n_nodes).
+ *     order, edge_ids [<= E] = kept original edge ids (to slice edge_attr); counts [3] int64 (device) = {#nodes, #edges,
+ *     != 0 when an edge endpoint was outside [0, n_nodes) -- such edges are never kept, nothing is read out of bounds}.
  * All int64 inputs are contiguous device arrays; workspaces from the *_workspace_bytes functions; asynchronous on
  * `stream`.
  */
 size_t dgcn_graph_csr_workspace_bytes(int64_t n_edges, int32_t n_rows);
 int dgcn_graph_csr_build(const int64_t* key, const int64_t* other, int64_t n_edges, int32_t n_rows, int32_t n_other,
-                         int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* erow, int32_t* status,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         int32_t hub_chunk, int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* erow,
+                         int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+size_t dgcn_graph_work_list_workspace_bytes(int32_t n_rows);
+int dgcn_graph_work_list(const int32_t* rowptr, int32_t n_rows, int32_t hub_chunk, int32_t* work_row, int32_t* work_beg,
+                         int32_t* work_end, int32_t* work_slot, int32_t* split_item, void* workspace,
+                         size_t workspace_bytes, void* stream);
+size_t dgcn_graph_coalesce_workspace_bytes(int64_t n_edges, int32_t n_nodes, int32_t both_directions);
+int dgcn_graph_coalesce(const int64_t* src, const int64_t* dst, int64_t n_edges, int32_t n_nodes, int32_t both_directions,
+                        int64_t* out, int64_t out_stride, int64_t* counts, void* workspace, size_t workspace_bytes,
+                        void* stream);
 size_t dgcn_subgraph_workspace_bytes(int64_t n_edges, int32_t n_nodes);
 int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edges, const int64_t* parts,
                           int32_t n_nodes, int64_t cluster, int64_t* node_ids, int64_t* sub_src, int64_t* sub_dst,

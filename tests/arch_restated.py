@@ -44,14 +44,18 @@ class DeeperGCN(torch.nn.Module):
     model.py looks like after the change INTEGRATION.md shows."""
 
     def __init__(self, num_layers=8, in_channels=32, hidden=64, num_tasks=10, aggr="softmax_sg", t=0.1,
-                 norm="batch", mlp_layers=1, dropout=0.0, fused_layers=False, **gen_kw):
+                 norm="batch", mlp_layers=1, dropout=0.0, fused_layers=False, checkpoint="reference", **gen_kw):
         super().__init__()
         from gcn_lib.sparse.torch_nn import norm_layer
         from gcn_lib.sparse.torch_vertex import GENConv
         self.num_layers = num_layers
         self.dropout = dropout
         self.fused_layers = fused_layers
-        self.checkpoint_grad = aggr in ("softmax_sg", "softmax", "power") and num_layers > 7
+        # the reference checkpoints the convolutions of deep softmax / power stacks because torch_scatter keeps several
+        # (E, C) temporaries per layer alive; "never" = what a user of this package can do instead: nothing of size
+        # (E, C) exists here, a layer keeps two (N, C) arrays (arxiv, 28 layers: 4.9 GB), and the recomputation of
+        # aggregation + GEMM disappears
+        self.checkpoint_grad = checkpoint == "reference" and aggr in ("softmax_sg", "softmax", "power") and num_layers > 7
         self.ckp_k = num_layers // 2
         self.gcns = torch.nn.ModuleList()
         self.norms = torch.nn.ModuleList()

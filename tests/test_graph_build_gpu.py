@@ -103,3 +103,45 @@ def test_induced_subgraph_matches_scipy_slicing(clusters):
     nd_c, sub_c, _, eids_c = gp.induced_subgraph(ei, torch.from_numpy(parts), 2, n)
     nd_d, sub_d, _, eids_d = gp.induced_subgraph(eid, pd, 2, n)
     assert torch.equal(nd_c, nd_d.cpu()) and torch.equal(sub_c, sub_d.cpu()) and torch.equal(eids_c, eids_d.cpu())
+
+
+def test_coalesce_and_to_undirected_match_the_host_composition():
+    """dgcn_graph_coalesce (radix sort of compact row * 2^b + col keys + first-of-run compaction) against the torch.unique
+    composition on the CPU: PyG to_undirected / torch_sparse.coalesce semantics (examples/ogb/ogbn_arxiv/main.py:72-75)."""
+    g = torch.Generator().manual_seed(3)
+    for n, e in ((50, 400), (3000, 40_000), (100_000, 300_000), (7, 0), (1, 5)):
+        ei = torch.randint(0, n, (2, e), generator=g)
+        for fn in (gp.coalesce, gp.to_undirected):
+            want = fn(ei, n)
+            got = fn(ei.to(DEV), n)
+            assert got.dtype == torch.long and torch.equal(got.cpu(), want), (fn.__name__, n, e)
+    s = synth.SHAPES["arxiv"]
+    raw = torch.randint(0, s["n"], (2, s["n_undirected"]), generator=g)
+    und = gp.to_undirected(raw.to(DEV), s["n"])
+    key = und[0] * s["n"] + und[1]
+    assert bool((key[1:] > key[:-1]).all())                                      # sorted by (row, col), no duplicates
+    assert torch.equal(torch.sort(und[1] * s["n"] + und[0]).values, key)          # symmetric
+    with pytest.raises(ValueError, match="out of range"):
+        gp.coalesce(torch.tensor([[0, 9], [1, 2]], device=DEV), 5)
+
+
+def test_subgraph_extract_rejects_out_of_range_endpoints():
+    parts = torch.zeros(5, dtype=torch.long, device=DEV)
+    with pytest.raises(ValueError, match="out of range"):
+        gp.induced_subgraph(torch.tensor([[0, 1, 7], [1, 2, 0]], device=DEV), parts, 0, 5)
+    with pytest.raises(ValueError, match="out of range"):
+        gp.induced_subgraph(torch.tensor([[0, -1], [1, 2]], device=DEV), parts, 0, 5)
+
+
+def test_hub_work_lists_on_power_law_graphs():
+    """The device work list (dgcn_graph_work_list) on the graphs it exists for: the ogbn-proteins cluster shape (hubs of
+    thousands of in-edges) -- array for array the host construction, and consistent with rowptr."""
+    s = synth.SHAPES["proteins_cluster"]
+    ei = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"])
+    _compare(ei, s["n"], s["n"])
+    gd = Graph(ei[0].to(DEV), ei[1].to(DEV), s["n"], s["n"])
+    n_work, n_slots, row, beg, end, slot, split = gd.work
+    assert n_work == row.numel() and int((slot >= 0).sum()) == n_slots
+    assert bool((end > beg).all()) and bool((end - beg <= 2 * 256).all())
+    rp = gd.rowptr.long()
+    assert torch.equal(beg[split.long()].long(), rp[row[split.long()].long()])    # first item of a split row starts the row

@@ -224,8 +224,11 @@ def test_res_plus_layer_equals_the_reference_loop_body(norm, use_checkpoint):
     y0, gh0, gp0 = run(False)
     torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-4 * float(y0.abs().max()))
     torch.testing.assert_close(gh1, gh0, rtol=1e-4, atol=1e-4 * float(gh0.abs().max()))
+    # a bias in front of a training-mode BatchNorm has an exactly-zero gradient (the mean is removed): what comes out is
+    # rounding noise of the size of the OTHER gradients, so the absolute gate uses the layer-wide gradient scale
+    gscale = max(float(b.abs().max()) for b in gp0)
     for a, b in zip(gp1, gp0):
-        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(1e-3, float(b.abs().max())))
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(gscale, float(b.abs().max())))
 
 
 def test_deepergcn_fused_layers_equal_the_plain_model():
