@@ -289,6 +289,90 @@ def extras(dev):
     return out
 
 
+def model_bench(args, dev, rank, world, dist):
+    """BASELINE config 4 as a model: DeeperGCN-14 (examples/ogb/ogbn_products/model.py shape: GENConv softmax_sg t=0.1,
+    BatchNorm, hidden 128, 100 input features, 47 classes, dropout 0.5, the reference's checkpointing) on the FULL
+    products-shaped graph; with N ranks the rows are partitioned by destination (deep_gcns_torch_amd.dist.partitioned):
+    the aggregation exchanges rows per layer, BatchNorm all-reduces 2 x C sums forward and backward, parameter gradients
+    are summed in one bucket.  A step = forward + backward + gradient all-reduce + Adam.  value = edges aggregated per
+    second over the whole job (E x 14 layers per step)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    import arch_restated
+    from deep_gcns_torch_amd import synth
+    from deep_gcns_torch_amd import dist as ddist
+    s = synth.SHAPES[args.shape]
+    n = s["n"]
+    gen = {"uniform": synth.undirected_random_graph, "powerlaw": synth.powerlaw_graph, "local": synth.local_graph}[args.graph]
+    ei = gen(n, s["n_undirected"], seed=s["seed"], device=dev)
+    E = ei.size(1)
+    torch.manual_seed(0)                                   # identical replicas
+    L = 14
+    m = arch_restated.DeeperGCN(num_layers=L, in_channels=100, hidden=128, num_tasks=47, dropout=0.5,
+                                fused_layers=True).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    gx = torch.Generator(device=dev).manual_seed(1234)
+    if world > 1:
+        scheme = "allgather" if args.scheme == "auto" else args.scheme
+        part = ddist.build_partition(ei, n, 128, rank, world, scheme=scheme)
+        lo, hi = part.lo, part.hi
+        del ei
+        ei_arg = torch.zeros(2, 0, dtype=torch.long, device=dev)      # not looked at inside the partition context
+    else:
+        part, lo, hi, ei_arg = None, 0, n, ei
+    x = torch.randn(n, 100, device=dev, generator=gx)[lo:hi].contiguous()
+    y = torch.randint(0, 47, (n,), device=dev, generator=gx)[lo:hi].contiguous()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if part is not None:
+            with ddist.partitioned(part):
+                torch.nn.functional.nll_loss(m(x, ei_arg), y, reduction="sum").div(n).backward()
+            ddist.allreduce_gradients(m)
+        else:
+            torch.nn.functional.nll_loss(m(x, ei_arg), y, reduction="sum").div(n).backward()
+        opt.step()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "edges/sec aggregated (fwd+bwd) per MI355X; achieved HBM GB/s vs roofline",
+            "value": E * L * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeeperGCN-14 train step (GENConv softmax_sg t=0.1, BatchNorm, hidden 128, dropout 0.5, "
+                                   f"fused 'res+' layers, reference checkpointing) on the full ogbn-{args.shape}-shaped "
+                                   f"{args.graph} graph N={n} E={E}: fwd + bwd + Adam, {L} aggregation layers per step",
+                       "parallelism": ("single GPU" if part is None else
+                                       f"rows partitioned x{world} ({type(part).__name__}), BatchNorm statistics and "
+                                       f"parameter gradients all-reduced over RCCL"),
+                       "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30},
+            "roofline": None, "cpu_baseline": None,
+            "note": "model-level mode (--model): the roofline / cpu_baseline objects belong to the default op benchmark"}),
+            flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +394,10 @@ def main():
                     help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
     ap.add_argument("--node-groups", type=int, default=0, help="transposed scheme: node groups (0 = library default)")
+    ap.add_argument("--model", default="", choices=["", "deepergcn14"],
+                    help="time a whole node-partitioned MODEL step instead of the aggregation op: deepergcn14 = BASELINE "
+                         "config 4 (DeeperGCN-14, GENConv softmax_sg, BatchNorm, hidden 128) on the full products-shaped "
+                         "graph, rows partitioned over the ranks, BatchNorm statistics all-reduced, fwd + bwd + Adam")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,6 +427,9 @@ def main():
         # a rank that dies inside a collective must surface as an error within minutes, not as the default 10-minute hang
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
                                 timeout=datetime.timedelta(seconds=240))
+
+    if args.model:
+        return model_bench(args, dev, rank, world, dist)
 
     s = synth.SHAPES[args.shape]
     C = args.channels or s["channels"]

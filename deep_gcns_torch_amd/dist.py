@@ -677,3 +677,135 @@ def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = 
     out["local_channels"] = int(c_loc)
     return out
 
+
+
+# ------------------------------------------------------------------------------------------------
+# Model-level node partition (BASELINE config 4: DeeperGCN on ogbn-products, node-partitioned across the GPUs of a node)
+# ------------------------------------------------------------------------------------------------
+# ``with dist.partitioned(part): out = model(x_local, edge_index_placeholder)`` runs an UNCHANGED gcn_lib.sparse model on
+# this rank's rows: while the context is active
+#   * GenMessagePassing.propagate (gcn_lib/sparse/torch_vertex.py:68) aggregates through ``aggregate(x_local, part)`` --
+#     the exchange scheme of ``part`` -- instead of building a graph from the edge_index argument;
+#   * BatchNorm1d (norm_layer('batch'), gcn_lib/sparse/torch_nn.py:23-34) takes its batch statistics over ALL ranks'
+#     rows: the per-rank partial sums (2 x C doubles: sum, sum of squares; in the backward sum g', sum g' xhat) are
+#     all-reduced, forward and backward -- values, gradients and running statistics equal the
+#     single-process ones;
+#   * everything else of the layer (Linear, LayerNorm, ReLU, dropout, residual) is row-local.
+# Parameters are replicated: after backward, ``allreduce_gradients(model)`` sums their gradients (one flat bucket).
+import threading
+
+_ACTIVE = threading.local()
+
+
+class BatchSync:
+    """All-reduce of BatchNorm partial sums across the ranks of ``group``; ``total_rows`` = rows of the whole graph."""
+
+    def __init__(self, total_rows: int, group=None):
+        self.total_rows, self.group = int(total_rows), group
+
+    def reduce(self, partials: torch.Tensor) -> torch.Tensor:
+        """(P, 2, C) fp32 per-workgroup partial sums of this rank -> (2, 2, C) fp32 = the global sums as a (hi, lo)
+        pair (the finalize kernels add partials in float64, so the pair carries ~48 bits)."""
+        tot = partials.double().sum(0)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        hi = tot.float()
+        lo = (tot - hi.double()).float()
+        return torch.stack([hi, lo]).contiguous()
+
+    def reduce64(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class partitioned:
+    """Context: run gcn_lib.sparse modules on the rows of one partition (see the section comment)."""
+
+    def __init__(self, part, group=None, local_aggregate=None, **aggregate_kw):
+        self.part, self.group, self.local_aggregate, self.kw = part, group, local_aggregate, aggregate_kw
+        self.sync = BatchSync(part.bounds[-1], group)
+
+    def __enter__(self):
+        self._prev = getattr(_ACTIVE, "ctx", None)
+        _ACTIVE.ctx = self
+        return self
+
+    def __exit__(self, *exc):
+        _ACTIVE.ctx = self._prev
+        return False
+
+
+def active_partition():
+    return getattr(_ACTIVE, "ctx", None)
+
+
+def partition_aggregate(ctx: "partitioned", x_local: torch.Tensor, aggr: str, **kw) -> torch.Tensor:
+    extra = dict(ctx.kw)
+    if ctx.local_aggregate is not None:
+        extra["local_aggregate"] = ctx.local_aggregate
+    return aggregate(x_local, ctx.part, aggr=aggr, group=ctx.group, **extra, **kw)
+
+
+class _SyncBatchNormTorch(torch.autograd.Function):
+    """BatchNorm1d (training) over the rows of ALL ranks in plain torch ops: the CPU / gloo form of what
+    node_ops._BatchNormRows does on the device with the same ``BatchSync`` (and the reference the GPU tests compare it
+    with).  y = [relu](gamma * xhat + beta) [* factors]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, momentum, eps, relu, factors, sync):
+        x64 = x.double()
+        s = sync.reduce64(torch.stack([x64.sum(0), (x64 * x64).sum(0)]))
+        n = float(sync.total_rows)
+        mean = s[0] / n
+        var = (s[1] / n - mean * mean).clamp_min(0.0)
+        istd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+                running_var.mul_(1 - momentum).add_(momentum * (var * (n / max(n - 1.0, 1.0))).to(running_var.dtype))
+                if num_batches is not None:
+                    num_batches.add_(1)
+        xh = (x64 - mean) * istd
+        g = weight.double() if weight is not None else torch.ones_like(mean)
+        b = bias.double() if bias is not None else torch.zeros_like(mean)
+        pre = xh * g + b
+        y = torch.relu(pre) if relu else pre
+        if factors is not None:
+            y = y * factors.double()
+        ctx.save_for_backward(xh, g, istd, pre, factors)
+        ctx.cfg = (relu, sync, n, weight is not None, bias is not None)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, g, istd, pre, factors = ctx.saved_tensors
+        relu, sync, n, has_w, has_b = ctx.cfg
+        gp = gy.double()
+        if factors is not None:
+            gp = gp * factors.double()
+        if relu:
+            gp = gp * (pre > 0)
+        s = sync.reduce64(torch.stack([gp.sum(0), (gp * xh).sum(0)]))
+        dx = g * istd * (gp - s[0] / n - xh * (s[1] / n))
+        # dgamma / dbeta: the GLOBAL sums (identical on every rank); allreduce_gradients averages replicated-parameter
+        # gradients by summing per-rank parts, so hand back this rank's share
+        gw = (gp * xh).sum(0) if has_w else None
+        gb = gp.sum(0) if has_b else None
+        return (dx.to(gy.dtype), None if gw is None else gw.to(gy.dtype), None if gb is None else gb.to(gy.dtype),
+                None, None, None, None, None, None, None, None)
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None) -> None:
+    """Sum the gradients of the (replicated) parameters over the ranks -- every rank differentiated the loss terms of
+    its own rows.  One flat bucket, one collective."""
+    buckets = {}
+    for p in module.parameters():
+        if p.grad is not None:
+            buckets.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+    for ps in buckets.values():                      # one flat bucket per dtype (normally exactly one)
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for p in ps:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n

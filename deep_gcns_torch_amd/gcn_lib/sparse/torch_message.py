@@ -11,6 +11,12 @@ from ...graph import Graph, graph_of, scatter_graph_of
 
 __all__ = ["GenMessagePassing", "MsgNorm"]
 
+
+def _active_partition():
+    import sys
+    d = sys.modules.get("deep_gcns_torch_amd.dist")      # only a process that imported dist can have an active partition
+    return d.active_partition() if d is not None else None
+
 _SOFTMAX = ("softmax_sg", "softmax", "softmax_sum")
 _POWER = ("power", "power_sum")
 
@@ -78,12 +84,36 @@ class GenMessagePassing(torch.nn.Module):
             out = torch.pow(graph.deg.unsqueeze(1), self.sigmoid_y) * out
         return out
 
+    def _aggregate_partitioned(self, ctx, x, edge_attr, add_root, edge_encoder):
+        """Inside ``with dist.partitioned(part)``: ``x`` holds this rank's rows, the aggregation runs through the
+        partition's exchange scheme (deep_gcns_torch_amd/dist.py), the ``edge_index`` argument is not looked at."""
+        from ... import dist as _dist
+        if edge_attr is not None or edge_encoder is not None:
+            raise NotImplementedError("node-partitioned layers: edge features are not partitioned yet")
+        aggr = self.aggr
+        kw = dict(eps=getattr(self, "eps", 1e-7))
+        if aggr in ("softmax_sum", "power_sum"):
+            raise NotImplementedError("node-partitioned layers: the degree-scaled (*_sum) aggregators are not wired up")
+        if aggr in _SOFTMAX:
+            kw.update(t=self.t)
+            if self.learn_t:
+                kw.update(learn_t=True)
+        elif aggr in _POWER:
+            kw.update(p=self.p)
+            if isinstance(self.p, torch.nn.Parameter):
+                kw.update(learn_p=True)
+        out = _dist.partition_aggregate(ctx, x, aggr or "add", **kw)
+        return x + out if add_root else out
+
     # -- PyG-flavoured entry points kept for API compatibility ----------------------------
     def propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False, edge_encoder=None):
         """``propagate(edge_index, x=x, edge_attr=edge_attr)`` as GENConv.forward calls it
         (gcn_lib/sparse/torch_vertex.py:68): message + aggregate + update in one kernel.  ``add_root`` (extension)
         returns ``x + aggregate`` from the same kernel when ``fusable_root()``; ``edge_encoder=(weight, bias)``
         (extension) takes ``edge_attr`` as RAW features and applies the Linear edge encoder inside the kernels."""
+        part = _active_partition()
+        if part is not None:
+            return self.update(self._aggregate_partitioned(part, x, edge_attr, add_root, edge_encoder))
         n = x.size(0) if size is None else (size[1] if isinstance(size, (tuple, list)) else size)
         return self.update(self._aggregate_fused(x, graph_of(edge_index, n), edge_attr, relu_eps=True,
                                                  eps=getattr(self, "eps", 1e-7), add_root=add_root,

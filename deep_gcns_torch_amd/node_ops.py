@@ -100,7 +100,9 @@ def _mask_rows(drop: DropSpec, rows: int, C: int, dev):
 class _BatchNormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, use_batch_stats: bool, momentum: float,
-                eps: float, relu: bool, track: bool, drop: DropSpec = None, stats=None):
+                eps: float, relu: bool, track: bool, drop: DropSpec = None, stats=None, sync=None):
+        """``sync`` (dist.BatchSync or None): all-reduce the statistics partials over the ranks of a node-partitioned
+        graph, forward and backward: the batch is the whole graph's rows."""
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
@@ -128,22 +130,26 @@ class _BatchNormRows(torch.autograd.Function):
                                "dgcn_rows_stats_f32")
             else:
                 stats = None
+            count = float(rows)
+            if sync is not None and use_batch_stats:
+                stats = sync.reduce(stats)
+                nparts, count = stats.size(0), float(sync.total_rows)
             _lib.check(lib.dgcn_bn_finalize_f32(
-                _lib.ptr(stats), nparts, C, float(rows), _lib.ptr(w), _lib.ptr(b), _lib.ptr(running_mean),
+                _lib.ptr(stats), nparts, C, count, _lib.ptr(w), _lib.ptr(b), _lib.ptr(running_mean),
                 _lib.ptr(running_var), _lib.ptr(num_batches), 1 if use_batch_stats else 0, float(momentum),
                 float(eps), bnbuf.data_ptr(), stream), "dgcn_bn_finalize_f32")
             _lib.check(lib.dgcn_rows_bn_act_apply_f32(x.data_ptr(), ld, bnbuf.data_ptr(), 1 if relu else 0, *drop.args(),
                                                       y.data_ptr(), rows, C, stream), "dgcn_rows_bn_act_apply_f32")
         if track and any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(x, bnbuf, drop.mask)
-            ctx.cfg = (use_batch_stats, weight is not None, bias is not None, relu, drop)
+            ctx.cfg = (use_batch_stats, weight is not None, bias is not None, relu, drop, sync)
         return y
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         x, bnbuf, mask = ctx.saved_tensors
-        use_batch_stats, has_w, has_b, relu, drop = ctx.cfg
+        use_batch_stats, has_w, has_b, relu, drop, sync = ctx.cfg
         dev = x.device
         stream = _lib.current_stream_handle(dev)
         rows, C = x.shape
@@ -158,7 +164,15 @@ class _BatchNormRows(torch.autograd.Function):
             _lib.check(lib.dgcn_rows_bn_act_bwd_stats_f32(g.data_ptr(), x.data_ptr(), ld, bnbuf.data_ptr(),
                                                           1 if relu else 0, *drop.args(), partial.data_ptr(), rows, C,
                                                           stream), "dgcn_rows_bn_act_bwd_stats_f32")
-            _lib.check(lib.dgcn_rows_bn_bwd_finalize_f32(partial.data_ptr(), nparts, C, float(rows),
+            count = float(rows)
+            local = None
+            if sync is not None and use_batch_stats:
+                # c1, c2 need the sums over ALL ranks' rows; dgamma / dbeta stay this rank's share (the caller sums the
+                # replicated parameters' gradients over the ranks)
+                local = partial.double().sum(0).float()
+                partial = sync.reduce(partial)
+                nparts, count = partial.size(0), float(sync.total_rows)
+            _lib.check(lib.dgcn_rows_bn_bwd_finalize_f32(partial.data_ptr(), nparts, C, count,
                                                          1 if use_batch_stats else 0, coef.data_ptr(), stream),
                        "dgcn_rows_bn_bwd_finalize_f32")
             if dx is not None:
@@ -166,9 +180,13 @@ class _BatchNormRows(torch.autograd.Function):
                                                               coef.data_ptr(), 1 if relu else 0, *drop.args(), None,
                                                               dx.data_ptr(), rows, C, stream),
                            "dgcn_rows_bn_act_bwd_apply_f32")
-        gw = coef[0] if (has_w and ctx.needs_input_grad[1]) else None      # rows of a fresh tensor: no copy needed
-        gb = coef[1] if (has_b and ctx.needs_input_grad[2]) else None
-        return (dx, gw, gb) + (None,) * 10
+        if local is not None:
+            gw = local[1] if (has_w and ctx.needs_input_grad[1]) else None
+            gb = local[0] if (has_b and ctx.needs_input_grad[2]) else None
+        else:
+            gw = coef[0] if (has_w and ctx.needs_input_grad[1]) else None  # rows of a fresh tensor: no copy needed
+            gb = coef[1] if (has_b and ctx.needs_input_grad[2]) else None
+        return (dx, gw, gb) + (None,) * 11
 
 
 def _supported(x: torch.Tensor) -> bool:
@@ -178,13 +196,13 @@ def _supported(x: torch.Tensor) -> bool:
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, num_batches, training: bool, momentum: float,
-                    eps: float, relu: bool = False, drop: DropSpec = None, stats=None) -> torch.Tensor:
+                    eps: float, relu: bool = False, drop: DropSpec = None, stats=None, sync=None) -> torch.Tensor:
     """BatchNorm1d over the rows of ``x`` (rows, C) [+ ReLU] [+ dropout]; ``training`` selects batch statistics (and
     updates the running buffers in place when given).  ``stats``: (parts, 2, C) partial sums of x and x^2 that the
     producer of ``x`` already computed (``rows_linear(..., want_stats=True)``): the statistics pass is skipped."""
     return _BatchNormRows.apply(x, weight, bias, running_mean, running_var, num_batches, bool(training),
                                 float(momentum), float(eps), bool(relu), torch.is_grad_enabled(), drop,
-                                stats if training else None)
+                                stats if training else None, sync if training else None)
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -208,12 +226,38 @@ class BatchNorm1d(nn.BatchNorm1d):
         return use_batch, momentum, nb, rm, rv
 
     def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None):
+        sync = _active_sync() if self.training else None      # node-partitioned graph: statistics over all ranks' rows
         a = self._hip_args(x)
         if a is None:
+            if sync is not None and x.dim() == 2:
+                return _sync_bn_torch(self, x, fuse_relu, drop, sync)
             return _stock_tail(super().forward(x), fuse_relu, drop)
         use_batch, momentum, nb, rm, rv = a
         return batch_norm_rows(x, self.weight, self.bias, rm, rv, nb, use_batch, momentum, self.eps, relu=fuse_relu,
-                               drop=drop, stats=stats if use_batch else None)
+                               drop=drop, stats=stats if use_batch else None, sync=sync if use_batch else None)
+
+
+def _active_sync():
+    import sys
+    d = sys.modules.get(__package__ + ".dist")         # only a process that imported dist can have an active partition
+    ctx = d.active_partition() if d is not None else None
+    return None if ctx is None else ctx.sync
+
+
+def _sync_bn_torch(bn, x, relu, drop, sync):
+    """Training-mode BatchNorm1d over all ranks' rows for inputs the row kernels do not take (CPU tensors: the gloo
+    tests): dist._SyncBatchNormTorch."""
+    from . import dist as _d
+    factors = None
+    if drop is not None and drop.mode == DROP_MASK:
+        factors = drop.mask
+    elif drop is not None and drop.mode == DROP_HASH:
+        factors = hash_keep_factors(x.size(0), x.size(1), drop.s0, drop.s1, drop.thr).to(x.device)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    track = bn.track_running_stats
+    return _d._SyncBatchNormTorch.apply(x, bn.weight, bn.bias, bn.running_mean if track else None,
+                                        bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                                        momentum, bn.eps, relu, factors, sync)
 
 
 def _stock_tail(y, relu: bool, drop: DropSpec):
