@@ -82,7 +82,7 @@ _SIGNATURES = {
     "dgcn_subgraph_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
-    "dgcn_knn_dense_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "dgcn_knn_dense_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dgcn_knn_dense_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -18,7 +18,7 @@
 // Selection is exact: the output is the ascending-distance order of torch.topk(-D, K) wherever
 // distances are distinct; equal distances are ordered by index (torch leaves that order open).
 
-#include "dgcn_common.h"
+#include "bf16x6.h"
 
 namespace dgcn {
 namespace {
@@ -34,6 +34,8 @@ struct KnnParams {
   int B, C, N, K, dilation, Kout;
   int* redo;           // null, or [1 + B*N]: redo[0] = number of rows the filter kernel could not finish, redo[1..] =
                        // their flat ids b*N+i (any order).  Exact kernel: when non-null, one listed row per tile.
+  const i4v* planes;   // bf16 filter path: [3][B*N][C/8] units of 8 bf16 -- the three exact bf16 planes of every point,
+                       // point-major (written by knn_planes_kernel), or null
   float* sqnorm;       // [B*N] |x_j|^2 (fma chain over channels), written by knn_prep_kernel for the filter pass
   uint32_t* tau;       // [B*N] per-row sample threshold (ordered-uint key), written by knn_prep_kernel
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
@@ -773,6 +775,193 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
   }
 }
 
+// ---- bf16 planes of the points: every fp32 coordinate split exactly into three bf16 values (csrc/bf16x6.h), written
+// point-major so that an MFMA fragment (8 consecutive channels of one point) is ONE 16-byte load.  Reads are coalesced
+// along the points of a channel row; 6 bytes per coordinate: 12.6 MB for B = 8, N = 4096, C = 64.
+__global__ __launch_bounds__(256) void knn_planes_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int B,
+                                                         int C, int N, i4v* __restrict__ planes) {
+  const int64_t pts = static_cast<int64_t>(B) * N;
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= pts) return;
+  const int b = static_cast<int>(gid / N), i = static_cast<int>(gid % N);
+  const float* xp = x + b * sb + i;
+  const int units = C / 8;
+  for (int u = 0; u < units; ++u) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = xp[static_cast<int64_t>(8 * u + e) * sc];
+    i4v h, m, l;
+    eg_split3(f4v{v[0], v[1], v[2], v[3]}, f4v{v[4], v[5], v[6], v[7]}, h, m, l);
+    planes[gid * units + u] = h;
+    planes[(pts + gid) * units + u] = m;
+    planes[(2 * pts + gid) * units + u] = l;
+  }
+}
+
+// ---- the filter kernel with the distance pass on the bf16 matrix pipe --------------------------------------------------
+// Same structure as knn_filter_kernel (16 query rows per 1024-thread workgroup, per-row candidate lists in LDS, exact
+// select per row, rows that miss [K, CAP] go to the exact kernel), but
+//   * the inner products come from v_mfma_f32_16x16x32_bf16 on pre-split operands: six products per 16x16x32 block
+//     (bf16x6.h: fp32-faithful, max error / sum|a||b| = 1.7e-7).  The fp32 MFMA of the kernel above issues on the
+//     VECTOR ALU port at the vector rate (SQ_VALU_MFMA_BUSY 20 % of the kernel, additive with the 65 % of VALU work of
+//     the append / select code, profiles/r01_knn_filter_counters.md); the bf16 pipe is 16x faster per flop and runs
+//     beside the other waves' VALU instructions;
+//   * operands are read as ready-made 16-byte fragments (no per-chunk LDS reads of the query rows, no fp32 split in the
+//     loop): the 16 query rows' fragments live in 24 registers for the whole kernel;
+//   * blocks are mapped sample-minor (sample = blockIdx % B): block v runs on XCD v % 8, so with B = 8 every XCD's L2
+//     holds ONE sample's planes (1.5 MB) instead of all eight (12.6 MB against 4 MB of L2).
+// Distances: D = (|x_i|^2 + (-2 ip)) + |x_j|^2 with ip from the six-product sum instead of the channel-ordered fma chain:
+// the same value up to fp32 rounding (not bit for bit); a row is ranked entirely by ONE of the two evaluations (this
+// kernel's, or the exact kernel's chain when the row is redone), never by a mixture.
+template <int kFCap, int KC>
+__global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const KnnParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = kFTM;
+  const int N = P.N, K = P.K;
+  float* sq = reinterpret_cast<float*>(smem);                       // [16]
+  uint32_t* tau = reinterpret_cast<uint32_t*>(sq + TM);             // [16]
+  int* cnt = reinterpret_cast<int*>(tau + TM);                      // [16]
+  uint32_t* ckey = reinterpret_cast<uint32_t*>(cnt + TM);           // [16][kFCap]
+  uint32_t* cidx = ckey + TM * kFCap;                               // [16][kFCap]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int b = blockIdx.x % P.B;                                   // sample-minor: see above
+  const int tile = blockIdx.x / P.B;
+  const int i0 = tile * TM;
+  constexpr int UNITS = 4 * KC;                                     // 16-byte units per point and plane (C = 32 KC)
+  const int64_t pts = static_cast<int64_t>(P.B) * N;
+  const i4v* pb = P.planes + static_cast<int64_t>(b) * N * UNITS;   // plane 0 of this sample; + p * pts * UNITS
+
+  if (tid < TM) {
+    const int64_t row = static_cast<int64_t>(b) * N + min(i0 + tid, N - 1);
+    sq[tid] = P.sqnorm[row];
+    tau[tid] = P.tau[row];
+    cnt[tid] = 0;
+  }
+  const int li = lane & 15, lk = lane >> 4;
+  // A fragments: lane (m = li, kq = lk) holds channels 32 kb + 8 lk .. + 7 of query row i0 + li, three planes
+  i4v a[KC][3];
+  {
+    const int64_t qrow = min(i0 + li, N - 1);
+#pragma unroll
+    for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[kb][p] = pb[p * pts * UNITS + qrow * UNITS + 4 * kb + lk];
+    }
+  }
+  __syncthreads();
+
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
+  constexpr int kColStride = kFWaves * 64;
+  // one step = the three plane fragments of TWO 16-candidate tiles for one 32-channel block: 6 loads, 12 MFMAs that
+  // alternate between the two accumulators (no back-to-back dependent MFMAs); the next step's loads are in flight
+  // while this step's MFMAs run.  Four steps (2 tile pairs x KC) per 64-candidate block when KC = 2.
+  auto load_step = [&](int col0, int pair, int kb, i4v (&f)[2][3]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t pt = min(col0 + 16 * (2 * pair + t) + li, N - 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) f[t][p] = pb[p * pts * UNITS + pt * UNITS + 4 * kb + lk];
+    }
+  };
+  auto mfma_step = [&](f32x4 (&acc)[4], int pair, int kb, const i4v (&f)[2][3]) {
+    // a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2
+    constexpr int pa[6] = {0, 0, 1, 0, 2, 1};
+    constexpr int pbb[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[2 * pair + t] = eg_mfma_bf16(a[kb][pa[s6]], f[t][pbb[s6]], acc[2 * pair + t]);
+    }
+  };
+  constexpr int NSTEP = 2 * KC;
+  i4v fA[2][3], fB[2][3];
+  load_step(wave * 64, 0, 0, fA);
+  for (int col0 = wave * 64; col0 < N; col0 += kColStride) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NSTEP; st += 2) {
+      // step st (in fA), prefetch st + 1 into fB; then step st + 1, prefetch st + 2 (or the next block's step 0) into fA
+      load_step(col0, (st + 1) / KC, (st + 1) % KC, fB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(acc, st / KC, st % KC, fA);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = st + 2 < NSTEP;
+      load_step(more ? col0 : col0 + kColStride, more ? (st + 2) / KC : 0, more ? (st + 2) % KC : 0, fA);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(acc, (st + 1) / KC, (st + 1) % KC, fB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // acc[t][reg] = <x_row, x_col> for row = lk*4 + reg, col = col0 + 16 t + li
+    float sj[4];
+    bool in[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = col0 + 16 * t + li;
+      in[t] = c < N;
+      sj[t] = in[t] ? sqn[c] : 0.f;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
+      const uint32_t tr = tau[r];
+      const int self = P.exclude_self ? i0 + r : -1;
+      uint32_t key[4];
+      bool hit[4];
+      unsigned long long m[4];
+      const unsigned long long grp = 0xFFFFull << (16 * lk);  // this row's lanes
+      int tot = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        key[t] = key_of((sq[r] + (-2.f * acc[t][reg])) + sj[t]);
+        hit[t] = in[t] && key[t] <= tr && (col0 + 16 * t + li) != self;
+        m[t] = __ballot(hit[t]) & grp;
+        tot += __popcll(m[t]);
+      }
+      int base = 0;
+      if (li == 0 && tot) base = atomicAdd(&cnt[r], tot);
+      base = __shfl(base, lk * 16);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pos = base + __popcll(m[t] & below);
+        if (hit[t] && pos < kFCap) {
+          ckey[r * kFCap + pos] = key[t];
+          cidx[r * kFCap + pos] = static_cast<uint32_t>(col0 + 16 * t + li);
+        }
+        base += __popcll(m[t]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per-row select on the candidate lists (as in knn_filter_kernel) ----
+  for (int rr = wave; rr < TM; rr += kFWaves) {
+    const int i = i0 + rr;
+    if (i >= N) continue;  // wave-uniform
+    const int c = cnt[rr];
+    const bool ok = c >= K && c <= kFCap;
+    if (!ok) {   // hand the row to the exact kernel
+      if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = b * N + i;
+      continue;
+    }
+    uint32_t* ck = ckey + rr * kFCap;
+    uint32_t* ci = cidx + rr * kFCap;
+    if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
+    else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
+    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
+    else if (c <= 12 * kWave) filter_select_row<12>(P, ck, ci, c, b, i, lane);
+    else filter_select_row<16>(P, ck, ci, c, b, i, lane);
+  }
+}
+
+size_t knn_filter_bf16_lds_bytes(int cap) { return 3u * kFTM * 4u + static_cast<size_t>(kFTM) * cap * 8u; }
+
 size_t knn_filter_lds_bytes(int C, int cap) {
   return (static_cast<size_t>(C) * kFTM + 3 * kFTM) * 4 + static_cast<size_t>(kFTM) * cap * 8;
 }
@@ -805,11 +994,21 @@ using namespace dgcn;
 // x: (B, C, N) fp32 with element strides (sb, sc, sn).  K = k*dilation neighbours are selected per
 // point (self included, ascending distance); positions 0, d, 2d, ... are written, Kout = ceil(K/d).
 // nn_out / ctr_out: [B, N, Kout] int64 contiguous (ctr_out may be NULL).
-extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N) {
-  if (B <= 0 || N <= 0) return 0;
-  // |x_j|^2 (fp32) and the sample threshold (u32) per point, then the redo list: a counter + up to B*N row ids
+namespace dgcn {
+namespace {
+// channels the bf16 filter kernel is instantiated for (C = 32 KC; KC = 4 would need 48 registers of query fragments and
+// spills under the 128-VGPR budget of 16 waves per workgroup: C = 128 stays on the fp32-MFMA kernel)
+inline int knn_bf16_kc(int C) { return (C == 32 || C == 64) ? C / 32 : 0; }
+inline size_t knn_ws_head(size_t pts) { return (pts * 12u + 4u + 255u) / 256u * 256u; }
+}  // namespace
+}  // namespace dgcn
+
+extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C) {
+  if (B <= 0 || N <= 0 || C <= 0) return 0;
+  // |x_j|^2 (fp32) and the sample threshold (u32) per point, then the redo list: a counter + up to B*N row ids; then the
+  // three bf16 planes of the points (6 bytes per coordinate) when the bf16 filter kernel serves this width
   const size_t pts = static_cast<size_t>(B) * static_cast<size_t>(N);
-  return (pts * 12u + 4u + 15u) / 16u * 16u;
+  return knn_ws_head(pts) + (knn_bf16_kc(C) ? pts * static_cast<size_t>(C) * 6u : 0u);
 }
 
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
@@ -837,6 +1036,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.Kout = (K + dilation - 1) / dilation;
   P.nn_out = nn_out; P.ctr_out = ctr_out;
   P.redo = nullptr;
+  P.planes = nullptr;
   P.sqnorm = nullptr;
   P.tau = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
@@ -858,7 +1058,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   // small lists (two workgroups per CU) when the 3.2-sigma target fits under 512 with margin
   const bool small_lists = K + 3.2 * (N / 256.0) * sqrt(K / (N / 256.0) > 1.0 ? K / (N / 256.0) : 1.0) + 2.0 * (N / 256.0) + 96 <= 512;
   const int cap = small_lists ? 512 : 1024;
-  if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N) &&
+  if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N, C) &&
       knn_filter_lds_bytes(C, cap) <= static_cast<size_t>(kLdsBudget)) {
     KnnParams F = P;
     const size_t pts = static_cast<size_t>(B) * N;
@@ -875,6 +1075,28 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
       if (e != hipSuccess) return static_cast<int>(e);
       hipLaunchKernelGGL(knn_prep_kernel, fgrid, dim3(kPrepThreads), plds, s, F);
+      const int kc = knn_bf16_kc(C);
+      if (kc) {
+        // distance pass on the bf16 matrix pipe from pre-split point-major planes
+        i4v* planes = reinterpret_cast<i4v*>(static_cast<char*>(workspace) + knn_ws_head(pts));
+        hipLaunchKernelGGL(knn_planes_kernel, dim3(static_cast<unsigned>((pts + 255) / 256)), dim3(256), 0, s, x, sb, sc,
+                           B, C, N, planes);
+        F.planes = planes;
+        const size_t blds = knn_filter_bf16_lds_bytes(cap);
+#define DGCN_KNNB_LAUNCH(CAP, KCV)                                                                           \
+  do {                                                                                                        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_bf16_kernel<CAP, KCV>),                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(blds));              \
+    if (e != hipSuccess) return static_cast<int>(e);                                                          \
+    hipLaunchKernelGGL((knn_filter_bf16_kernel<CAP, KCV>), fgrid, dim3(kFThreads), blds, s, F);               \
+  } while (0)
+        if (cap == 512) {
+          if (kc == 1) DGCN_KNNB_LAUNCH(512, 1); else DGCN_KNNB_LAUNCH(512, 2);
+        } else {
+          if (kc == 1) DGCN_KNNB_LAUNCH(1024, 1); else DGCN_KNNB_LAUNCH(1024, 2);
+        }
+#undef DGCN_KNNB_LAUNCH
+      } else {
       // chunk = 4*KS channels, two chunks per column block: KS sized so that C fills both
       const int ks = C > 16 ? 4 : 2;   // (KS = 8 double-buffered needs > 128 VGPRs: spills)
 #define DGCN_KNNF_LAUNCH(CAP, KSV)                                                                           \
@@ -890,6 +1112,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
         if (ks == 4) DGCN_KNNF_LAUNCH(1024, 4); else DGCN_KNNF_LAUNCH(1024, 2);
       }
 #undef DGCN_KNNF_LAUNCH
+      }
       // The exact pass below only redoes the rows the filter pass listed: one row per tile (a redo then costs one
       // row's distance strip, not eight), a fixed grid striding over the device-side list.
       P.redo = F.redo;

@@ -292,9 +292,13 @@ int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edge
  *   workspace (optional, dgcn_knn_dense_workspace_bytes): enables the candidate-filter fast path for N >= 1024
  *            (pre-pass: |x_j|^2 and a per-row sampled threshold; 16 rows per workgroup on the matrix cores; the
  *            rows it cannot finish are listed on the device and redone by the exact path);
- *            without it every row takes the exact full-row path.  Results are identical either way.
+ *            without it every row takes the exact full-row path.  For C in {32, 64} the fast path evaluates the
+ *            inner products on the bf16 matrix pipe from exact three-way bf16 splits (six products, fp32-faithful:
+ *            csrc/bf16x6.h) instead of the channel-ordered fma chain: the same distances up to fp32 rounding, so two
+ *            candidates closer than that may be ranked either way (as on any other fp32 evaluation of the reference's
+ *            formula); every row is ranked by one evaluation only.  Other widths: identical results either way.
  * Limits: N <= 4096, K <= 1024 (the candidate-filter fast path serves K <= 512), K <= N. */
-size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N);
+size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C);
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,
                        int32_t N, int32_t K, int32_t dilation, int32_t exclude_self, int64_t* nn_out,
                        int64_t* ctr_out, void* workspace, size_t workspace_bytes, void* stream);

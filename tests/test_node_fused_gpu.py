@@ -255,9 +255,14 @@ def test_deepergcn_fused_layers_equal_the_plain_model():
     o1 = fused(x, ei)
     torch.nn.functional.nll_loss(o1, y).backward()
     torch.testing.assert_close(o1, o0, rtol=1e-3, atol=1e-4)
+    # nine stacked layers, each re-normalised by a training-mode BatchNorm: the two loops differ by fp32 rounding per
+    # layer (residual added in the GEMM epilogue, statistics summed in another order) and a pre-activation within
+    # rounding of 0 may cross the ReLU: gate every parameter gradient by its relative L2 error
+    gscale = max(float(p.grad.abs().max()) for p in plain.parameters())
     for (n0, p0), (n1, p1) in zip(plain.named_parameters(), fused.named_parameters()):
         assert n0 == n1
-        torch.testing.assert_close(p1.grad, p0.grad, rtol=2e-3, atol=2e-3 * max(1e-4, float(p0.grad.abs().max())), msg=n0)
+        err = float((p1.grad - p0.grad).double().norm() / p0.grad.double().norm().clamp_min(1e-6 * gscale))
+        assert err < 5e-3, f"{n0}: gradient relative L2 error {err:.2e}"
     for (n0, b0), (n1, b1) in zip(plain.named_buffers(), fused.named_buffers()):
         torch.testing.assert_close(b1.float(), b0.float(), rtol=1e-4, atol=1e-5, msg=n0)
     # with dropout: runs, finite, and about the right fraction of the pre-activations is dropped
