@@ -51,12 +51,17 @@ def main():
     edges = B * N * k
     out = []
 
-    for d in (1, 14, 27):
-        g = DenseDilatedKnnGraph(k, d)
-        avg, mn = timed(lambda: g(x), a.iters)
-        flops = 2.0 * B * N * N * C
-        out.append(dict(op="knn_dense", dilation=d, K=k * d, ms_avg=avg, ms_min=mn,
-                        distance_tflops=flops / (avg * 1e-3) / 1e12, rows_per_s=B * N / (avg * 1e-3)))
+    from deep_gcns_torch_amd import dense_ops
+    for pipe in (True, False):
+        dense_ops.KNN_BF16_PIPE = pipe
+        for d in (1, 7, 14, 27):
+            g = DenseDilatedKnnGraph(k, d)
+            avg, mn = timed(lambda: g(x), a.iters)
+            flops = 2.0 * B * N * N * C
+            out.append(dict(op="knn_dense", distance_pass="bf16x6 matrix pipe" if pipe else "fp32 MFMA", dilation=d, K=k * d,
+                            ms_avg=avg, ms_min=mn, distance_tflops=flops / (avg * 1e-3) / 1e12,
+                            rows_per_s=B * N / (avg * 1e-3)))
+    dense_ops.KNN_BF16_PIPE = True
     ei = DenseDilatedKnnGraph(k, 1)(x)
     conv = EdgeConv2d(C, C, "relu", "batch", True).to(dev).train()
     xg = x.clone().requires_grad_(True)

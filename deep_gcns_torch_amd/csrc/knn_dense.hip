@@ -775,26 +775,49 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
   }
 }
 
-// ---- bf16 planes of the points: every fp32 coordinate split exactly into three bf16 values (csrc/bf16x6.h), written
-// point-major so that an MFMA fragment (8 consecutive channels of one point) is ONE 16-byte load.  Reads are coalesced
-// along the points of a channel row; 6 bytes per coordinate: 12.6 MB for B = 8, N = 4096, C = 64.
+// ---- bf16 planes of the points: every fp32 coordinate split exactly into three bf16 values (csrc/bf16x6.h), stored in
+// the order the MFMA fragments are read: per sample and plane [tile of 16 points][unit = 8 channels][point in tile], 16
+// bytes each -- a wave's fragment load (lane = (point in tile, unit within the 32-channel block)) is then ONE contiguous
+// kilobyte.  A 256-thread block owns 256 / units consecutive points x all units: reads are coalesced along the points
+// of a channel row, writes along the points of a tile; 6 bytes per coordinate (12.6 MB for B = 8, N = 4096, C = 64).
+// The same pass leaves |x_j|^2 (8-channel fma chains, summed over the units in order: deterministic) and resets the
+// redo counter: the filter path needs no other pre-pass.  Points past N (the last tile) repeat point N - 1: never
+// selected (their columns are masked), but finite.
 __global__ __launch_bounds__(256) void knn_planes_kernel(const float* __restrict__ x, int64_t sb, int64_t sc, int B,
-                                                         int C, int N, i4v* __restrict__ planes) {
-  const int64_t pts = static_cast<int64_t>(B) * N;
-  const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (gid >= pts) return;
-  const int b = static_cast<int>(gid / N), i = static_cast<int>(gid % N);
-  const float* xp = x + b * sb + i;
-  const int units = C / 8;
-  for (int u = 0; u < units; ++u) {
+                                                         int C, int N, int Np, i4v* __restrict__ planes,
+                                                         float* __restrict__ sqnorm, int* __restrict__ redo) {
+  __shared__ float part[256];
+  const int units = C / 8;                       // 4 or 8
+  const int ppb = 256 / units;                   // points per block
+  const int blocks_per_sample = (Np + ppb - 1) / ppb;
+  const int b = blockIdx.x / blocks_per_sample;
+  const int p0 = (blockIdx.x % blocks_per_sample) * ppb;
+  const int u = threadIdx.x / ppb, pl = threadIdx.x % ppb;
+  const int pt = p0 + pl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) redo[0] = 0;
+  const int64_t per_sample = static_cast<int64_t>(Np) * units;
+  const int64_t total = per_sample * B;
+  float sq = 0.f;
+  if (pt < Np) {
+    const float* xp = x + b * sb + min(pt, N - 1);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = xp[static_cast<int64_t>(8 * u + e) * sc];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sq = fmaf(v[e], v[e], sq);
     i4v h, m, l;
     eg_split3(f4v{v[0], v[1], v[2], v[3]}, f4v{v[4], v[5], v[6], v[7]}, h, m, l);
-    planes[gid * units + u] = h;
-    planes[(pts + gid) * units + u] = m;
-    planes[(2 * pts + gid) * units + u] = l;
+    const int64_t o = b * per_sample + (static_cast<int64_t>(pt >> 4) * units + u) * 16 + (pt & 15);
+    planes[o] = h;
+    planes[total + o] = m;
+    planes[2 * total + o] = l;
+  }
+  part[threadIdx.x] = sq;
+  __syncthreads();
+  if (threadIdx.x < ppb && pt < N) {
+    float t = 0.f;
+    for (int q = 0; q < units; ++q) t += part[q * ppb + threadIdx.x];
+    sqnorm[static_cast<int64_t>(b) * N + pt] = t;
   }
 }
 
@@ -831,31 +854,25 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
   const int tile = blockIdx.x / P.B;
   const int i0 = tile * TM;
   constexpr int UNITS = 4 * KC;                                     // 16-byte units per point and plane (C = 32 KC)
-  const int64_t pts = static_cast<int64_t>(P.B) * N;
-  const i4v* pb = P.planes + static_cast<int64_t>(b) * N * UNITS;   // plane 0 of this sample; + p * pts * UNITS
+  const int Np = (N + 15) & ~15;                                    // points per sample in the planes (whole tiles)
+  const int64_t plane = static_cast<int64_t>(P.B) * Np * UNITS;     // units per plane
+  const i4v* pb = P.planes + static_cast<int64_t>(b) * Np * UNITS;  // plane 0 of this sample; + p * plane
 
   if (tid < TM) {
     const int64_t row = static_cast<int64_t>(b) * N + min(i0 + tid, N - 1);
     sq[tid] = P.sqnorm[row];
-    tau[tid] = P.tau[row];
     cnt[tid] = 0;
   }
   const int li = lane & 15, lk = lane >> 4;
-  // A fragments: lane (m = li, kq = lk) holds channels 32 kb + 8 lk .. + 7 of query row i0 + li, three planes
-  i4v a[KC][3];
-  {
-    const int64_t qrow = min(i0 + li, N - 1);
-#pragma unroll
-    for (int kb = 0; kb < KC; ++kb) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a[kb][p] = pb[p * pts * UNITS + qrow * UNITS + 4 * kb + lk];
-    }
-  }
-  __syncthreads();
-
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const unsigned long long below = (1ull << lane) - 1ull;
   const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
+  // A fragments: lane (m = li, kq = lk) holds channels 32 kb + 8 lk .. + 7 of query row i0 + li, three planes
+  i4v a[KC][3];
+  // tile layout [tile][unit][point in tile]: lane (li, lk) of k-block kb reads unit 4 kb + lk of point li
+  auto frag = [&](int ctile, int kb, int p) -> i4v {
+    return pb[p * plane + static_cast<int64_t>(ctile) * UNITS * 16 + (4 * kb + lk) * 16 + li];
+  };
   constexpr int kColStride = kFWaves * 64;
   // one step = the three plane fragments of TWO 16-candidate tiles for one 32-channel block: 6 loads, 12 MFMAs that
   // alternate between the two accumulators (no back-to-back dependent MFMAs); the next step's loads are in flight
@@ -863,15 +880,14 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
   auto load_step = [&](int col0, int pair, int kb, i4v (&f)[2][3]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int64_t pt = min(col0 + 16 * (2 * pair + t) + li, N - 1);
+      const int ct = min((col0 >> 4) + 2 * pair + t, (Np >> 4) - 1);      // candidate tile (clamped past the end)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) f[t][p] = pb[p * pts * UNITS + pt * UNITS + 4 * kb + lk];
+      for (int p = 0; p < 3; ++p) f[t][p] = frag(ct, kb, p);
     }
   };
+  constexpr int pa[6] = {0, 0, 1, 0, 2, 1};       // a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2
+  constexpr int pbb[6] = {0, 1, 0, 2, 0, 1};
   auto mfma_step = [&](f32x4 (&acc)[4], int pair, int kb, const i4v (&f)[2][3]) {
-    // a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2
-    constexpr int pa[6] = {0, 0, 1, 0, 2, 1};
-    constexpr int pbb[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
     for (int s6 = 0; s6 < 6; ++s6) {
 #pragma unroll
@@ -880,7 +896,64 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
   };
   constexpr int NSTEP = 2 * KC;
   i4v fA[2][3], fB[2][3];
-  load_step(wave * 64, 0, 0, fA);
+
+  // ---- prologue: ONE memory latency for everything the workgroup needs before its first append -- the query
+  // fragments, the fragments of this wave's two SAMPLE tiles and the first step of the main loop are requested together.
+  // Per-row threshold tau_r = the sample_rank-th smallest of row r's distances to 512 sampled candidates: 32 tiles
+  // spread over the sample (rotated per query tile), two per wave, on the same matrix-pipe path.  (The fp32 kernel
+  // above takes tau from knn_prep_kernel, a separate latency-bound launch of ~43 us; twice the samples also halve the
+  // spread of the candidate count, so the short lists serve K = 224 and fewer rows need the exact pass.)
+  {
+    uint32_t* skeys = ckey;                       // [16][512], aliasing the (still empty) candidate lists
+    const int NT = Np >> 4;
+    const int rot = (tile * 7) % max(NT / 32, 1);
+    int sct[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) sct[t] = static_cast<int>((static_cast<int64_t>(2 * wave + t) * NT / 32 + rot) % NT);
+    i4v sf[KC][2][3];
+#pragma unroll
+    for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[kb][p] = frag(tile, kb, p);
+        sf[kb][0][p] = frag(sct[0], kb, p);
+        sf[kb][1][p] = frag(sct[1], kb, p);
+      }
+    }
+    load_step(wave * 64, 0, 0, fA);
+    float sjv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) sjv[t] = (sct[t] * 16 + li) < N ? sqn[sct[t] * 16 + li] : 0.f;
+    __syncthreads();                              // sq[], cnt[] visible
+    f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) sacc[t] = eg_mfma_bf16(a[kb][pa[s6]], sf[kb][t][pbb[s6]], sacc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool inn = (sct[t] * 16 + li) < N;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = lk * 4 + reg;
+        skeys[r * 512 + (2 * wave + t) * 16 + li] = inn ? key_of((sq[r] + (-2.f * sacc[t][reg])) + sjv[t]) : 0xFFFFFFFFu;
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t ks[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ks[q] = skeys[wave * 512 + q * kWave + lane];
+      const uint32_t tv = kth_smallest<8, 12>(ks, P.sample_rank);     // 12 low mantissa bits of a threshold do not matter
+      if (lane == 0) tau[wave] = tv;
+    }
+    __syncthreads();
+  }
+
   for (int col0 = wave * 64; col0 < N; col0 += kColStride) {
     f32x4 acc[4];
 #pragma unroll
@@ -970,16 +1043,16 @@ size_t knn_prep_lds_bytes(int C) {
   return (static_cast<size_t>(C) * kFTM + kFTM) * 4 + static_cast<size_t>(kFTM) * kFSamples * 4;
 }
 
-// rank of the 256-sample threshold for a list capacity `cap` (see the comment at the call site)
-int knn_sample_rank(int N, int K, int cap) {
-  const double ns = kFSamples, unit = N / ns;
+// rank of the ns-sample threshold for a list capacity `cap` (see the comment at the call site)
+int knn_sample_rank(int N, int K, int cap, int nsamples = kFSamples) {
+  const double ns = nsamples, unit = N / ns;
   const double r0 = K / unit;
   const double sd0 = unit * sqrt(r0 > 1.0 ? r0 : 1.0);
   double target = K + 3.2 * sd0 + 2.0 * unit;
   const double mid = 0.5 * (K + static_cast<double>(cap));
   if (target > mid) target = mid;
   const int r = static_cast<int>(ceil(target / unit));
-  return (r >= 1 && r <= 200) ? r : 0;
+  return (r >= 1 && r <= 200 * nsamples / kFSamples) ? r : 0;
 }
 
 size_t knn_lds_bytes(int TM, int C, int Npad, int Kpad) {
@@ -1004,11 +1077,12 @@ inline size_t knn_ws_head(size_t pts) { return (pts * 12u + 4u + 255u) / 256u * 
 }  // namespace dgcn
 
 extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C) {
-  if (B <= 0 || N <= 0 || C <= 0) return 0;
+  if (B <= 0 || N <= 0 || C < 0) return 0;      // C == 0: the head only (fp32-MFMA filter kernel, no planes)
   // |x_j|^2 (fp32) and the sample threshold (u32) per point, then the redo list: a counter + up to B*N row ids; then the
   // three bf16 planes of the points (6 bytes per coordinate) when the bf16 filter kernel serves this width
   const size_t pts = static_cast<size_t>(B) * static_cast<size_t>(N);
-  return knn_ws_head(pts) + (knn_bf16_kc(C) ? pts * static_cast<size_t>(C) * 6u : 0u);
+  const size_t ppts = static_cast<size_t>(B) * ((static_cast<size_t>(N) + 15u) & ~static_cast<size_t>(15u));
+  return knn_ws_head(pts) + (knn_bf16_kc(C) ? ppts * static_cast<size_t>(C) * 6u : 0u);
 }
 
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
@@ -1058,7 +1132,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   // small lists (two workgroups per CU) when the 3.2-sigma target fits under 512 with margin
   const bool small_lists = K + 3.2 * (N / 256.0) * sqrt(K / (N / 256.0) > 1.0 ? K / (N / 256.0) : 1.0) + 2.0 * (N / 256.0) + 96 <= 512;
   const int cap = small_lists ? 512 : 1024;
-  if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N, C) &&
+  if (vec4 && P.sample_rank > 0 && workspace && workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N, 0) &&
       knn_filter_lds_bytes(C, cap) <= static_cast<size_t>(kLdsBudget)) {
     KnnParams F = P;
     const size_t pts = static_cast<size_t>(B) * N;
@@ -1070,19 +1144,29 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     const size_t plds = knn_prep_lds_bytes(C);
     const int ftiles = (N + kFTM - 1) / kFTM;
     const dim3 fgrid(static_cast<unsigned>(B) * ftiles);
-    if (F.sample_rank > 0 && plds <= static_cast<size_t>(kLdsBudget)) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_prep_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(knn_prep_kernel, fgrid, dim3(kPrepThreads), plds, s, F);
-      const int kc = knn_bf16_kc(C);
+    // the bf16 variant needs the planes behind the head of the workspace; a caller that passes the head only
+    // (dgcn_knn_dense_workspace_bytes(B, N, 0)) gets the fp32-MFMA filter kernel
+    const int kc = workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N, C) ? knn_bf16_kc(C) : 0;
+    int bcap = cap;
+    if (kc) {
+      // 512 samples (unit = N / 512): the candidate count spreads half as much, so the short lists serve larger K
+      const double unit = N / 512.0, r0 = K / unit;
+      const bool small = K + 3.2 * unit * sqrt(r0 > 1.0 ? r0 : 1.0) + 2.0 * unit + 96 <= 512;
+      bcap = small ? 512 : 1024;
+      F.sample_rank = knn_sample_rank(N, K, bcap, 512);
+    }
+    if (F.sample_rank > 0 && (kc || plds <= static_cast<size_t>(kLdsBudget))) {
       if (kc) {
-        // distance pass on the bf16 matrix pipe from pre-split point-major planes
+        // distance pass on the bf16 matrix pipe from pre-split point-major planes; |x_j|^2, the redo-counter reset and
+        // the sample thresholds come from the planes kernel / the filter kernel itself: no prep launch
         i4v* planes = reinterpret_cast<i4v*>(static_cast<char*>(workspace) + knn_ws_head(pts));
-        hipLaunchKernelGGL(knn_planes_kernel, dim3(static_cast<unsigned>((pts + 255) / 256)), dim3(256), 0, s, x, sb, sc,
-                           B, C, N, planes);
+        const int Np = (N + 15) & ~15;
+        const int ppb = 256 / (C / 8);
+        const unsigned pblocks = static_cast<unsigned>(B) * static_cast<unsigned>((Np + ppb - 1) / ppb);
+        hipLaunchKernelGGL(knn_planes_kernel, dim3(pblocks), dim3(256), 0, s, x, sb, sc, B, C, N, Np, planes, F.sqnorm,
+                           F.redo);
         F.planes = planes;
-        const size_t blds = knn_filter_bf16_lds_bytes(cap);
+        const size_t blds = knn_filter_bf16_lds_bytes(bcap);
 #define DGCN_KNNB_LAUNCH(CAP, KCV)                                                                           \
   do {                                                                                                        \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_bf16_kernel<CAP, KCV>),                  \
@@ -1090,13 +1174,17 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     if (e != hipSuccess) return static_cast<int>(e);                                                          \
     hipLaunchKernelGGL((knn_filter_bf16_kernel<CAP, KCV>), fgrid, dim3(kFThreads), blds, s, F);               \
   } while (0)
-        if (cap == 512) {
+        if (bcap == 512) {
           if (kc == 1) DGCN_KNNB_LAUNCH(512, 1); else DGCN_KNNB_LAUNCH(512, 2);
         } else {
           if (kc == 1) DGCN_KNNB_LAUNCH(1024, 1); else DGCN_KNNB_LAUNCH(1024, 2);
         }
 #undef DGCN_KNNB_LAUNCH
       } else {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_prep_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
+      if (e != hipSuccess) return static_cast<int>(e);
+      hipLaunchKernelGGL(knn_prep_kernel, fgrid, dim3(kPrepThreads), plds, s, F);
       // chunk = 4*KS channels, two chunks per column block: KS sized so that C fills both
       const int ks = C > 16 ? 4 : 2;   // (KS = 8 double-buffered needs > 128 VGPRs: spills)
 #define DGCN_KNNF_LAUNCH(CAP, KSV)                                                                           \

@@ -17,6 +17,7 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 USE_INVERSE_LISTS = True      # dense edge backward: dQ through inverse neighbour lists (False: LDS-privatised atomics)
 USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fallback inside the library)
+KNN_BF16_PIPE = True    # distance tiles of the filter pass on the bf16 matrix pipe (C in {32, 64}); False: fp32 MFMA (A/B)
 
 
 # ----------------------------------------------------------------------------------------
@@ -36,7 +37,7 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
         raise ValueError(f"k*dilation = {K} neighbours asked of clouds with {N} points")
     if N > KNN_MAX_POINTS or K > KNN_MAX_NEIGHBOURS:
         return _knn_beyond_kernel_limits(x3, K, dilation, nn_out, ctr_out, exclude_self)
-    ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N, C) if (N >= 1024 and USE_KNN_FILTER) else 0
+    ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N, C if KNN_BF16_PIPE else 0) if (N >= 1024 and USE_KNN_FILTER) else 0
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     with _lib.device_ctx(dev):
         rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,

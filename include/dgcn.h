@@ -296,7 +296,8 @@ int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edge
  *            inner products on the bf16 matrix pipe from exact three-way bf16 splits (six products, fp32-faithful:
  *            csrc/bf16x6.h) instead of the channel-ordered fma chain: the same distances up to fp32 rounding, so two
  *            candidates closer than that may be ranked either way (as on any other fp32 evaluation of the reference's
- *            formula); every row is ranked by one evaluation only.  Other widths: identical results either way.
+ *            formula); every row is ranked by one evaluation only.  Other widths, or a workspace sized with C = 0
+ *            (no room for the bf16 planes): the fp32-MFMA chain, identical results either way.
  * Limits: N <= 4096, K <= 1024 (the candidate-filter fast path serves K <= 512), K <= N. */
 size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C);
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,

@@ -258,10 +258,14 @@ def test_deepergcn_fused_layers_equal_the_plain_model():
     # nine stacked layers, each re-normalised by a training-mode BatchNorm: the two loops differ by fp32 rounding per
     # layer (residual added in the GEMM epilogue, statistics summed in another order) and a pre-activation within
     # rounding of 0 may cross the ReLU: gate every parameter gradient by its relative L2 error
+    # (the Linear biases add a per-channel constant to h, which every following training-mode BatchNorm removes: their
+    # true gradient is 0 and what comes out is rounding noise -- the error is measured against the model-wide gradient
+    # scale, not against that noise)
     gscale = max(float(p.grad.abs().max()) for p in plain.parameters())
     for (n0, p0), (n1, p1) in zip(plain.named_parameters(), fused.named_parameters()):
         assert n0 == n1
-        err = float((p1.grad - p0.grad).double().norm() / p0.grad.double().norm().clamp_min(1e-6 * gscale))
+        floor = 1e-3 * gscale * p0.numel() ** 0.5
+        err = float((p1.grad - p0.grad).double().norm() / max(float(p0.grad.double().norm()), floor))
         assert err < 5e-3, f"{n0}: gradient relative L2 error {err:.2e}"
     for (n0, b0), (n1, b1) in zip(plain.named_buffers(), fused.named_buffers()):
         torch.testing.assert_close(b1.float(), b0.float(), rtol=1e-4, atol=1e-5, msg=n0)
