@@ -382,8 +382,10 @@ def rows_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return x.size(1) == K and bool(_lib.load().dgcn_rows_linear_supported(K, C))
 
 
-def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum):
-    """y = x @ (w^T | w) + bias + res on the matrix pipe; returns (y, stats or None, xsum partials or None)."""
+def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum, out=None):
+    """y = x @ (w^T | w) + bias + res on the matrix pipe; returns (y, stats or None, xsum partials or None).
+    ``out``: write the result there (contiguous fp32 (rows, C)); ``out is res`` accumulates in place -- every element is
+    read (one 16-row batch ahead) and written by the same wave, rows of different waves are disjoint."""
     lib = _lib.load()
     dev = x.device
     if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
@@ -394,14 +396,19 @@ def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum):
         w = w.contiguous()
     if res is not None and (res.stride(1) != 1 or res.dtype != torch.float32):
         res = res.float().contiguous()
-    y = torch.empty(rows, C, device=dev, dtype=torch.float32)
+    if out is None:
+        y = torch.empty(rows, C, device=dev, dtype=torch.float32)
+    else:
+        if out.shape != (rows, C) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError("rows_linear: out must be fp32 (rows, C) with unit column stride")
+        y = out
     nparts = lib.dgcn_rows_linear_num_partials(rows, K, C)
     stats = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32) if want_stats else None
     xsum = torch.empty(nparts, K, device=dev, dtype=torch.float32) if want_xsum else None
     with _lib.device_ctx(dev):
         _lib.check(lib.dgcn_rows_linear_f32(x.data_ptr(), x.stride(0), rows, w.data_ptr(), w.stride(0), 1 if w_trans else 0,
                                             _lib.ptr(bias), _lib.ptr(res), res.stride(0) if res is not None else 0,
-                                            y.data_ptr(), C, K, C, 1 if relu else 0, _lib.ptr(stats), _lib.ptr(xsum),
+                                            y.data_ptr(), y.stride(0), K, C, 1 if relu else 0, _lib.ptr(stats), _lib.ptr(xsum),
                                             _lib.current_stream_handle(dev)), "dgcn_rows_linear_f32")
     return y, stats, xsum
 
@@ -444,6 +451,24 @@ class _RowsLinear(torch.autograd.Function):
             gb = g.sum(0)
         gres = g if ctx.needs_input_grad[3] else None
         return gx, gw, gb, gres, None
+
+
+def rows_matmul_accumulate_(acc: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``acc += x @ w`` in place for (rows, K) x (K, C) with rows >> K, C (no autograd): the running sum of the shared
+    edge-embedding gradient in the reversible backward (``dz @ W`` of every layer, ops._GenAggregate.backward)."""
+    if (x.is_cuda and x.dtype == torch.float32 and acc.dtype == torch.float32 and w.dtype == torch.float32
+            and x.size(0) >= ROWS_LINEAR_MIN_ROWS and _lib.load().dgcn_rows_linear_supported(x.size(1), w.size(1))):
+        _rl_launch(x, w, True, None, acc, False, False, False, out=acc)
+        return acc
+    return torch.addmm(acc, x, w, out=acc)
+
+
+def rows_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``x @ w`` for (rows, K) x (K, C) with rows >> K, C (no autograd)."""
+    if (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.size(0) >= ROWS_LINEAR_MIN_ROWS
+            and _lib.load().dgcn_rows_linear_supported(x.size(1), w.size(1))):
+        return _rl_launch(x, w, True, None, None, False, False, False)[0]
+    return x @ w
 
 
 def rows_linear(x, weight, bias=None, residual=None, want_stats: bool = False):

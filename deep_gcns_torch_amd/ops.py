@@ -301,10 +301,11 @@ class _GenAggregate(torch.autograd.Function):
                 if dz is not None:
                     if ctx.needs_input_grad[14]:
                         sink = ctx.grad_sink
+                        from . import node_ops
                         if sink is not None:
-                            torch.addmm(sink, dz, w_enc, out=sink)       # running sum owned by the caller
+                            node_ops.rows_matmul_accumulate_(sink, dz, w_enc)   # running sum owned by the caller
                         else:
-                            grad_feat = dz @ w_enc
+                            grad_feat = node_ops.rows_matmul(dz, w_enc)
                     if ctx.needs_input_grad[15]:
                         grad_w = _splitk_tn(dz, feat)
                     if b_enc is not None and ctx.needs_input_grad[16]:
