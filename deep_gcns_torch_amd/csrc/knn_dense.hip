@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kKnnThreads = 512;
 constexpr int kKnnWaves = kKnnThreads / kWave;  // 8
-constexpr int kMaxPerLane = 64;                 // keys per lane in the select phase -> N <= 4096*... see TM
+constexpr int kMaxPerLane = 64;                 // N <= 64 * 64 = 4096 points per cloud
 constexpr int kLdsBudget = 160 * 1024 - 1024;
 
 struct KnnParams {
@@ -206,17 +206,19 @@ __device__ __forceinline__ void select_from_candidates(const uint32_t* ckey, con
   compact_winners<R>(ck, ci, (cnt + kWave - 1) / kWave, tau, need_eq, skey, sidx, lane);
 }
 
-// Phases 2-5 for one query row, executed by one wave (inlined: a call would spill the 64 live keys).
+// Phases 2-5 for one query row, executed by ONE wave holding SLOTS keys per lane (N <= 64 SLOTS).  Serves clouds of up to
+// 2048 points (SLOTS = 16 / 32: register-resident without spills); larger rows take select_rows_coop below.
+template <int SLOTS>
 __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint32_t* skey, int b, int i) {
   const int lane = lane_id();
   const int N = P.N, K = P.K;
   uint32_t* sidx = reinterpret_cast<uint32_t*>(drow);  // in-place compaction target (position <= index)
 
   // keys of this lane: element j = s*64 + lane
-  uint32_t key[kMaxPerLane];
-  const int slots = (N + kWave - 1) / kWave;  // <= 64
+  uint32_t key[SLOTS];
+  const int slots = (N + kWave - 1) / kWave;  // <= SLOTS
 #pragma unroll
-  for (int s = 0; s < kMaxPerLane; ++s) {
+  for (int s = 0; s < SLOTS; ++s) {
     const int j = s * kWave + lane;
     key[s] = (s < slots && j < N && !(P.exclude_self && j == i)) ? key_of(drow[j]) : 0xFFFFFFFFu;
   }
@@ -234,11 +236,11 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
     for (int i = 0; i < 4; ++i) {
       uint32_t v = 0xFFFFFFFFu;
 #pragma unroll
-      for (int s = 0; s < kMaxPerLane; ++s) v = (s == i * st) ? key[s] : v;   // key[] stays in registers
+      for (int s = 0; s < SLOTS; ++s) v = (s == i * st) ? key[s] : v;   // key[] stays in registers
       ks[i] = v;
     }
     const uint32_t ts = kth_smallest<4>(ks, P.sample_rank);
-    const int cnt = count_below<kMaxPerLane>(key, ts, true);
+    const int cnt = count_below<SLOTS>(key, ts, true);
     const int cap = min(16 * kWave, (N / 2) & ~3);
     if (cnt >= K && cnt <= cap) {
       uint32_t* cidx = reinterpret_cast<uint32_t*>(drow);          // the row is dead: its keys are in registers
@@ -246,7 +248,7 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
       int n_c = 0;
       const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-      for (int s = 0; s < kMaxPerLane; ++s) {
+      for (int s = 0; s < SLOTS; ++s) {
         if (s < slots) {
           const bool in = key[s] <= ts;
           const unsigned long long m = __ballot(in);
@@ -269,12 +271,12 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
   }
   if (!done) {
     // exact full-row path
-    const uint32_t tau = kth_smallest<kMaxPerLane>(key, K);
-    const int need_eq = K - count_below<kMaxPerLane>(key, tau, false);  // >= 1 ties at the threshold
-    uint32_t id[kMaxPerLane];
+    const uint32_t tau = kth_smallest<SLOTS>(key, K);
+    const int need_eq = K - count_below<SLOTS>(key, tau, false);  // >= 1 ties at the threshold
+    uint32_t id[SLOTS];
 #pragma unroll
-    for (int s = 0; s < kMaxPerLane; ++s) id[s] = static_cast<uint32_t>(s * kWave + lane);
-    compact_winners<kMaxPerLane>(key, id, slots, tau, need_eq, skey, sidx, lane);
+    for (int s = 0; s < SLOTS; ++s) id[s] = static_cast<uint32_t>(s * kWave + lane);
+    compact_winners<SLOTS>(key, id, slots, tau, need_eq, skey, sidx, lane);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -288,9 +290,96 @@ __device__ __forceinline__ void select_row(const KnnParams& P, float* drow, uint
   else sort_and_emit<16>(P, skey, sidx, lane, K, out_base, i);     // deeper stacks than ResGCN-28 (k * d up to 1024)
 }
 
+// ---- cooperative select: all eight waves of the workgroup work on ONE row (N up to 4096: 8 keys per thread) ---------
+// The wave-per-row form needs 64 keys per lane at N = 4096 (256 VGPRs + spills); here a thread holds element
+// j = s * 512 + tid, s < 8, and the 32-step bisection counts across the workgroup: per step one DPP wave sum, one LDS
+// atomic per wave and one barrier (three rotating counters: a slot is cleared two steps before it is used again).
+// Winners are compacted in ANY order (the sort that follows orders them by (key, id)); among keys equal to the
+// threshold the lowest point ids are taken, found by a 12-bit bisection on the id only when the tie is real.
+constexpr int kCoopSlots = 8;
+
+struct CoopCtx {
+  int* cnt3;      // LDS int[4]: three rotating counters + the append cursor
+  int phase;
+};
+
+__device__ __forceinline__ int coop_total(CoopCtx& c, int lane_count) {
+  const int w = wave_sum(lane_count);
+  if (lane_id() == 0 && w) atomicAdd(&c.cnt3[c.phase], w);
+  __syncthreads();
+  const int total = c.cnt3[c.phase];
+  if (threadIdx.x == 0) c.cnt3[(c.phase + 2) % 3] = 0;
+  c.phase = (c.phase + 1) % 3;
+  return total;
+}
+
+__device__ __forceinline__ void select_row_coop(const KnnParams& P, float* drow, uint32_t* skey, int i, CoopCtx& c) {
+  const int N = P.N, K = P.K;
+  const int tid = threadIdx.x, lane = lane_id();
+  uint32_t key[kCoopSlots];
+#pragma unroll
+  for (int s = 0; s < kCoopSlots; ++s) {
+    const int j = s * kKnnThreads + tid;
+    key[s] = (j < N && !(P.exclude_self && j == i)) ? key_of(drow[j]) : 0xFFFFFFFFu;
+  }
+  uint32_t tau = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = tau | (1u << bit);
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < kCoopSlots; ++s) n += (key[s] < cand) ? 1 : 0;
+    if (coop_total(c, n) < K) tau = cand;
+  }
+  int n_lt = 0, n_eq = 0;
+#pragma unroll
+  for (int s = 0; s < kCoopSlots; ++s) { n_lt += (key[s] < tau) ? 1 : 0; n_eq += (key[s] == tau) ? 1 : 0; }
+  const int need_eq = K - coop_total(c, n_lt);
+  const int have_eq = coop_total(c, n_eq);
+  uint32_t id_thr = 0xFFFFFFFFu;          // ids <= id_thr among the keys equal to tau are taken
+  if (have_eq != need_eq) {               // block-uniform
+    id_thr = 0;
+#pragma unroll 1
+    for (int bit = 12; bit >= 0; --bit) {
+      const uint32_t cand = id_thr | (1u << bit);
+      int n = 0;
+#pragma unroll
+      for (int s = 0; s < kCoopSlots; ++s) n += (key[s] == tau && static_cast<uint32_t>(s * kKnnThreads + tid) < cand) ? 1 : 0;
+      if (coop_total(c, n) < need_eq) id_thr = cand;
+    }
+  }
+  // unordered compaction: the row's distances are dead (every key is in a register and a barrier has passed), so the
+  // ids go to the front of the row itself
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(drow);
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int s = 0; s < kCoopSlots; ++s) {
+    const uint32_t j = static_cast<uint32_t>(s * kKnnThreads + tid);
+    const bool take = key[s] < tau || (key[s] == tau && j <= id_thr);
+    const unsigned long long m = __ballot(take);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&c.cnt3[3], __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (take) {
+      const int pos = base + __popcll(m & below);
+      skey[pos] = key[s];
+      sidx[pos] = j;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) c.cnt3[3] = 0;            // cursor for the next row (its first append is many barriers away)
+}
+
+template <int R>
+__device__ __forceinline__ void emit_sorted(const KnnParams& P, const float* drow, const uint32_t* skey, int b, int i) {
+  const int64_t out_base = (static_cast<int64_t>(b) * P.N + i) * P.Kout;
+  sort_and_emit<R>(P, skey, reinterpret_cast<const uint32_t*>(drow), lane_id(), P.K, out_base, i);
+}
+
 // LDS layout (dynamic): q[C][TM] | sq[TM] | dist[TM][Npad] | selkey[TM][Kpad]
 // (the winners' indices are compacted IN PLACE at the front of each dist row: position <= index)
-template <int TM, bool VEC4>
+// SLOTS: keys per lane of the wave-per-row select (16: N <= 1024, 32: N <= 2048); 0: the cooperative select (N <= 4096)
+template <int TM, bool VEC4, int SLOTS>
 __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams P, int Npad, int Kpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int C = P.C, N = P.N;
@@ -350,7 +439,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
       }
       // software pipeline: the next CH channels are in flight while the current CH are consumed
       // (only 2 waves per SIMD are resident, so latency must be hidden by ILP, not by occupancy)
-      constexpr int CH = 8;
+      constexpr int CH = TM >= 8 ? 4 : 8;      // eight rows: 32 accumulators, so half the loads in flight (no spills)
       float4 nxt[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
@@ -437,11 +526,36 @@ __global__ __launch_bounds__(kKnnThreads) void knn_dense_kernel(const KnnParams 
   }
   __syncthreads();
 
-  // ---- phases 2-5: one wave per query row ----
-  for (int r = wave; r < TM; r += kKnnWaves) {
-    const int i = i0 + r;
-    if (i >= N) continue;  // wave-uniform
-    select_row(P, dist + static_cast<size_t>(r) * Npad, selkey + static_cast<size_t>(r) * Kpad, b, i);
+  if constexpr (SLOTS > 0) {
+    // ---- phases 2-5: one wave per query row ----
+    for (int r = wave; r < TM; r += kKnnWaves) {
+      const int i = i0 + r;
+      if (i >= N) continue;  // wave-uniform
+      select_row<SLOTS>(P, dist + static_cast<size_t>(r) * Npad, selkey + static_cast<size_t>(r) * Kpad, b, i);
+    }
+  } else {
+    // ---- phases 2-3 with the whole workgroup per row, then phases 4-5 one wave per row ----
+    __shared__ int coop_cnt[4];
+    if (tid < 4) coop_cnt[tid] = 0;
+    __syncthreads();
+    CoopCtx cc{coop_cnt, 0};
+    for (int r = 0; r < TM; ++r) {
+      if (i0 + r >= N) break;  // block-uniform
+      select_row_coop(P, dist + static_cast<size_t>(r) * Npad, selkey + static_cast<size_t>(r) * Kpad, i0 + r, cc);
+    }
+    __syncthreads();
+    for (int r = wave; r < TM; r += kKnnWaves) {
+      const int i = i0 + r;
+      if (i >= N) continue;
+      const float* dr = dist + static_cast<size_t>(r) * Npad;
+      const uint32_t* sk = selkey + static_cast<size_t>(r) * Kpad;
+      const int K = P.K;
+      if (K <= 64) emit_sorted<1>(P, dr, sk, b, i);
+      else if (K <= 128) emit_sorted<2>(P, dr, sk, b, i);
+      else if (K <= 256) emit_sorted<4>(P, dr, sk, b, i);
+      else if (K <= 512) emit_sorted<8>(P, dr, sk, b, i);
+      else emit_sorted<16>(P, dr, sk, b, i);
+    }
   }
   }  // tiles
 }
@@ -1210,12 +1324,19 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
       grid = dim3(kRedoGrid);
     }
   }
-#define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \
+#define DGCN_KNN_LAUNCH_S(TMV, V4, SL)                                                                     \
   do {                                                                                                      \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<TMV, V4>),                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_dense_kernel<TMV, V4, SL>),                   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));             \
     if (e != hipSuccess) return static_cast<int>(e);                                                        \
-    hipLaunchKernelGGL((knn_dense_kernel<TMV, V4>), grid, block, lds, s, P, Npad, Kpad);                    \
+    hipLaunchKernelGGL((knn_dense_kernel<TMV, V4, SL>), grid, block, lds, s, P, Npad, Kpad);                \
+  } while (0)
+  // keys per lane of the wave-per-row select, or the cooperative select for the big clouds
+#define DGCN_KNN_LAUNCH(TMV, V4)                                                                           \
+  do {                                                                                                      \
+    if (N <= 16 * kWave) DGCN_KNN_LAUNCH_S(TMV, V4, 16);                                                    \
+    else if (N <= 32 * kWave) DGCN_KNN_LAUNCH_S(TMV, V4, 32);                                               \
+    else DGCN_KNN_LAUNCH_S(TMV, V4, 0);                                                                     \
   } while (0)
   switch (TM) {
     case 8: if (vec4) DGCN_KNN_LAUNCH(8, true); else DGCN_KNN_LAUNCH(8, false); break;
@@ -1224,5 +1345,6 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     default: if (vec4) DGCN_KNN_LAUNCH(1, true); else DGCN_KNN_LAUNCH(1, false); break;
   }
 #undef DGCN_KNN_LAUNCH
+#undef DGCN_KNN_LAUNCH_S
   return launch_status();
 }
