@@ -50,7 +50,8 @@ def main():
         print(json.dumps(kw), flush=True)
 
     # ---- the GEMM alone ------------------------------------------------------------------------------------------
-    for rows, K, C in () if args.only else ((169343, 128, 128), (244902, 128, 128), (13253, 112, 224), (13253, 224, 112), (2449029, 128, 128)):
+    for rows, K, C in () if args.only else ((169343, 128, 128), (244902, 128, 128), (13253, 112, 224), (13253, 224, 112),
+                                            (791225, 224, 112), (2449029, 128, 128)):
         x = torch.randn(rows, K, device=dev)
         w = torch.randn(C, K, device=dev) / K ** 0.5
         b = torch.randn(C, device=dev)
@@ -64,9 +65,14 @@ def main():
             t_k_res_st = timed(lambda: node_ops.rows_linear(x, w, b, r, want_stats=True), args.iters)
             t_dx_lib = timed(lambda: g @ w, args.iters)
             t_dx_k = timed(lambda: node_ops._rl_launch(g, w, True, None, None, False, False, C <= 128), args.iters)
+            t_dw_k = timed(lambda: node_ops.rows_tn(g, x), args.iters)
+            node_ops.ROWS_TN_KERNEL = False
+            t_dw_lib = timed(lambda: node_ops.rows_tn(g, x), args.iters)
+            node_ops.ROWS_TN_KERNEL = True
         byt = rows * (K + 2 * C) * 4
         emit(what="rows_linear", rows=rows, K=K, C=C, lib_ms=t_lib, lib_plus_residual_ms=t_lib_res, kernel_ms=t_k,
              kernel_residual_ms=t_k_res, kernel_residual_stats_ms=t_k_res_st, dx_lib_ms=t_dx_lib, dx_kernel_with_bias_grad_ms=t_dx_k,
+             dw_lib_splitk_ms=t_dw_lib, dw_kernel_ms=t_dw_k,
              kernel_residual_GBs=byt / (t_k_res * 1e-3) / 1e9, kernel_TF=2.0 * rows * K * C / (t_k * 1e-3) / 1e12)
         del x, r, g
 

@@ -46,7 +46,8 @@ class _TallLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g @ weight
         if ctx.needs_input_grad[1]:
-            gw = splitk_xt_g(g2.contiguous(), x.reshape(-1, x.size(-1)).contiguous())
+            from . import node_ops
+            gw = node_ops.rows_tn(g2, x.reshape(-1, x.size(-1)))     # matrix-pipe kernel, or the split-K library form
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb

@@ -446,7 +446,7 @@ class _RowsLinear(torch.autograd.Function):
             else:
                 gx = g @ weight
         if ctx.needs_input_grad[1]:
-            gw = splitk_xt_g(g.contiguous(), x.contiguous())
+            gw = rows_tn(g, x)
         if need_b and gb is None:
             gb = g.sum(0)
         gres = g if ctx.needs_input_grad[3] else None
@@ -469,6 +469,34 @@ def rows_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
             and _lib.load().dgcn_rows_linear_supported(x.size(1), w.size(1))):
         return _rl_launch(x, w, True, None, None, False, False, False)[0]
     return x @ w
+
+
+ROWS_TN_KERNEL = True      # False: library split-K GEMM for the weight gradients (A/B measurements)
+
+
+def rows_tn(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``g.T @ x`` for (rows, C), (rows, K) with rows >> C, K: the weight gradient of a row-wise Linear (no autograd).
+    csrc/rows_tn.hip on device rows (C <= 128, K <= 256, both multiples of 4, unit column strides, 16-byte aligned rows);
+    anything else: the split-K library GEMM."""
+    from .nn_util import splitk_xt_g
+    C, K = g.size(1), x.size(1)
+    if not (ROWS_TN_KERNEL and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2
+            and x.dim() == 2 and g.size(0) == x.size(0) and g.size(0) >= ROWS_LINEAR_MIN_ROWS and g.stride(1) == 1
+            and x.stride(1) == 1 and max(g.stride(0), x.stride(0)) < (1 << 22)
+            and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and _lib.load().dgcn_rows_tn_supported(C, K)):
+        return splitk_xt_g(g.contiguous(), x.contiguous())
+    lib = _lib.load()
+    dev = g.device
+    rows = g.size(0)
+    nparts = lib.dgcn_rows_tn_num_partials(rows, C, K)
+    parts = torch.empty(nparts, C, K, device=dev, dtype=torch.float32)
+    out = torch.empty(C, K, device=dev, dtype=torch.float32)
+    with _lib.device_ctx(dev):
+        stream = _lib.current_stream_handle(dev)
+        _lib.check(lib.dgcn_rows_tn_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), rows, C, K,
+                                        parts.data_ptr(), out.data_ptr(), K, stream), "dgcn_rows_tn_f32")
+    return out
 
 
 def rows_linear(x, weight, bias=None, residual=None, want_stats: bool = False):

@@ -65,22 +65,6 @@ def _feat_rows(f: torch.Tensor) -> torch.Tensor:
     return f
 
 
-def _splitk_tn(g2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """g2^T @ x2 for (R, M), (R, K) with R >> M, K as a batched split-K product + fixed-order sum (the un-split
-    GEMM runs on a handful of CUs); row-strided operands are used in place (no (R, K) copy)."""
-    R = g2.size(0)
-    S = 1
-    while S < 128 and R // (S * 2) >= 256:
-        S *= 2
-    if S == 1:
-        return g2.t() @ x2
-    Rp = (R // S) * S
-    part = torch.bmm(g2[:Rp].unflatten(0, (S, Rp // S)).transpose(1, 2), x2[:Rp].unflatten(0, (S, Rp // S))).sum(0)
-    if Rp != R:
-        part = part + g2[Rp:].t() @ x2[Rp:]
-    return part
-
-
 # ---- in-place accumulation of edge-feature gradients ------------------------------------------------------------------
 # The reference's deep models hand ONE (E, hidden) edge embedding to every layer (ogbn_proteins/model.py:116-127,
 # ogb_eff/ogbn_proteins/model_rev.py:98-107); autograd then materialises an (E, hidden) gradient per layer and adds
@@ -307,7 +291,8 @@ class _GenAggregate(torch.autograd.Function):
                         else:
                             grad_feat = node_ops.rows_matmul(dz, w_enc)
                     if ctx.needs_input_grad[15]:
-                        grad_w = _splitk_tn(dz, feat)
+                        from . import node_ops
+                        grad_w = node_ops.rows_tn(dz, feat)        # dz^T F on the matrix pipe (strided feature view in place)
                     if b_enc is not None and ctx.needs_input_grad[16]:
                         # sum_e dz_e = sum_s grad_x[s] (every edge lands in exactly one source row): an (N, C)
                         # reduction instead of an (E, C) one; the fused root term adds g to every row

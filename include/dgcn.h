@@ -520,6 +520,19 @@ int dgcn_rows_linear_f32(const float* x, int64_t ldx, int64_t rows, const float*
                          const float* bias, const float* res, int64_t ldr, float* y, int64_t ldy, int32_t K, int32_t C,
                          int32_t relu, float* col_stats, float* xcol_sum, void* stream);
 
+/* Weight gradient of a row-wise Linear:  dW[c][k] = sum_r g[r][c] * x[r][k]  (g^T x; csrc/rows_tn.hip), fp32-faithful on
+ * the bf16 matrix pipe.  Replaces the backward GEMMs with a 10^5 .. 10^6-long reduction: the gradient of
+ * edge_encoder.weight (dz^T F; gcn_lib/sparse/torch_vertex.py:63-66 under eff_gcn_modules/rev/gcn_revop.py:121-133) and
+ * of the MLP Linear weights (gcn_lib/sparse/torch_nn.py:50-71).
+ *   g (rows, C) row stride ldg, x (rows, K) row stride ldx; 1 <= C <= 128, 1 <= K <= 256
+ *   partials [dgcn_rows_tn_num_partials(rows, C, K)][C][K]: scratch, one partial per workgroup
+ *   out (C, K) row stride ldo >= K: the sum of the partials in a fixed order (a second launch on the same stream): the
+ *   result is deterministic.  Row strides are limited to 2^31 / 128 bytes (DGCN_E_SHAPE beyond). */
+int32_t dgcn_rows_tn_supported(int32_t C, int32_t K);
+int32_t dgcn_rows_tn_num_partials(int64_t rows, int32_t C, int32_t K);
+int dgcn_rows_tn_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C, int32_t K,
+                     float* partials, float* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

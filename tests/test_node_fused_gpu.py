@@ -62,6 +62,57 @@ def test_rows_linear_forward_backward(rows, K, C, with_res):
     torch.testing.assert_close(tot[1], (yr.detach() ** 2).sum(0), rtol=2e-5, atol=1e-6 * nat * nat * rows)
 
 
+@pytest.mark.parametrize("rows,C,K,strided", [(5000, 128, 128, False), (100_003, 112, 224, True), (3001, 64, 64, False),
+                                              (2500, 100, 40, False), (4100, 112, 224, False), (2049, 20, 132, False), (3000, 47, 128, False),
+                                              (2111, 128, 256, False),
+                                              (169343, 128, 128, False)])
+def test_rows_tn_weight_gradient(rows, C, K, strided):
+    """g^T x on the matrix pipe (csrc/rows_tn.hip) against float64: the weight gradient of the row-wise Linear layers and
+    of the fused edge encoder (x = the strided per-group view of the (E, 2 hidden) embedding)."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(rows + C + K)
+    g = torch.randn(rows, C, generator=gen)
+    xf = torch.randn(rows, 2 * K if strided else K, generator=gen)
+    x = xf[:, K:] if strided else xf
+    ref = g.double().t() @ x.double()
+    xd = xf.to(dev)
+    out = node_ops.rows_tn(g.to(dev), xd[:, K:] if strided else xd)
+    nat = float((g.double().abs().t() @ x.double().abs()).max())
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-6 * nat)
+    node_ops.ROWS_TN_KERNEL = False
+    try:
+        lib_out = node_ops.rows_tn(g.to(dev), xd[:, K:] if strided else xd)
+    finally:
+        node_ops.ROWS_TN_KERNEL = True
+    torch.testing.assert_close(out, lib_out, rtol=1e-4, atol=1e-5 * nat)
+
+
+@pytest.mark.parametrize("rows", [7, 32, 40, 65, 8 * 32 * 3 + 31])
+def test_rows_tn_short_row_counts_through_the_abi(rows):
+    """Whole steps, the zero-filled remainder step and workgroup ranges of dgcn_rows_tn_f32 at row counts the host wrapper
+    hands to the library."""
+    from deep_gcns_torch_amd import _lib
+    dev = _dev()
+    C, K = 112, 224
+    gen = torch.Generator().manual_seed(rows)
+    g = torch.randn(rows, C, generator=gen)
+    x = torch.randn(rows, K, generator=gen)
+    gd, xd = g.to(dev), x.to(dev)
+    lib = _lib.load()
+    nparts = lib.dgcn_rows_tn_num_partials(rows, C, K)
+    assert nparts >= 1
+    parts = torch.empty(nparts, C, K, device=dev)
+    out = torch.full((C, K + 4), 7.0, device=dev)            # row stride K + 4: the padding stays untouched
+    with _lib.device_ctx(dev):
+        _lib.check(lib.dgcn_rows_tn_f32(gd.data_ptr(), C, xd.data_ptr(), K, rows, C, K, parts.data_ptr(), out.data_ptr(),
+                                        K + 4, _lib.current_stream_handle(dev)), "dgcn_rows_tn_f32")
+    ref = g.double().t() @ x.double()
+    nat = float((g.double().abs().t() @ x.double().abs()).max())
+    torch.testing.assert_close(out[:, :K].cpu().double(), ref, rtol=1e-5, atol=2e-6 * nat)
+    assert bool((out[:, K:] == 7.0).all())
+
+
 def test_rows_linear_strided_input_and_no_bias():
     from deep_gcns_torch_amd import node_ops
     dev = _dev()
