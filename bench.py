@@ -155,6 +155,7 @@ def extras(dev):
     deep_gcns_torch_amd.install()
     import arch_restated
     import rev_restated
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
     from deep_gcns_torch_amd import ops, synth
     from deep_gcns_torch_amd.graph import Graph
     from gcn_lib.dense import DenseDilatedKnnGraph, EdgeConv2d, ResDynBlock2d
@@ -188,6 +189,7 @@ def extras(dev):
     ya = torch.randint(0, 40, (s["n"],), device=dev)
     d28 = {}
     for name, kw in (("reference_loop", dict()), ("res_plus_layer", dict(fused_layers=True)),
+                     ("res_plus_layer_full_recompute", dict(fused_layers=True, checkpoint="reference_full")),
                      ("res_plus_layer_no_checkpoint", dict(fused_layers=True, checkpoint="never"))):
         m = arch_restated.DeeperGCN(num_layers=28, in_channels=128, hidden=128, num_tasks=40, dropout=0.5, **kw).to(dev).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
@@ -202,8 +204,10 @@ def extras(dev):
         workload="DeeperGCN-28 GENConv softmax_sg 'res+' (ogbn_arxiv/model.py; BatchNorm, dropout 0.5 as the reference's "
                  "defaults -- round 2 timed the loop WITHOUT dropout), full graph, fwd+bwd+Adam.  reference_loop = the model "
                  "file's layer loop on this gcn_lib; res_plus_layer = the loop body through deep_gcns_torch_amd.blocks "
-                 "(INTEGRATION.md); *_no_checkpoint = the same without the reference's gradient checkpointing (nothing of "
-                 "size (E, C) exists here: 2 x (N, C) per layer instead)",
+                 "(INTEGRATION.md) with the reference's checkpointing, the recomputation re-running the node-wise part and "
+                 "taking the aggregation's (N, C) outputs from the first pass; *_full_recompute = the recomputation runs the "
+                 "aggregation again too (what torch.utils.checkpoint around GENConv does); *_no_checkpoint = no "
+                 "checkpointing (nothing of size (E, C) exists here: a layer keeps (N, C) arrays only)",
         ms_per_step=d28["res_plus_layer"], ms_per_step_variants=d28,
         edges_per_s=ei.size(1) * 28 / (d28["res_plus_layer"] * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
     del g, x, go
@@ -218,6 +222,7 @@ def extras(dev):
     yc = torch.randint(0, 47, (n_c,), device=dev)
     d14 = {}
     for name, kw in (("reference_loop", dict()), ("res_plus_layer", dict(fused_layers=True)),
+                     ("res_plus_layer_full_recompute", dict(fused_layers=True, checkpoint="reference_full")),
                      ("res_plus_layer_no_checkpoint", dict(fused_layers=True, checkpoint="never"))):
         m = arch_restated.DeeperGCN(num_layers=14, in_channels=100, hidden=128, num_tasks=47, dropout=0.5, **kw).to(dev).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
@@ -315,13 +320,15 @@ def extras(dev):
     rev = {}
     for name, layers, impl, fused, aggr in (
             ("revgcn112_product", 112, "product", True, "max"), ("revgcn8_product", 8, "product", True, "max"),
+            ("revgcn8_product_pure_recompute", 8, "product_pure", True, "max"),
             ("revgcn8_reference_algorithm_stock_gemm", 8, "restated", False, "max"),
             # BASELINE.json words config 5 with power-mean aggregation (the reference's commands use max): both
             ("revgcn8_power_product", 8, "product", True, "power"),
             ("revgcn8_power_reference_algorithm_stock_gemm", 8, "restated", False, "power")):
         ops.FUSED_EDGE_GEMM = fused
+        gcn_revop.KEEP_AGGREGATION = impl != "product_pure"
         m = rev_restated.RevGCN(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
-                                impl=impl).to(dev).train()
+                                impl="product" if impl == "product_pure" else impl).to(dev).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
         def rev_step():
@@ -335,13 +342,18 @@ def extras(dev):
                          peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
         del m, opt
     ops.FUSED_EDGE_GEMM = True
+    gcn_revop.KEEP_AGGREGATION = True
     rev["speedup_per_layer_vs_reference_algorithm_on_stock_gemm"] = (
         rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_product"]["ms_per_layer"])
     rev["speedup_per_layer_power_aggregation"] = (
         rev["revgcn8_power_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_power_product"]["ms_per_layer"])
     rev["workload"] = (f"RevGCN hidden=224 group=2 gcn_aggr=max (the README's commands; *_power_* rows: power) conv_encode_edge (ogb_eff/ogbn_proteins/model_rev.py) on a "
                        f"cluster-shaped power-law graph N={Np} E={Ep}, train step fwd + reversible bwd + Adam; "
-                       f"'product' = eff_gcn_modules.rev drop-in + fused edge-GEMM kernels, 'reference_algorithm_stock_gemm' "
+                       f"'product' = eff_gcn_modules.rev drop-in + fused edge-GEMM kernels, the backward's evaluation of "
+                       f"every coupling function taking the forward's aggregation results (max: (N, C) output + arg-max "
+                       f"ids per function; softmax / power need (E, C) pre-activations and launch again), "
+                       f"'product_pure_recompute' = the same with every edge kernel launched again (KEEP_AGGREGATION off: "
+                       f"memory as in the reference's scheme), 'reference_algorithm_stock_gemm' "
                        f"= the reference's inverse + recompute pattern on library GEMMs + (E,C) edge embeddings")
     rev["graph_build_ms"] = build_ms
     rev["graph_build_cold_ms"] = build_cold

@@ -101,6 +101,7 @@ def main():
     ya = torch.randint(0, 40, (s["n"],), device=dev)
     for name, kw in (("plain_loop_no_dropout", dict(dropout=0.0)), ("plain_loop", dict(dropout=0.5)),
                      ("res_plus_layer", dict(dropout=0.5, fused_layers=True)),
+                     ("res_plus_layer_full_recompute", dict(dropout=0.5, fused_layers=True, checkpoint="reference_full")),
                      ("res_plus_layer_no_checkpoint", dict(dropout=0.5, fused_layers=True, checkpoint="never")),
                      ("plain_loop_no_checkpoint", dict(dropout=0.5, checkpoint="never")),
                      ("res_plus_layer_library_gemm", dict(dropout=0.5, fused_layers=True))):

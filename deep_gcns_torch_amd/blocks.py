@@ -24,7 +24,7 @@ from __future__ import annotations
 import torch
 from torch.utils.checkpoint import checkpoint
 
-from . import node_ops
+from . import node_ops, ops
 
 __all__ = ["res_plus_layer", "ResPlusLayer"]
 
@@ -42,11 +42,23 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
     norm: ``gcn_lib.sparse.torch_nn.norm_layer`` module; conv: ``gcn_lib.sparse.torch_vertex.GENConv``.
     stats: what the previous call returned (BatchNorm statistics of ``h`` taken in the GEMM that produced it) or None.
     use_checkpoint: wrap the convolution in ``torch.utils.checkpoint`` as the reference does for deep stacks
-    (ogbn_arxiv/model.py:101: only the aggregation + MLP is recomputed; ``h`` and ``h2`` stay alive)."""
+    (ogbn_arxiv/model.py:101: the convolution is recomputed in the backward; ``h`` and ``h2`` stay alive).  True or
+    "aggregation": the recomputation re-runs the node-wise part only -- the aggregation's outputs (two or three (N, C)
+    arrays per layer; the reference checkpoints because ITS aggregation keeps (E, C) temporaries) are kept from the first
+    pass (ops.AggregationStash); "full": everything is recomputed, aggregation included, exactly as
+    torch.utils.checkpoint around the reference's GENConv would."""
     h2 = node_ops.pre_activation(norm, h, p=p, training=training, stats=stats)
     if use_checkpoint and torch.is_grad_enabled():
+        if use_checkpoint not in (True, "aggregation", "full"):
+            raise ValueError("use_checkpoint: False, True / 'aggregation', or 'full'")
+        stash = None if use_checkpoint == "full" else ops.AggregationStash()
+
         def run(h2_, h_):
-            out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
+            if stash is None:
+                out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
+            else:
+                with ops.stash_aggregation(stash, "replay" if torch.is_grad_enabled() else "record"):
+                    out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
             return out if want_stats else (out, None)
         # the second output (statistics) is not differentiable; checkpoint hands it through
         hn, st = checkpoint(run, h2, h, use_reentrant=True)

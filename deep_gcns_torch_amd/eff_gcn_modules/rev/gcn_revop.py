@@ -38,6 +38,11 @@ from ... import ops
 __all__ = ["InvertibleCheckpointFunction", "InvertibleModuleWrapper", "get_device_states", "set_device_states"]
 
 _STATE = "_dgcn_rev_state"      # attribute on a shared argument tensor: its _SharedArgState
+# The fused backward re-evaluates every coupling function on the input the forward gave it.  True: the aggregation
+# launches of that forward keep their node-sized results for it (ops.AggregationStash; per GENBlock of the ogbn-proteins
+# RevGCN: the (N, C) output + arg-max ids, 12 MB against 0.3 ms of edge kernel); False: launch again (memory as in the
+# reference's reversible scheme, to the byte).
+KEEP_AGGREGATION = True
 
 
 class _SharedArgState:
@@ -121,13 +126,6 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
             if ctx.had_cuda_in_fwd:
                 ctx.fwd_gpu_devices, ctx.fwd_gpu_states = get_device_states(*inputs)
         ctx.input_requires_grad = [isinstance(t, torch.Tensor) and t.requires_grad for t in inputs]
-        with torch.no_grad():
-            outputs = fn(*_detached(inputs))
-        if not isinstance(outputs, tuple):
-            outputs = (outputs,)
-        outputs = tuple(o.detach_() for o in outputs)
-        if not keep_input:
-            _release(inputs[0])                    # only the node features are dropped (reference :62-67)
         # tensors every layer receives (edge embedding): count the layers whose backward will contribute
         module = getattr(fn, "__self__", None)
         ctx.fused = (hasattr(module, "fused_backward") and getattr(fn, "__name__", "") == "forward"
@@ -135,6 +133,21 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
                      and all(hasattr(t, _STATE) and module.arg_sink_ok(t) for t in inputs[2:] if _is_shared_arg(t))
                      and not any(isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training
                                  for m in module.modules()))
+        # the backward's grad-enabled evaluation of every F_i repeats this pass's: keep the aggregations' (N, C) results
+        # (max / add / mean and the unfused softmax / power forms: 2 - 3 node-sized arrays per coupling function) instead
+        # of launching the edge kernels again -- KEEP_AGGREGATION = False restores the pure recomputation
+        ctx.stashes = (module.new_stashes() if ctx.fused and KEEP_AGGREGATION
+                       and hasattr(module, "new_stashes") and any(ctx.needs_input_grad) else None)
+        with torch.no_grad():
+            if ctx.stashes is not None:
+                outputs = fn(*_detached(inputs), _stashes=ctx.stashes)
+            else:
+                outputs = fn(*_detached(inputs))
+        if not isinstance(outputs, tuple):
+            outputs = (outputs,)
+        outputs = tuple(o.detach_() for o in outputs)
+        if not keep_input:
+            _release(inputs[0])                    # only the node features are dropped (reference :62-67)
         ctx.inputs = [inputs] * num_bwd_passes
         ctx.outputs = [outputs] * num_bwd_passes
         return outputs
@@ -202,7 +215,9 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
             sinks.append(st.acc)
             first.append(fresh)
         x, grad_x, weight_grads = module.fused_backward(y, grad_outputs[0], inputs[1], inputs[2:], ctx.weights,
-                                                        sinks, ops.edge_grad_sink)
+                                                        sinks, ops.edge_grad_sink, stashes=ctx.stashes)
+        if len(ctx.outputs) == 0:
+            ctx.stashes = None                     # last backward pass over this layer: the kept arrays go
         _release(y)
         _restore(inputs[0], x)
         arg_grads = []

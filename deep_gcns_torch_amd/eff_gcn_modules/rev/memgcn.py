@@ -6,6 +6,7 @@ backward step used by ``gcn_revop.InvertibleCheckpointFunction``.
 """
 import torch
 
+from ... import ops
 from .gcn_revop import InvertibleModuleWrapper  # noqa: F401  (model_rev.py reaches it as memgcn.InvertibleModuleWrapper)
 
 __all__ = ["GroupAdditiveCoupling", "InvertibleModuleWrapper"]
@@ -22,7 +23,15 @@ class GroupAdditiveCoupling(torch.nn.Module):
         per_arg = [torch.chunk(a, self.group, dim=self.split_dim) for a in args]
         return list(zip(*per_arg))                      # [group][arg]
 
-    def forward(self, x, edge_index, *args):
+    def new_stashes(self):
+        """One ops.AggregationStash per coupling function (see ``forward(..., _stashes)``)."""
+        return [ops.AggregationStash(node_sized_only=True) for _ in range(self.group)]
+
+    def forward(self, x, edge_index, *args, _stashes=None):
+        """_stashes (the reversible wrapper's no_grad forward only): the aggregation launches of F_i record their
+        (N, C) outputs and what their backward needs there; ``fused_backward`` hands them out again instead of
+        launching -- F_i sees the same input in both passes (y_{i-1} exactly; F_0 the rebuilt sum of the other groups,
+        equal up to the rounding of the reconstruction)."""
         xs = torch.chunk(x, self.group, dim=self.split_dim)
         extra = self._arg_chunks(args)
         y_in = sum(xs[1:])
@@ -30,7 +39,11 @@ class GroupAdditiveCoupling(torch.nn.Module):
             # the reversible wrapper's forward (no graph): every y_i is written straight into its columns of the result
             y = torch.empty_like(x)
             for i, yv in enumerate(torch.chunk(y, self.group, dim=1)):
-                y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
+                if _stashes is None:
+                    y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
+                else:
+                    with ops.stash_aggregation(_stashes[i], "record"):
+                        y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
             return y
         ys = []
         for i in range(self.group):
@@ -64,7 +77,7 @@ class GroupAdditiveCoupling(torch.nn.Module):
         """(group, rows, w) -> the layout of the argument (rows, group * w)."""
         return buf.permute(1, 0, 2).reshape(t.shape).to(t.dtype)
 
-    def fused_backward(self, y, grad_y, edge_index, args, weights, arg_sinks, sink_ctx):
+    def fused_backward(self, y, grad_y, edge_index, args, weights, arg_sinks, sink_ctx, stashes=None):
         """Inverse and gradient of one coupling step from ONE grad-enabled evaluation of every F_i.
 
         ``F_i`` sees the same input in ``inverse`` and in the recompute of ``forward`` (y_{i-1}, or the sum of the
@@ -108,6 +121,8 @@ class GroupAdditiveCoupling(torch.nn.Module):
                     else:
                         call_args.append(a)
                 ctxs = [sink_ctx(c, v) for c, v in zip(leaves, views) if v is not None]
+                if stashes is not None and stashes[i].items:
+                    ctxs.append(ops.stash_aggregation(stashes[i], "replay"))
                 for cm in ctxs:
                     cm.__enter__()
                 try:

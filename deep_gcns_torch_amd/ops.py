@@ -75,6 +75,54 @@ def _feat_rows(f: torch.Tensor) -> torch.Tensor:
 _SINK_ATTR = "_dgcn_grad_sink"
 
 
+class AggregationStash:
+    """Outputs of the aggregation launches of one checkpointed function (blocks.res_plus_layer).
+
+    torch.utils.checkpoint runs a function under no_grad and again, with grad enabled, inside the backward.  The
+    aggregation is by far the most expensive part of that function and its results are a few (N, C) arrays: recorded in
+    the first pass (``mode = "record"``: the launch also writes what the backward needs -- log-sum-exp, arg-max ids,
+    pre-activations), handed out again in the second (``"replay"``: no launch).  The node-wise part is recomputed as
+    torch.utils.checkpoint intends.  The recorded tensors are the ones the first pass returned: they must not be written
+    in place by the caller (GENConv does not)."""
+
+    def __init__(self, node_sized_only: bool = False):
+        self.items = []
+        self.pos = 0
+        self.mode = None
+        # True: an aggregation whose backward needs an (E, C) array of the forward (the fused edge encoder's
+        # pre-activations under softmax / power) is not kept -- its slot says "launch again"
+        self.node_sized_only = node_sized_only
+
+
+_STASH: Optional[AggregationStash] = None
+
+
+class stash_aggregation:
+    """``with stash_aggregation(stash, "record" | "replay"):`` around the function a checkpoint runs twice."""
+
+    def __init__(self, stash: AggregationStash, mode: str):
+        if mode not in ("record", "replay"):
+            raise ValueError("mode must be 'record' or 'replay'")
+        self.stash, self.mode = stash, mode
+
+    def __enter__(self):
+        global _STASH
+        self._prev = _STASH
+        self.stash.mode = self.mode
+        if self.mode == "replay":
+            self.stash.pos = 0
+        else:
+            self.stash.items.clear()
+        _STASH = self.stash
+        return self.stash
+
+    def __exit__(self, *exc):
+        global _STASH
+        _STASH = self._prev
+        self.stash.mode = None
+        return False
+
+
 class edge_grad_sink:
     """``with edge_grad_sink(feat, buffer): out = layer(..., feat, ...); autograd.grad(out, ...)``: gradients of ``feat``
     (the very tensor object handed to the layer, an (E, F) edge-feature tensor) produced by the fused edge-GEMM backward
@@ -148,9 +196,39 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError(f"fused edge encoder: unsupported shape F={n_feat}, C={C} (see encoder_fusable)")
         need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[14:17]))
         # (no_grad / inverse passes skip the saved aux)
+        stash = _STASH
+        record = stash is not None and stash.mode == "record"
+        replay = stash is not None and stash.mode == "replay" and need_grad
+        if replay:
+            if stash.pos >= len(stash.items):
+                raise RuntimeError("aggregation stash: the recomputation runs more aggregations than the recorded pass")
+            key, kept = stash.items[stash.pos]
+            stash.pos += 1
+            if key != (graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root):
+                raise RuntimeError("aggregation stash: the recomputation does not repeat the recorded pass")
+            replay = kept is not None
+        if replay:
+            out, aux1, aux2, range_flag, z_save = kept
+            ctx.range_flag = range_flag
+            ctx.enc = (enc_feat, enc_w, enc_b) if enc else None
+            ctx.egemm = egemm
+            ctx.grad_sink = grad_sink
+            ctx.save_for_backward(x, z_save if egemm else edge_attr, t_param, p_param, aux1, aux2, out)
+            ctx.graph, ctx.mode, ctx.msg, ctx.eps = graph, mode, msg, eps
+            ctx.t_val, ctx.p_val = t_val, p_val
+            ctx.flags = ((_lib.FLAG_LEARN_T if learn_t else 0) | (_lib.FLAG_LEARN_P if learn_p else 0)
+                         | (_lib.FLAG_ADD_ROOT if add_root else 0))
+            ctx.learn_t, ctx.learn_p = learn_t, learn_p
+            ctx.t_dtype, ctx.p_dtype = t_dtype, p_dtype
+            ctx.add_root = add_root
+            return out
+        if record and stash.node_sized_only and egemm and mode != _lib.AGGR_MAX:
+            stash.items.append(((graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root), None))
+            record = False
+        want_aux = need_grad or record
         out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
         aux1 = aux2 = None
-        if need_grad:
+        if want_aux:
             if mode == _lib.AGGR_MAX:
                 aux1 = torch.empty(graph.n_dst, C, device=dev, dtype=torch.int32)
             elif mode in (_lib.AGGR_SOFTMAX, _lib.AGGR_POWER):
@@ -163,13 +241,13 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError("add_root needs a square graph and non-learnable t / p")
             flags |= _lib.FLAG_ADD_ROOT
         range_flag = None
-        if need_grad and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
+        if want_aux and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
             range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
         z_save = None
         if egemm:
-            if need_grad and mode != _lib.AGGR_MAX:    # max: the arg-max ids carry all the backward needs
+            if want_aux and mode != _lib.AGGR_MAX:    # max: the arg-max ids carry all the backward needs
                 z_save = torch.empty(graph.n_edges, C, device=dev, dtype=torch.float32)   # z_e, original edge order
             ws_bytes = lib.dgcn_gen_aggr_egemm_fwd_workspace_bytes(graph.n_edges, graph.n_src, n_feat, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
@@ -187,6 +265,9 @@ class _GenAggregate(torch.autograd.Function):
                     _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else "dgcn_gen_aggr_fwd_f32")
+        if record:
+            stash.items.append(((graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root),
+                                (out, aux1, aux2, range_flag, z_save)))
         if need_grad:
             ctx.range_flag = range_flag
             ctx.enc = (enc_feat, enc_w, enc_b) if enc else None

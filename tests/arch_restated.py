@@ -55,7 +55,12 @@ class DeeperGCN(torch.nn.Module):
         # (E, C) temporaries per layer alive; "never" = what a user of this package can do instead: nothing of size
         # (E, C) exists here, a layer keeps two (N, C) arrays (arxiv, 28 layers: 4.9 GB), and the recomputation of
         # aggregation + GEMM disappears
-        self.checkpoint_grad = checkpoint == "reference" and aggr in ("softmax_sg", "softmax", "power") and num_layers > 7
+        # "reference_full": res_plus_layer recomputes the aggregation too (what torch.utils.checkpoint around the
+        # reference's GENConv does); "reference": it keeps the aggregation's (N, C) outputs and recomputes the rest
+        if checkpoint not in ("reference", "reference_full", "never"):
+            raise ValueError(checkpoint)
+        self.checkpoint_grad = checkpoint != "never" and aggr in ("softmax_sg", "softmax", "power") and num_layers > 7
+        self.checkpoint_mode = "full" if checkpoint == "reference_full" else True
         self.ckp_k = num_layers // 2
         self.gcns = torch.nn.ModuleList()
         self.norms = torch.nn.ModuleList()
@@ -73,7 +78,8 @@ class DeeperGCN(torch.nn.Module):
             for layer in range(1, self.num_layers):
                 h, stats = blocks.res_plus_layer(self.norms[layer - 1], self.gcns[layer], h, edge_index, p=self.dropout,
                                                  training=self.training, stats=stats,
-                                                 use_checkpoint=self.checkpoint_grad and layer % self.ckp_k != 0)
+                                                 use_checkpoint=(self.checkpoint_grad and layer % self.ckp_k != 0)
+                                                 and self.checkpoint_mode)
             h = node_ops.pre_activation(self.norms[self.num_layers - 1], h, p=self.dropout, training=self.training,
                                         stats=stats)
             return torch.log_softmax(self.node_pred_linear(h), dim=-1)

@@ -326,3 +326,76 @@ def test_deepergcn_fused_layers_equal_the_plain_model():
     assert torch.isfinite(out).all()
     torch.nn.functional.nll_loss(out, y).backward()
     assert all(torch.isfinite(p.grad).all() for p in drop.parameters())
+
+
+@pytest.mark.parametrize("aggr,kw", [("softmax_sg", {}), ("softmax", dict(learn_t=True)), ("power", dict(p=1.3, learn_p=True)),
+                                     ("max", {})])
+def test_checkpoint_with_kept_aggregation_equals_full_recomputation(aggr, kw):
+    """blocks.res_plus_layer(use_checkpoint=True) keeps the aggregation's outputs of the first pass and recomputes the
+    node-wise part only (ops.AggregationStash); "full" recomputes everything.  Same kernels on the same inputs either way:
+    identical outputs and gradients, with dropout (the hash seed is drawn before the checkpoint) and learnable t / p."""
+    import os
+    import sys
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import arch_restated
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    N = 6000
+    ei = synth.undirected_random_graph(N, 30000, seed=11, device=dev)
+    x = torch.randn(N, 32, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = torch.randint(0, 10, (N,), generator=torch.Generator().manual_seed(4)).to(dev)
+    res = {}
+    for mode in ("reference", "reference_full", "never"):
+        torch.manual_seed(21)
+        m = arch_restated.DeeperGCN(num_layers=9, in_channels=32, hidden=64, num_tasks=10, aggr=aggr, dropout=0.3,
+                                    fused_layers=True, checkpoint=mode, **kw).to(dev).train()
+        if aggr == "max":
+            m.checkpoint_grad = mode != "never"              # (the reference checkpoints softmax / power stacks only)
+        torch.manual_seed(22)                                # the dropout seeds of the layers
+        out = m(x, ei)
+        torch.nn.functional.nll_loss(out, y).backward()
+        res[mode] = (out.detach(), [p.grad.clone() for p in m.parameters()])
+    o_ref, g_ref = res["reference_full"]
+    # learnable t / p: the launch that also writes the second moment is another instantiation of the kernel than the
+    # no_grad launch of the full recomputation's first pass -- the passes then differ by fp32 rounding, not bit for bit
+    exact = not (kw.get("learn_t") or kw.get("learn_p"))
+    gscale = max(float(b.abs().max()) for b in g_ref)
+    for mode in ("reference", "never"):
+        o, g = res[mode]
+        if exact:
+            assert torch.equal(o, o_ref)
+        else:
+            torch.testing.assert_close(o, o_ref, rtol=1e-4, atol=1e-5)
+        for a, b in zip(g, g_ref):
+            if exact:
+                assert torch.equal(a, b), mode
+            else:
+                floor = 1e-3 * gscale * b.numel() ** 0.5
+                err = float((a - b).double().norm() / max(float(b.double().norm()), floor))
+                assert err < 2e-3, (mode, err)
+
+
+def test_aggregation_stash_refuses_a_different_recomputation():
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    ei = synth.undirected_random_graph(500, 3000, seed=2, device=dev)
+    x = torch.randn(500, 32, device=dev, requires_grad=True)
+    st = ops.AggregationStash()
+    with torch.no_grad(), ops.stash_aggregation(st, "record"):
+        ops.gen_aggregate(x, ei, aggr="softmax", t=0.5)
+    assert len(st.items) == 1
+    with ops.stash_aggregation(st, "replay"):
+        out = ops.gen_aggregate(x, ei, aggr="softmax", t=0.5)
+        with pytest.raises(RuntimeError, match="more aggregations"):
+            ops.gen_aggregate(x, ei, aggr="softmax", t=0.5)
+    with ops.stash_aggregation(st, "replay"):
+        with pytest.raises(RuntimeError, match="does not repeat"):
+            ops.gen_aggregate(x, ei, aggr="max")
+    ref = ops.gen_aggregate(x, ei, aggr="softmax", t=0.5)
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    g0, = torch.autograd.grad(out, x, g)
+    g1, = torch.autograd.grad(ref, x, g)
+    assert torch.equal(g0, g1)

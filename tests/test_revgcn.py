@@ -78,18 +78,71 @@ def test_restated_reversible_wrapper_matches_reference_on_cpu(case, impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["restated", "product"])
+@pytest.mark.parametrize("impl", ["restated", "product", "product_pure_recompute"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
 def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
     """Forward under no_grad, freed input storage, inverse, recompute with grad: everything the reference's
     InvertibleCheckpointFunction does, around the HIP GENConv (impl='restated'), and the package's own fused
-    reversible step (impl='product': eff_gcn_modules.rev)."""
+    reversible step (impl='product': eff_gcn_modules.rev, the forward's aggregation results kept for the backward
+    where they are node-sized; 'product_pure_recompute': KEEP_AGGREGATION off, every edge kernel launched again)."""
     _install()
     assert torch.cuda.is_available()
-    hn, grads = _run(case, torch.device("cuda:0"), impl)
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
+    keep = gcn_revop.KEEP_AGGREGATION
+    gcn_revop.KEEP_AGGREGATION = impl != "product_pure_recompute"
+    try:
+        hn, grads = _run(case, torch.device("cuda:0"), "product" if impl.startswith("product") else impl)
+    finally:
+        gcn_revop.KEEP_AGGREGATION = keep
     # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge
     # on another device, so the gradient gate is relative to each tensor's scale (not elementwise)
     _check(case, hn, grads, 2e-4, 2e-3)
+
+
+@pytest.mark.gpu
+def test_kept_aggregation_skips_the_edge_kernels_of_the_backward():
+    """With KEEP_AGGREGATION the fused reversible backward launches no aggregation forward (max: arg-max ids and outputs
+    come from the no_grad pass); the gradients agree with the pure recomputation up to the rounding of the rebuilt inputs."""
+    _install()
+    from deep_gcns_torch_amd import _lib
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
+    case = next(c for c in CASES if c["ctor"]["aggr"] == "max")
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    names = ("dgcn_gen_aggr_egemm_fwd_f32", "dgcn_gen_aggr_fwd_f32")
+    counts = {}
+    results = {}
+    keep = gcn_revop.KEEP_AGGREGATION
+    try:
+        for flag in (True, False):
+            gcn_revop.KEEP_AGGREGATION = flag
+            n = [0]
+            real = {k: getattr(lib, k) for k in names}
+
+            def counted(fn):
+                def call(*a):
+                    n[0] += 1
+                    return fn(*a)
+                return call
+            for k in names:
+                setattr(lib, k, counted(real[k]))
+            try:
+                results[flag] = _run(case, dev, "product")
+            finally:
+                for k in names:
+                    setattr(lib, k, real[k])
+            counts[flag] = n[0]
+    finally:
+        gcn_revop.KEEP_AGGREGATION = keep
+    layers, group = case["ctor"]["num_layers"], 2
+    # pure: forward + grad-enabled evaluation per coupling function; kept: the backward's evaluations launch nothing
+    assert counts[False] == 2 * layers * group and counts[True] == layers * group, counts
+    hn1, g1 = results[True]
+    hn0, g0 = results[False]
+    assert torch.equal(hn1, hn0)
+    for k in g0:
+        scale = float(g0[k].abs().max()) + 1e-12
+        assert float((g1[k] - g0[k]).abs().max()) / scale < 2e-3, k
 
 
 def test_shared_leaf_argument_survives_eval_passes_and_aborted_backwards():
