@@ -476,10 +476,12 @@ ROWS_TN_KERNEL = True      # False: library split-K GEMM for the weight gradient
 
 def rows_tn(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """``g.T @ x`` for (rows, C), (rows, K) with rows >> C, K: the weight gradient of a row-wise Linear (no autograd).
-    csrc/rows_tn.hip on device rows (C <= 128, K <= 256, both multiples of 4, unit column strides, 16-byte aligned rows);
-    anything else: the split-K library GEMM."""
+    csrc/rows_tn.hip on device rows (min(C, K) <= 128, max(C, K) <= 256, both multiples of 4, unit column strides,
+    16-byte aligned rows); anything else: the split-K library GEMM."""
     from .nn_util import splitk_xt_g
     C, K = g.size(1), x.size(1)
+    if C > 128 and K <= 128 and g.dim() == 2 and x.dim() == 2:
+        return rows_tn(x, g).t().contiguous()      # the kernel's first operand is the narrow one: (x^T g)^T
     if not (ROWS_TN_KERNEL and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2
             and x.dim() == 2 and g.size(0) == x.size(0) and g.size(0) >= ROWS_LINEAR_MIN_ROWS and g.stride(1) == 1
             and x.stride(1) == 1 and max(g.stride(0), x.stride(0)) < (1 << 22)

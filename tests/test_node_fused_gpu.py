@@ -64,7 +64,7 @@ def test_rows_linear_forward_backward(rows, K, C, with_res):
 
 @pytest.mark.parametrize("rows,C,K,strided", [(5000, 128, 128, False), (100_003, 112, 224, True), (3001, 64, 64, False),
                                               (2500, 100, 40, False), (4100, 112, 224, False), (2049, 20, 132, False), (3000, 47, 128, False),
-                                              (2111, 128, 256, False),
+                                              (2111, 128, 256, False), (13253, 224, 112, False), (5000, 256, 64, True),
                                               (169343, 128, 128, False)])
 def test_rows_tn_weight_gradient(rows, C, K, strided):
     """g^T x on the matrix pipe (csrc/rows_tn.hip) against float64: the weight gradient of the row-wise Linear layers and
