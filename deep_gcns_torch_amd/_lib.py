@@ -105,6 +105,8 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "dgcn_bn_apply_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p]),
+    "dgcn_bn_apply_res_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dgcn_bn_bwd_num_partials": (C.c_int32, [C.c_int32, C.c_int32]),
     "dgcn_bn_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -98,6 +98,9 @@ struct BnApplyParams {
   const float* bnbuf;  // [4][C] or null (identity)
   float* out;          // [B,C,N]
   int B, N, C;
+  const float* res;     // (B,C,N) with element strides, added as res_scale * res (the block's skip connection), or null
+  int64_t rb, rc, rn;
+  float res_scale;
 };
 
 __global__ __launch_bounds__(kWgThreads) void bn_apply_kernel(const BnApplyParams P) {
@@ -128,7 +131,11 @@ __global__ __launch_bounds__(kWgThreads) void bn_apply_kernel(const BnApplyParam
   // write: rows = channels, fast = points (coalesced along n)
   for (int i = ly; i < kTile; i += 4) {
     const int c = c0 + i, n = n0 + lx;
-    if (c < P.C && n < P.N) P.out[(static_cast<int64_t>(b) * P.C + c) * P.N + n] = tile[lx][i];
+    if (c < P.C && n < P.N) {
+      float v = tile[lx][i];
+      if (P.res) v = fmaf(P.res_scale, P.res[b * P.rb + c * P.rc + n * P.rn], v);
+      P.out[(static_cast<int64_t>(b) * P.C + c) * P.N + n] = v;
+    }
   }
 }
 
@@ -291,10 +298,16 @@ extern "C" int dgcn_bn_finalize_f32(const float* stats, int32_t nparts, int32_t 
 
 extern "C" int dgcn_bn_apply_f32(const float* vmax, const float* vmin, const float* bnbuf, float* out,
                                  int32_t B, int32_t N, int32_t C, void* stream) {
+  return dgcn_bn_apply_res_f32(vmax, vmin, bnbuf, nullptr, 0, 0, 0, 0.f, out, B, N, C, stream);
+}
+
+extern "C" int dgcn_bn_apply_res_f32(const float* vmax, const float* vmin, const float* bnbuf, const float* res,
+                                     int64_t rb, int64_t rc, int64_t rn, float res_scale, float* out, int32_t B,
+                                     int32_t N, int32_t C, void* stream) {
   if (!vmax || !out) return DGCN_E_NULL;
   if (B < 0 || N <= 0 || C <= 0) return DGCN_E_SHAPE;
   if (B == 0) return DGCN_OK;
-  BnApplyParams P{vmax, vmin, bnbuf, out, B, N, C};
+  BnApplyParams P{vmax, vmin, bnbuf, out, B, N, C, res, rb, rc, rn, res_scale};
   const int64_t tiles = static_cast<int64_t>(B) * ((N + kTile - 1) / kTile) * ((C + kTile - 1) / kTile);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kWgThreads), 0,
                      static_cast<hipStream_t>(stream), P);

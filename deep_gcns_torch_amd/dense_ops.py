@@ -309,7 +309,7 @@ from .nn_util import splitk_xt_g as _splitk_xt_g  # noqa: E402  (tall-skinny g^T
 class _EdgeConv2dFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, idx, act, slope, bn_mode, running_mean, running_var,
-                num_batches, momentum, eps, track):
+                num_batches, momentum, eps, track, res_scale=None):
         lib = _lib.load()
         dev = _lib.require_device(x, weight, idx)
         stream = _lib.current_stream_handle(dev)
@@ -351,11 +351,20 @@ class _EdgeConv2dFused(torch.autograd.Function):
                     _lib.ptr(stats), nparts, Cout, count, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                     _lib.ptr(running_var), _lib.ptr(num_batches), 1 if bn_mode == BN_TRAIN else 0,
                     float(momentum), float(eps), bnbuf.data_ptr(), stream), "dgcn_bn_finalize_f32")
-            _lib.check(lib.dgcn_bn_apply_f32(vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(bnbuf), out.data_ptr(),
-                                             B, N, Cout, stream), "dgcn_bn_apply_f32")
+            if res_scale is None:
+                _lib.check(lib.dgcn_bn_apply_f32(vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(bnbuf), out.data_ptr(),
+                                                 B, N, Cout, stream), "dgcn_bn_apply_f32")
+            else:
+                # the block's skip connection rides in the transposing store: out = conv(x) + res_scale * x
+                if Cout != C:
+                    raise ValueError("residual needs in_channels == out_channels")
+                _lib.check(lib.dgcn_bn_apply_res_f32(vmax.data_ptr(), _lib.ptr(vmin), _lib.ptr(bnbuf), x3.data_ptr(),
+                                                     x3.stride(0), x3.stride(1), x3.stride(2), float(res_scale),
+                                                     out.data_ptr(), B, N, Cout, stream), "dgcn_bn_apply_res_f32")
         if need_bwd:
             ctx.save_for_backward(x3, W2, pq, idx, amax, amin, vmax, vmin, bnbuf, gamma)
             ctx.cfg = (act, slope, bn_mode, count, tuple(x.shape), tuple(weight.shape), bias is not None)
+            ctx.res_scale = res_scale
         return out
 
     @staticmethod
@@ -420,7 +429,13 @@ class _EdgeConv2dFused(torch.autograd.Function):
         w1, w2h = W2[:, :C], W2[:, C:]
         if ctx.needs_input_grad[0]:
             wc = torch.cat([w1 - w2h, w2h], dim=0)                          # (2Cout, C)
-            gx = torch.matmul(dPQ, wc).permute(0, 2, 1).reshape(x_shape)    # (B,C,N[,1])
+            # (B, C, N) straight out of the GEMM (transposed operands, no permute + copy); the skip connection's
+            # gradient res_scale * g is the GEMM's beta term
+            wct = wc.t().unsqueeze(0).expand(B, C, 2 * Cout)
+            if ctx.res_scale is None:
+                gx = torch.bmm(wct, dPQ.transpose(1, 2)).reshape(x_shape)
+            else:
+                gx = torch.baddbmm(g3, wct, dPQ.transpose(1, 2), beta=float(ctx.res_scale)).reshape(x_shape)
         if ctx.needs_input_grad[1]:
             xr = x3.permute(0, 2, 1).reshape(B * N, C)
             dwc = _splitk_xt_g(dPQ.view(B * N, 2 * Cout), xr)               # (2Cout, C)
@@ -432,15 +447,17 @@ class _EdgeConv2dFused(torch.autograd.Function):
                 ggamma = coef[0]
             if ctx.needs_input_grad[4]:
                 gbeta = coef[1]
-        return (gx, gW, gb, ggamma, gbeta) + (None,) * 10
+        return (gx, gW, gb, ggamma, gbeta) + (None,) * 11
 
 
-def edgeconv2d_fused(x, weight, bias, idx, act, slope, bn=None):
+def edgeconv2d_fused(x, weight, bias, idx, act, slope, bn=None, res_scale=None):
     """max_l BN(act(W [x_i ; x_j - x_i] + b)) for x (B,C,N,1), idx (B,N,k) -> (B,Cout,N,1).
-    ``bn``: a BatchNorm2d module (training or eval semantics, running statistics updated in place) or None."""
+    ``bn``: a BatchNorm2d module (training or eval semantics, running statistics updated in place) or None.
+    ``res_scale``: add ``res_scale * x`` (ResDynBlock2d's skip connection) in the final store; its gradient joins the
+    input-gradient GEMM."""
     if bn is None:
         return _EdgeConv2dFused.apply(x, weight, bias, None, None, idx, act, float(slope), BN_NONE, None, None,
-                                      None, 0.0, 0.0, torch.is_grad_enabled())
+                                      None, 0.0, 0.0, torch.is_grad_enabled(), res_scale)
     use_batch = bn.training or not bn.track_running_stats
     momentum = bn.momentum
     nbt = bn.num_batches_tracked if (use_batch and bn.track_running_stats and bn.training) else None
@@ -455,4 +472,4 @@ def edgeconv2d_fused(x, weight, bias, idx, act, slope, bn=None):
     return _EdgeConv2dFused.apply(x, weight, bias, bn.weight, bn.bias, idx, act, float(slope),
                                   BN_TRAIN if use_batch else BN_EVAL, rm, rv, nbt,
                                   0.0 if momentum is None else float(momentum), float(bn.eps),
-                                  torch.is_grad_enabled())
+                                  torch.is_grad_enabled(), res_scale)

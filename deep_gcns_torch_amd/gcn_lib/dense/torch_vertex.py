@@ -47,6 +47,14 @@ class MRConv2d(nn.Module):
         return self.nn(torch.cat([x, rel], dim=1))
 
 
+def _with_skip(y, x, res_scale):
+    """``y + x * res_scale`` as the reference writes it (gcn_lib/dense/torch_vertex.py:101); the multiplication by the
+    default scale 1 is skipped (x * 1 == x bit for bit)."""
+    if res_scale is None:
+        return y
+    return y + x if res_scale == 1 else y + x * res_scale
+
+
 class EdgeConv2d(nn.Module):
     """Edge convolution max_j norm(act(W [x_i ; x_j - x_i] + b)) for dense data.
 
@@ -69,17 +77,22 @@ class EdgeConv2d(nn.Module):
         x_j = batched_index_select(x, edge_index[0])
         return torch.max(self.nn(torch.cat([x_i, x_j - x_i], dim=1)), -1, keepdim=True)[0]
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, res_scale=None):
+        """res_scale (not in the reference's signature): the caller's ``+ x * res_scale`` done in the last kernel."""
         if self._per_edge:
-            return self._forward_per_edge(x, edge_index)
+            return _with_skip(self._forward_per_edge(x, edge_index), x, res_scale)
         dense_ops.check_centres(edge_index)
         conv = self.nn[0]
         act, slope = _act_code(self.nn)
         bn = next((m for m in self.nn if isinstance(m, nn.BatchNorm2d)), None)
         if conv.out_channels % 4 == 0:
             # fused path: P/Q GEMM straight from the conv weight, edge kernel, BN finalize, transposing apply
-            return dense_ops.edgeconv2d_fused(x, conv.weight, conv.bias, edge_index[0], act, slope, bn)
-        return self._forward_composed(x, edge_index, conv, act, slope, bn)
+            if res_scale is not None and (x.dim() != 4 or conv.out_channels * 2 != conv.in_channels or not x.is_floating_point()
+                                          or x.dtype != torch.float32):
+                return _with_skip(dense_ops.edgeconv2d_fused(x, conv.weight, conv.bias, edge_index[0], act, slope, bn),
+                                  x, res_scale)
+            return dense_ops.edgeconv2d_fused(x, conv.weight, conv.bias, edge_index[0], act, slope, bn, res_scale)
+        return _with_skip(self._forward_composed(x, edge_index, conv, act, slope, bn), x, res_scale)
 
     def _forward_composed(self, x, edge_index, conv, act, slope, bn):
         """Same math from separately differentiable pieces (channel counts that are not a multiple of 4)."""
@@ -130,8 +143,12 @@ class GraphConv2d(nn.Module):
         else:
             raise NotImplementedError('conv:{} is not supported'.format(conv))
 
-    def forward(self, x, edge_index):
-        return self.gconv(x, edge_index)
+    def forward(self, x, edge_index, res_scale=None):
+        if res_scale is None:
+            return self.gconv(x, edge_index)
+        if isinstance(self.gconv, EdgeConv2d):
+            return self.gconv(x, edge_index, res_scale)
+        return _with_skip(self.gconv(x, edge_index), x, res_scale)
 
 
 class DynConv2d(GraphConv2d):
@@ -145,10 +162,10 @@ class DynConv2d(GraphConv2d):
         graph_cls = DenseDilatedKnnGraph if knn == 'matrix' else DilatedKnnGraph
         self.dilated_knn_graph = graph_cls(kernel_size, dilation, stochastic, epsilon)
 
-    def forward(self, x, edge_index=None):
+    def forward(self, x, edge_index=None, res_scale=None):
         if edge_index is None:
             edge_index = self.dilated_knn_graph(x)
-        return super().forward(x, edge_index)
+        return super().forward(x, edge_index, res_scale)
 
 
 class PlainDynBlock2d(nn.Module):
@@ -171,7 +188,8 @@ class ResDynBlock2d(nn.Module):
         self.res_scale = res_scale
 
     def forward(self, x, edge_index=None):
-        return self.body(x, edge_index) + x * self.res_scale
+        # self.body(x, edge_index) + x * self.res_scale, the skip connection added by the convolution's last kernel
+        return self.body(x, edge_index, self.res_scale)
 
 
 class DenseDynBlock2d(nn.Module):

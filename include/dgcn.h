@@ -373,6 +373,11 @@ int dgcn_bn_finalize_f32(const float* stats, int32_t nparts, int32_t C, double c
  * (B,C,N,1) channel-major layer output (LDS tile transpose).  bnbuf NULL = identity (norm=None). */
 int dgcn_bn_apply_f32(const float* vmax, const float* vmin, const float* bnbuf, float* out, int32_t B,
                       int32_t N, int32_t C, void* stream);
+/* The same with the block's skip connection in the store: out += res_scale * res[b,c,n] (element strides rb, rc, rn; the
+ * `self.body(x) + x * self.res_scale` of ResDynBlock2d, gcn_lib/dense/torch_vertex.py:100-101).  res NULL = the call above. */
+int dgcn_bn_apply_res_f32(const float* vmax, const float* vmin, const float* bnbuf, const float* res, int64_t rb,
+                          int64_t rc, int64_t rn, float res_scale, float* out, int32_t B, int32_t N, int32_t C,
+                          void* stream);
 
 /* Backward prologue: g (B,C,N) with element strides -> gsel[b,n,c] = g*scale (point-major) and per-workgroup
  * partial sums of g and g*sel, partial [dgcn_bn_bwd_num_partials(B,N)][2][C] (NULL to skip). */

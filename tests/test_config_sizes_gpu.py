@@ -132,7 +132,8 @@ def test_resgcn28_full_depth_forward():
         return ei
 
     torch_edge.DenseDilatedKnnGraph.forward = knn_oracle
-    torch_vertex.EdgeConv2d.forward = lambda self, x, edge_index: dense_ref.edgeconv2d(x, edge_index, self.nn)
+    torch_vertex.EdgeConv2d.forward = lambda self, x, edge_index, res_scale=None: torch_vertex._with_skip(
+        dense_ref.edgeconv2d(x, edge_index, self.nn), x, res_scale)
     try:
         mc.train()
         with torch.no_grad():
@@ -215,7 +216,8 @@ def test_resgcn_three_blocks_b8_forward_backward():
         return ei
 
     torch_edge.DenseDilatedKnnGraph.forward = knn_oracle
-    torch_vertex.EdgeConv2d.forward = lambda self, x, edge_index: dense_ref.edgeconv2d(x, edge_index, self.nn)
+    torch_vertex.EdgeConv2d.forward = lambda self, x, edge_index, res_scale=None: torch_vertex._with_skip(
+        dense_ref.edgeconv2d(x, edge_index, self.nn), x, res_scale)
     try:
         mc.train()
         xin_c = inputs.clone().requires_grad_(True)

@@ -186,6 +186,37 @@ def test_dense_resdynblock_matches_reference():
         _close(named[pname].grad, g, rtol=5e-4, atol_scale=2e-5, what=f"grad {pname}")
 
 
+@pytest.mark.parametrize("res_scale,conv,norm", [(1, "edge", "batch"), (0.5, "edge", "batch"), (2.0, "edge", None),
+                                                 (1, "mr", "batch"), (0.25, "edge", "instance")])
+def test_resdynblock_skip_connection_in_the_last_kernel(res_scale, conv, norm):
+    """ResDynBlock2d adds `x * res_scale` inside the convolution's final store (EdgeConv2d fused path) and its gradient in
+    the input-gradient GEMM; other convolutions / norms add it afterwards.  Against the reference's own expression."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from gcn_lib.dense import ResDynBlock2d
+    dev = _dev()
+    torch.manual_seed(3)
+    blk = ResDynBlock2d(32, 9, 2, conv, "relu", norm, True, res_scale=res_scale).to(dev).train()
+    x0 = torch.randn(3, 32, 700, 1, device=dev)
+    probe = torch.randn(3, 32, 700, 1, device=dev)
+    ei = blk.body.dilated_knn_graph(x0)
+    xa = x0.clone().requires_grad_(True)
+    out = blk(xa, ei)
+    (out * probe).sum().backward()
+    ga = [p.grad.clone() for p in blk.parameters()]
+    for p in blk.parameters():
+        p.grad = None
+    bufs = {k: v.clone() for k, v in blk.named_buffers()}
+    xb = x0.clone().requires_grad_(True)
+    ref = blk.body(xb, ei) + xb * res_scale                 # gcn_lib/dense/torch_vertex.py:101
+    (ref * probe).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-4 * float(xb.grad.abs().max()))
+    for a, p in zip(ga, blk.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-4 * float(p.grad.abs().max()) + 1e-7)
+    assert set(bufs) == set(dict(blk.named_buffers()))
+
+
 def test_vertex_gemm_is_an_exact_fma_chain():
     """fp32 MFMA == channel-ordered fmaf chain (guide: bitwise); checked against float64 within 1 ulp-ish
     and against small-integer data exactly."""
@@ -207,7 +238,11 @@ def test_vertex_gemm_is_an_exact_fma_chain():
 
 @pytest.mark.parametrize("N,C,K,kind", [(4096, 3, 16, "lattice"), (4096, 64, 432, "lattice"), (2048, 16, 64, "sorted"),
                                         (1024, 3, 100, "duplicates"), (4096, 8, 512, "lattice"), (1536, 5, 1, "lattice"),
-                                        (4096, 64, 880, "lattice"), (2048, 8, 1024, "sorted"), (1100, 3, 600, "duplicates")])
+                                        (4096, 64, 880, "lattice"), (2048, 8, 1024, "sorted"), (1100, 3, 600, "duplicates"),
+                                        # 32 / 64 channels: the bf16 filter kernel, whose overflow rows the workgroup
+                                        # redoes in place (sorted clouds and duplicates defeat the sampled threshold)
+                                        (4096, 64, 64, "sorted"), (2048, 32, 200, "sorted"), (1024, 64, 100, "duplicates"),
+                                        (4096, 32, 432, "duplicates"), (4096, 64, 16, "sorted")])
 def test_dense_knn_large_n_sampled_select_vs_oracle(N, C, K, kind):
     """N >= 1024 takes the sample-pre-filtered select; its result must equal the exact top-K whatever the
     point order (sorted clouds defeat the sample -> exact fallback) and with heavy ties (duplicates)."""
