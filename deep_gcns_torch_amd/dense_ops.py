@@ -9,6 +9,8 @@ of gcn_lib/dense/torch_vertex.py:16-20,31-35 of the reference.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -79,7 +81,7 @@ def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1, exclude_self: boo
         kout = (K + dilation - 1) // dilation
         ei = torch.empty(2, B, N, kout, dtype=torch.int64, device=x.device)
         _knn_launch(x3, K, dilation, ei[0], ei[1], exclude_self)
-    _CENTRES_OK.add(ei.untyped_storage().data_ptr())     # written by the kernel: edge_index[1][b, n, :] == n
+    _register_centres(ei)                                  # written by the kernel: edge_index[1][b, n, :] == n
     return ei
 
 
@@ -88,7 +90,9 @@ def knn_edge_index(x: torch.Tensor, k: int, dilation: int = 1, exclude_self: boo
 # graph builder of the library writes edge_index[1][b, n, :] = n, which is what the fused kernels assume (row n of
 # the neighbour list belongs to point n).  Edge lists built here are known to satisfy it (their storage is
 # registered, views such as edge_index[..., ::d] share it); a caller-supplied edge_index is verified ONCE per
-# storage (one device reduction + host read) and rejected loudly if its centres differ.
+# storage (one device reduction + host read) and rejected loudly if its centres differ.  An entry is keyed by
+# (storage address, version counter) -- an in-place edit of a verified tensor is a new key -- and dies with the tensor
+# object it was registered for, so a later tensor that the caching allocator places at the same address is checked again.
 class _StorageSet:
     def __init__(self, cap=256):
         self._d, self._cap = {}, cap
@@ -96,7 +100,14 @@ class _StorageSet:
     def add(self, key):
         if len(self._d) >= self._cap:
             self._d.pop(next(iter(self._d)))
-        self._d[key] = True
+        self._d[key] = self._d.get(key, 0) + 1
+
+    def discard(self, key):
+        n = self._d.get(key, 0)
+        if n <= 1:
+            self._d.pop(key, None)
+        else:
+            self._d[key] = n - 1
 
     def __contains__(self, key):
         return key in self._d
@@ -105,9 +116,18 @@ class _StorageSet:
 _CENTRES_OK = _StorageSet()
 
 
+def _centres_key(t: torch.Tensor):
+    return (t.untyped_storage().data_ptr(), t._version)
+
+
+def _register_centres(t: torch.Tensor) -> None:
+    key = _centres_key(t)
+    _CENTRES_OK.add(key)
+    weakref.finalize(t, _CENTRES_OK.discard, key)
+
+
 def check_centres(edge_index: torch.Tensor) -> None:
-    key = edge_index.untyped_storage().data_ptr()
-    if key in _CENTRES_OK:
+    if _centres_key(edge_index) in _CENTRES_OK:
         return
     centre = edge_index[1]
     n = centre.size(-2)
@@ -117,7 +137,7 @@ def check_centres(edge_index: torch.Tensor) -> None:
             "dense EdgeConv2d / MRConv2d: edge_index[1][b, n, :] must equal n (the centre of neighbour row n is "
             "point n, as every gcn_lib.dense graph builder produces); general centre ids are not supported by the "
             "fused kernels")
-    _CENTRES_OK.add(key)
+    _register_centres(edge_index)
 
 
 def knn_indices(pts: torch.Tensor, k: int, dilation: int = 1, exclude_self: bool = False) -> torch.Tensor:
