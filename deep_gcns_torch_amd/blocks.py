@@ -47,7 +47,8 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
     arrays per layer; the reference checkpoints because ITS aggregation keeps (E, C) temporaries) are kept from the first
     pass (ops.AggregationStash); "full": everything is recomputed, aggregation included, exactly as
     torch.utils.checkpoint around the reference's GENConv would."""
-    h2 = node_ops.pre_activation(norm, h, p=p, training=training, stats=stats)
+    # h_skip is h: the second output routes the skip connection's gradient into the pre-activation's backward kernel
+    h2, h_skip = node_ops.pre_activation(norm, h, p=p, training=training, stats=stats, skip=True)
     if use_checkpoint and torch.is_grad_enabled():
         if use_checkpoint not in (True, "aggregation", "full"):
             raise ValueError("use_checkpoint: False, True / 'aggregation', or 'full'")
@@ -61,9 +62,9 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
                     out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
             return out if want_stats else (out, None)
         # the second output (statistics) is not differentiable; checkpoint hands it through
-        hn, st = checkpoint(run, h2, h, use_reentrant=True)
+        hn, st = checkpoint(run, h2, h_skip, use_reentrant=True)
     else:
-        out = _conv_res(conv, h2, edge_index, edge_attr, h, want_stats)
+        out = _conv_res(conv, h2, edge_index, edge_attr, h_skip, want_stats)
         hn, st = out if want_stats else (out, None)
     return hn, st
 

@@ -100,9 +100,11 @@ def _mask_rows(drop: DropSpec, rows: int, C: int, dev):
 class _BatchNormRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches, use_batch_stats: bool, momentum: float,
-                eps: float, relu: bool, track: bool, drop: DropSpec = None, stats=None, sync=None):
+                eps: float, relu: bool, track: bool, drop: DropSpec = None, stats=None, sync=None, skip: bool = False):
         """``sync`` (dist.BatchSync or None): all-reduce the statistics partials over the ranks of a node-partitioned
-        graph, forward and backward: the batch is the whole graph's rows."""
+        graph, forward and backward: the batch is the whole graph's rows.
+        ``skip``: also return the input itself (an alias) for the caller's skip connection; its gradient is added to
+        ``dx`` inside the backward's apply kernel instead of by an autograd accumulation pass."""
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
@@ -143,10 +145,12 @@ class _BatchNormRows(torch.autograd.Function):
         if track and any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(x, bnbuf, drop.mask)
             ctx.cfg = (use_batch_stats, weight is not None, bias is not None, relu, drop, sync)
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         lib = _lib.load()
         x, bnbuf, mask = ctx.saved_tensors
         use_batch_stats, has_w, has_b, relu, drop, sync = ctx.cfg
@@ -154,7 +158,11 @@ class _BatchNormRows(torch.autograd.Function):
         stream = _lib.current_stream_handle(dev)
         rows, C = x.shape
         ld = x.stride(0) if rows > 1 else C
+        if g is None:                                   # only the skip output was used
+            g = torch.zeros(rows, C, device=dev, dtype=torch.float32)
         g = g.float().contiguous()
+        if g_skip is not None:
+            g_skip = g_skip.float().contiguous()
         nparts = lib.dgcn_rows_num_partials(rows, C)
         partial = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
         coef = torch.empty(4, C, device=dev, dtype=torch.float32)
@@ -177,8 +185,8 @@ class _BatchNormRows(torch.autograd.Function):
                        "dgcn_rows_bn_bwd_finalize_f32")
             if dx is not None:
                 _lib.check(lib.dgcn_rows_bn_act_bwd_apply_f32(g.data_ptr(), x.data_ptr(), ld, bnbuf.data_ptr(),
-                                                              coef.data_ptr(), 1 if relu else 0, *drop.args(), None,
-                                                              dx.data_ptr(), rows, C, stream),
+                                                              coef.data_ptr(), 1 if relu else 0, *drop.args(),
+                                                              _lib.ptr(g_skip), dx.data_ptr(), rows, C, stream),
                            "dgcn_rows_bn_act_bwd_apply_f32")
         if local is not None:
             gw = local[1] if (has_w and ctx.needs_input_grad[1]) else None
@@ -186,7 +194,7 @@ class _BatchNormRows(torch.autograd.Function):
         else:
             gw = coef[0] if (has_w and ctx.needs_input_grad[1]) else None  # rows of a fresh tensor: no copy needed
             gb = coef[1] if (has_b and ctx.needs_input_grad[2]) else None
-        return (dx, gw, gb) + (None,) * 11
+        return (dx, gw, gb) + (None,) * 12
 
 
 def _supported(x: torch.Tensor) -> bool:
@@ -196,13 +204,13 @@ def _supported(x: torch.Tensor) -> bool:
 
 
 def batch_norm_rows(x, weight, bias, running_mean, running_var, num_batches, training: bool, momentum: float,
-                    eps: float, relu: bool = False, drop: DropSpec = None, stats=None, sync=None) -> torch.Tensor:
+                    eps: float, relu: bool = False, drop: DropSpec = None, stats=None, sync=None, skip: bool = False):
     """BatchNorm1d over the rows of ``x`` (rows, C) [+ ReLU] [+ dropout]; ``training`` selects batch statistics (and
     updates the running buffers in place when given).  ``stats``: (parts, 2, C) partial sums of x and x^2 that the
     producer of ``x`` already computed (``rows_linear(..., want_stats=True)``): the statistics pass is skipped."""
     return _BatchNormRows.apply(x, weight, bias, running_mean, running_var, num_batches, bool(training),
                                 float(momentum), float(eps), bool(relu), torch.is_grad_enabled(), drop,
-                                stats if training else None, sync if training else None)
+                                stats if training else None, sync if training else None, bool(skip))
 
 
 class BatchNorm1d(nn.BatchNorm1d):
@@ -225,16 +233,20 @@ class BatchNorm1d(nn.BatchNorm1d):
         rv = self.running_var if (not self.training or self.track_running_stats) else None
         return use_batch, momentum, nb, rm, rv
 
-    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None):
+    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None, skip: bool = False):
+        """skip: return ``(y, x)`` -- the second output carries the caller's skip connection (see _BatchNormRows)."""
         sync = _active_sync() if self.training else None      # node-partitioned graph: statistics over all ranks' rows
         a = self._hip_args(x)
         if a is None:
             if sync is not None and x.dim() == 2:
-                return _sync_bn_torch(self, x, fuse_relu, drop, sync)
-            return _stock_tail(super().forward(x), fuse_relu, drop)
+                y = _sync_bn_torch(self, x, fuse_relu, drop, sync)
+            else:
+                y = _stock_tail(super().forward(x), fuse_relu, drop)
+            return (y, x) if skip else y
         use_batch, momentum, nb, rm, rv = a
         return batch_norm_rows(x, self.weight, self.bias, rm, rv, nb, use_batch, momentum, self.eps, relu=fuse_relu,
-                               drop=drop, stats=stats if use_batch else None, sync=sync if use_batch else None)
+                               drop=drop, stats=stats if use_batch else None, sync=sync if use_batch else None,
+                               skip=skip)
 
 
 def _active_sync():
@@ -274,7 +286,7 @@ def _stock_tail(y, relu: bool, drop: DropSpec):
 
 class _LayerNormRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float, relu: bool, track: bool, drop: DropSpec = None):
+    def forward(ctx, x, weight, bias, eps: float, relu: bool, track: bool, drop: DropSpec = None, skip: bool = False):
         lib = _lib.load()
         dev = _lib.require_device(x)
         stream = _lib.current_stream_handle(dev)
@@ -300,10 +312,12 @@ class _LayerNormRows(torch.autograd.Function):
         if track and any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(x2, w, b, mean, rstd, drop.mask)
             ctx.cfg = (weight is not None, bias is not None, tuple(shape), relu, drop)
+        if skip:
+            return y.view(shape), x.view_as(x)
         return y.view(shape)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         lib = _lib.load()
         x2, w, b, mean, rstd, mask = ctx.saved_tensors
         has_w, has_b, shape, relu, drop = ctx.cfg
@@ -311,7 +325,10 @@ class _LayerNormRows(torch.autograd.Function):
         stream = _lib.current_stream_handle(dev)
         rows, C = x2.shape
         ld = x2.stride(0) if rows > 1 else C
+        if g is None:
+            g = torch.zeros(rows, C, device=dev, dtype=torch.float32)
         g2 = g.reshape(rows, C).float().contiguous()
+        gs2 = None if g_skip is None else g_skip.reshape(rows, C).float().contiguous()
         need_dx = ctx.needs_input_grad[0]
         need_p = (has_w and ctx.needs_input_grad[1]) or (has_b and ctx.needs_input_grad[2])
         dx = torch.empty(rows, C, device=dev, dtype=torch.float32) if need_dx else None
@@ -322,13 +339,14 @@ class _LayerNormRows(torch.autograd.Function):
                 partial = torch.empty(nparts, 2, C, device=dev, dtype=torch.float32)
             _lib.check(lib.dgcn_rows_ln_act_bwd_f32(g2.data_ptr(), x2.data_ptr(), ld, _lib.ptr(w), _lib.ptr(b),
                                                     mean.data_ptr(), rstd.data_ptr(), 1 if relu else 0, *drop.args(),
-                                                    None, _lib.ptr(dx), _lib.ptr(partial), rows, C, stream),
+                                                    _lib.ptr(gs2) if need_dx else None, _lib.ptr(dx), _lib.ptr(partial),
+                                                    rows, C, stream),
                        "dgcn_rows_ln_act_bwd_f32")
             if need_p:
                 psum = partial.sum(0)                 # (2, C): sum g' | sum g' xhat over <= 1024 workgroup partials
         gw = psum[1] if (has_w and ctx.needs_input_grad[1]) else None
         gb = psum[0] if (has_b and ctx.needs_input_grad[2]) else None
-        return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None, None
+        return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None, None, None
 
 
 def _ln_supported(x: torch.Tensor, C: int) -> bool:
@@ -336,38 +354,44 @@ def _ln_supported(x: torch.Tensor, C: int) -> bool:
             and x.numel() > 0 and not torch.is_autocast_enabled())
 
 
-def layer_norm_rows(x, weight, bias, eps: float = 1e-5, relu: bool = False, drop: DropSpec = None) -> torch.Tensor:
+def layer_norm_rows(x, weight, bias, eps: float = 1e-5, relu: bool = False, drop: DropSpec = None, skip: bool = False):
     """LayerNorm over the last dimension of ``x`` (..., C) [+ ReLU] [+ dropout]."""
-    return _LayerNormRows.apply(x, weight, bias, float(eps), bool(relu), torch.is_grad_enabled(), drop)
+    return _LayerNormRows.apply(x, weight, bias, float(eps), bool(relu), torch.is_grad_enabled(), drop, bool(skip))
 
 
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (normalised over the last dimension only) whose fp32 device inputs run on the HIP row kernels; other
     shapes / dtypes take the stock implementation.  Same parameters and ``state_dict`` keys."""
 
-    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None):
+    def forward(self, x, fuse_relu: bool = False, drop: DropSpec = None, stats=None, skip: bool = False):
         if len(self.normalized_shape) == 1 and _ln_supported(x, self.normalized_shape[0]):
-            return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu, drop=drop)
-        return _stock_tail(super().forward(x), fuse_relu, drop)
+            return layer_norm_rows(x, self.weight, self.bias, self.eps, relu=fuse_relu, drop=drop, skip=skip)
+        y = _stock_tail(super().forward(x), fuse_relu, drop)
+        return (y, x) if skip else y
 
 
 def pre_activation(norm: nn.Module, x: torch.Tensor, p: float = 0.0, training: bool = True, mask: torch.Tensor = None,
-                   stats=None) -> torch.Tensor:
+                   stats=None, skip: bool = False):
     """``dropout(relu(norm(x)))`` -- the run in front of every convolution of the 'res+' models
     (examples/ogb/ogbn_arxiv/model.py:96-99: ``norm -> F.relu -> F.dropout(p, training)``) and of the reversible
     BasicBlock (eff_gcn_modules/rev/rev_layer.py:38-46: ``norm -> relu -> x * shared mask``) in ONE row kernel when
     ``norm`` is this package's BatchNorm1d / LayerNorm; any other module runs the three steps.
-    ``mask``: the shared dropout mask (already scaled) -- used as is, ``p`` is ignored.  ``stats``: see batch_norm_rows."""
+    ``mask``: the shared dropout mask (already scaled) -- used as is, ``p`` is ignored.  ``stats``: see batch_norm_rows.
+    ``skip``: return ``(y, x_skip)`` with ``x_skip`` = ``x`` for the skip connection AROUND the block that follows
+    (``conv(y) + x_skip``): the gradient of that connection is added inside this op's backward kernel instead of by a
+    separate accumulation pass over the (N, C) gradient."""
     if mask is not None:
         drop = DropSpec.shared(mask) if training else None
     else:
         drop = DropSpec.hashed(p) if (training and p > 0.0) else None
     if isinstance(norm, (BatchNorm1d, LayerNorm)):
-        return norm(x, fuse_relu=True, drop=drop, stats=stats)
+        return norm(x, fuse_relu=True, drop=drop, stats=stats, skip=skip)
     y = torch.relu(norm(x))
     if mask is not None:
-        return y * mask if training else y
-    return torch.nn.functional.dropout(y, p=p, training=training)
+        y = y * mask if training else y
+    else:
+        y = torch.nn.functional.dropout(y, p=p, training=training)
+    return (y, x) if skip else y
 
 
 # ---- Linear over node rows ------------------------------------------------------------------------------------------
