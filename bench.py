@@ -324,11 +324,12 @@ def extras(dev):
             ("revgcn8_reference_algorithm_stock_gemm", 8, "restated", False, "max"),
             # BASELINE.json words config 5 with power-mean aggregation (the reference's commands use max): both
             ("revgcn8_power_product", 8, "product", True, "power"),
+            ("revgcn8_power_product_keep_edge_state", 8, "product_edge", True, "power"),
             ("revgcn8_power_reference_algorithm_stock_gemm", 8, "restated", False, "power")):
         ops.FUSED_EDGE_GEMM = fused
-        gcn_revop.KEEP_AGGREGATION = impl != "product_pure"
+        gcn_revop.KEEP_AGGREGATION = {"product_pure": False, "product_edge": "edge"}.get(impl, True)
         m = rev_restated.RevGCN(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
-                                impl="product" if impl == "product_pure" else impl).to(dev).train()
+                                impl="product" if impl.startswith("product_") else impl).to(dev).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
         def rev_step():
@@ -353,7 +354,9 @@ def extras(dev):
                        f"every coupling function taking the forward's aggregation results (max: (N, C) output + arg-max "
                        f"ids per function; softmax / power need (E, C) pre-activations and launch again), "
                        f"'product_pure_recompute' = the same with every edge kernel launched again (KEEP_AGGREGATION off: "
-                       f"memory as in the reference's scheme), 'reference_algorithm_stock_gemm' "
+                       f"memory as in the reference's scheme), 'product_keep_edge_state' = KEEP_AGGREGATION = 'edge': the "
+                       f"(E, C) pre-activations of softmax / power are kept too (354 MB per GENBlock), "
+                       f"'reference_algorithm_stock_gemm' "
                        f"= the reference's inverse + recompute pattern on library GEMMs + (E,C) edge embeddings")
     rev["graph_build_ms"] = build_ms
     rev["graph_build_cold_ms"] = build_cold

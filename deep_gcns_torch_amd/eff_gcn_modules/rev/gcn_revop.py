@@ -41,7 +41,10 @@ _STATE = "_dgcn_rev_state"      # attribute on a shared argument tensor: its _Sh
 # The fused backward re-evaluates every coupling function on the input the forward gave it.  True: the aggregation
 # launches of that forward keep their node-sized results for it (ops.AggregationStash; per GENBlock of the ogbn-proteins
 # RevGCN: the (N, C) output + arg-max ids, 12 MB against 0.3 ms of edge kernel); False: launch again (memory as in the
-# reference's reversible scheme, to the byte).
+# reference's reversible scheme, to the byte); "edge": also the aggregations whose backward needs an (E, C) array of
+# the forward (softmax / power with the fused edge encoder: the pre-activations, 354 MB per GENBlock at the
+# ogbn-proteins cluster shape -- 79 GB for RevGCN-112, which a 288 GB device holds; the reversible scheme's memory
+# argument is then gone and only its arithmetic remains).
 KEEP_AGGREGATION = True
 
 
@@ -136,7 +139,7 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
         # the backward's grad-enabled evaluation of every F_i repeats this pass's: keep the aggregations' (N, C) results
         # (max / add / mean and the unfused softmax / power forms: 2 - 3 node-sized arrays per coupling function) instead
         # of launching the edge kernels again -- KEEP_AGGREGATION = False restores the pure recomputation
-        ctx.stashes = (module.new_stashes() if ctx.fused and KEEP_AGGREGATION
+        ctx.stashes = (module.new_stashes(node_sized_only=KEEP_AGGREGATION != "edge") if ctx.fused and KEEP_AGGREGATION
                        and hasattr(module, "new_stashes") and any(ctx.needs_input_grad) else None)
         with torch.no_grad():
             if ctx.stashes is not None:

@@ -23,9 +23,9 @@ class GroupAdditiveCoupling(torch.nn.Module):
         per_arg = [torch.chunk(a, self.group, dim=self.split_dim) for a in args]
         return list(zip(*per_arg))                      # [group][arg]
 
-    def new_stashes(self):
+    def new_stashes(self, node_sized_only: bool = True):
         """One ops.AggregationStash per coupling function (see ``forward(..., _stashes)``)."""
-        return [ops.AggregationStash(node_sized_only=True) for _ in range(self.group)]
+        return [ops.AggregationStash(node_sized_only=node_sized_only) for _ in range(self.group)]
 
     def forward(self, x, edge_index, *args, _stashes=None):
         """_stashes (the reversible wrapper's no_grad forward only): the aggregation launches of F_i record their

@@ -78,7 +78,7 @@ def test_restated_reversible_wrapper_matches_reference_on_cpu(case, impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["restated", "product", "product_pure_recompute"])
+@pytest.mark.parametrize("impl", ["restated", "product", "product_pure_recompute", "product_keep_edge_state"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
 def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
     """Forward under no_grad, freed input storage, inverse, recompute with grad: everything the reference's
@@ -89,7 +89,7 @@ def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
     assert torch.cuda.is_available()
     from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
     keep = gcn_revop.KEEP_AGGREGATION
-    gcn_revop.KEEP_AGGREGATION = impl != "product_pure_recompute"
+    gcn_revop.KEEP_AGGREGATION = {"product_pure_recompute": False, "product_keep_edge_state": "edge"}.get(impl, True)
     try:
         hn, grads = _run(case, torch.device("cuda:0"), "product" if impl.startswith("product") else impl)
     finally:
