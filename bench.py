@@ -320,6 +320,9 @@ def extras(dev):
     rev = {}
     for name, layers, impl, fused, aggr in (
             ("revgcn112_product", 112, "product", True, "max"), ("revgcn8_product", 8, "product", True, "max"),
+            ("revgcn112_product_composed_edge_encoders", 112, "product_composed", True, "max"),
+            ("revgcn8_product_composed_edge_encoders", 8, "product_composed", True, "max"),
+            ("revgcn8_power_product_composed_edge_encoders", 8, "product_composed", True, "power"),
             ("revgcn8_product_pure_recompute", 8, "product_pure", True, "max"),
             ("revgcn8_reference_algorithm_stock_gemm", 8, "restated", False, "max"),
             # BASELINE.json words config 5 with power-mean aggregation (the reference's commands use max): both
@@ -329,7 +332,8 @@ def extras(dev):
         ops.FUSED_EDGE_GEMM = fused
         gcn_revop.KEEP_AGGREGATION = {"product_pure": False, "product_edge": "edge"}.get(impl, True)
         m = rev_restated.RevGCN(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
-                                impl="product" if impl.startswith("product_") else impl).to(dev).train()
+                                impl="product" if impl.startswith("product_") else impl,
+                                composed_edges=impl == "product_composed").to(dev).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
         def rev_step():
@@ -346,6 +350,9 @@ def extras(dev):
     gcn_revop.KEEP_AGGREGATION = True
     rev["speedup_per_layer_vs_reference_algorithm_on_stock_gemm"] = (
         rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_product"]["ms_per_layer"])
+    rev["speedup_per_layer_composed_edge_encoders_vs_reference_algorithm"] = (
+        rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"]
+        / rev["revgcn8_product_composed_edge_encoders"]["ms_per_layer"])
     rev["speedup_per_layer_power_aggregation"] = (
         rev["revgcn8_power_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_power_product"]["ms_per_layer"])
     rev["workload"] = (f"RevGCN hidden=224 group=2 gcn_aggr=max (the README's commands; *_power_* rows: power) conv_encode_edge (ogb_eff/ogbn_proteins/model_rev.py) on a "

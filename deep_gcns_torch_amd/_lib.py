@@ -58,6 +58,16 @@ _SIGNATURES = {
         C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
         C.c_void_p]),
+    "dgcn_gen_aggr_enc_fwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_gen_aggr_enc_bwd_num_partials": (C.c_int32, [C.POINTER(DgcnGraph), C.c_int32]),
+    "dgcn_gen_aggr_enc_bwd_f32": (C.c_int, [
+        C.POINTER(DgcnGraph), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_gen_aggr_egemm_supported": (C.c_int32, [C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_f32": (C.c_int, [

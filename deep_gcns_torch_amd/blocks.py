@@ -26,7 +26,7 @@ from torch.utils.checkpoint import checkpoint
 
 from . import node_ops, ops
 
-__all__ = ["res_plus_layer", "ResPlusLayer"]
+__all__ = ["res_plus_layer", "ResPlusLayer", "ComposedEdgeEmbedding"]
 
 
 def _conv_res(conv, h2, edge_index, edge_attr, h, want_stats):
@@ -81,3 +81,62 @@ class ResPlusLayer(torch.nn.Module):
     def forward(self, h, edge_index, edge_attr=None, stats=None):
         return res_plus_layer(self.norm, self.conv, h, edge_index, edge_attr, p=self.dropout, training=self.training,
                               stats=stats, use_checkpoint=self.use_checkpoint)
+
+
+class ComposedEdgeEmbedding:
+    """``edge_encoder(edge_attr)`` [repeated ``repeat`` times along the feature axis] WITHOUT building it.
+
+    The reference's models with edge features apply two Linear maps in a row to the 8 raw edge features, with nothing in
+    between: the model-level ``edge_emb = self.edge_encoder(edge_attr)`` -- Linear(8 -> hidden), repeated per group in
+    the reversible models (examples/ogb_eff/ogbn_proteins/model_rev.py:98-100; ogbn_proteins/model.py:103-107) -- and
+    every GENConv's own ``edge_encoder`` = Linear(hidden -> C) (gcn_lib/sparse/torch_vertex.py:56-66).  Their
+    composition is ONE Linear(8 -> C) per layer: ``W' = W_l We``, ``b' = W_l be + b_l`` (two tiny products, written
+    with autograd ops so that the gradients of both layers follow).  A GENConv that receives this object instead of the
+    (E, hidden) tensor evaluates ``W' f_e + b'`` per edge inside the aggregation kernels from the 32 raw bytes
+    (dgcn_gen_aggr_enc_{fwd,bwd}_f32): neither the (E, hidden) embedding, nor the per-layer (E, hidden) x (hidden, C)
+    GEMM, nor the (E, hidden) gradient accumulated over the layers exist any more.  The model's lines become
+
+        edge_emb = ComposedEdgeEmbedding(self.edge_encoder, edge_attr, repeat=self.group)
+
+    Same function of the same parameters (the two roundings of ``(A We) W_l`` become one of ``A (We W_l)``).  Consumers
+    that cannot fuse (another convolution, a non-Linear encoder, CPU tensors) call ``materialize()``."""
+
+    def __init__(self, encoder: torch.nn.Linear, edge_attr: torch.Tensor, repeat: int = 1):
+        if not isinstance(encoder, torch.nn.Linear):
+            raise TypeError("ComposedEdgeEmbedding: the model-level edge encoder must be an nn.Linear")
+        if edge_attr.dim() != 2 or edge_attr.size(1) != encoder.in_features:
+            raise ValueError("edge_attr must be (E, encoder.in_features)")
+        self.encoder = encoder
+        self.raw = edge_attr.detach()
+        self.repeat = int(repeat)
+        self._full = None
+
+    # -- what the reversible wrapper / the coupling need from an argument --------------------------------------------
+    def parameters(self):
+        return [p for p in self.encoder.parameters() if p.requires_grad]
+
+    def group_view(self, i: int, groups: int):
+        """Chunk ``i`` of ``groups`` along the feature axis: every chunk of a repeated embedding is the embedding."""
+        if groups != self.repeat:
+            raise ValueError(f"embedding repeated {self.repeat}x cannot be split into {groups} groups")
+        return self if self.repeat == 1 else ComposedEdgeEmbedding(self.encoder, self.raw, 1)
+
+    @property
+    def hidden(self) -> int:
+        return self.encoder.out_features
+
+    def composed(self, layer_encoder: torch.nn.Linear):
+        """(W', b') of ``layer_encoder(encoder(.))`` for a per-layer Linear(hidden -> C)."""
+        if self.repeat != 1:
+            raise ValueError("compose a group view, not the repeated embedding")
+        w = layer_encoder.weight @ self.encoder.weight                               # (C, 8)
+        b = None
+        if self.encoder.bias is not None:
+            b = layer_encoder.weight @ self.encoder.bias
+        if layer_encoder.bias is not None:
+            b = layer_encoder.bias if b is None else b + layer_encoder.bias
+        return w, b
+
+    def materialize(self) -> torch.Tensor:
+        e = self.encoder(self.raw)
+        return e if self.repeat == 1 else torch.cat([e] * self.repeat, dim=-1)

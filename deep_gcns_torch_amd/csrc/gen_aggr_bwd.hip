@@ -1,7 +1,7 @@
 // Sparse generalized aggregation for gfx950 (MI355X): backward (see gen_aggr_fwd.hip for the execution shape).
 //
-// Walks the CSC (rows = sources) with the same one-wave-per-item scheme and produces grad_x (and grad_edge_attr) in one
-// deterministic pass; softmax takes the single-gather form
+// Walks the CSC (rows = sources) with the same one-wave-per-item scheme and produces grad_x (and grad_edge_attr,
+// or the fused edge encoder's dW | db partials) in one deterministic pass; softmax takes the single-gather form
 // prepared by softmax_bwd_prep_kernel when the forward's range flag allows it.
 
 #include "gen_aggr_common.h"
@@ -19,8 +19,16 @@ template <int MODE, int VEC, int LPR, int SW, int EA>
 __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
   constexpr int G = SW / LPR;
   constexpr int R = kWave / SW;
-  constexpr int U = (VEC == 4) ? 4 : 8;
+  constexpr int U = (EA == 2) ? 2 : ((VEC == 4) ? 4 : 8);   // EA == 2 keeps U feature rows + 9 VEC sums live
   constexpr bool NEED_EID = EA != 0 || MODE == DGCN_AGGR_MAX;
+  constexpr int EV = (EA == 2) ? VEC : 1;
+  EncW<EV> enc, genc;       // encoder weights of this lane's channels, and the sums dW | db over this wave's edges
+#pragma unroll
+  for (int j = 0; j < EV; ++j) {
+    genc.b[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) genc.w[j][f] = 0.f;
+  }
 
   const int lane = lane_id();
   const int sl = lane % SW;
@@ -95,6 +103,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
       if constexpr (MODE == kModeSoftmaxShifted) {
         if (act) load_vec<VEC>(ksh, P.kshift + c0);
       }
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0, act);
 
       int mycol = col0, myeid = eid0;
       for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
@@ -111,6 +120,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
         }
         for (int s0 = 0; any_sub<SW>(s0 < nb); s0 += G * U) {
           float gc[U][VEC], a1[U][VEC], oo[U][VEC], ea[U][VEC];
+          float fe[(EA == 2) ? U : 1][kEncF];
           int ai[U][VEC];
           bool ok[U];
           int eid[U];
@@ -161,6 +171,7 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
                   load_vec<VEC>(ea[u], P.ea + static_cast<int64_t>(eid[u]) * C + c0);
                 }
               }
+              if constexpr (EA == 2) enc_feat_row(fe[u], P.enc_feat, eid[u]);
             }
           }
           if constexpr (MODE == DGCN_AGGR_MAX) {
@@ -178,6 +189,9 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
           for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
             float dz[VEC];
+            if constexpr (EA == 2) {
+              if (act) enc_apply<VEC>(ea[u], enc, fe[u]);
+            }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
               const float z = (EA != 0) ? xs[j] + ea[u][j] : xs[j];   // xs == 0 when the edge rows are z itself
@@ -206,6 +220,16 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
             if constexpr (EA == 1) {
               if (act && P.grad_ea) {
                 store_vec<VEC>(P.grad_ea + static_cast<int64_t>(eid[u]) * C + c0, dz);
+              }
+            }
+            if constexpr (EA == 2) {
+              if (act) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                  genc.b[j] += dz[j];
+#pragma unroll
+                  for (int f = 0; f < kEncF; ++f) genc.w[j][f] = fmaf(dz[j], fe[u][f], genc.w[j][f]);
+                }
               }
             }
           }
@@ -243,6 +267,37 @@ __device__ __forceinline__ void gen_aggr_bwd_body(const BwdParams& P) {
 #endif
   }
 
+  if constexpr (EA == 2) {
+    // dW | db of this workgroup: lanes with the same channel group (cl) are summed with shuffles, the four waves
+    // through LDS in a fixed order, and the workgroup writes one (C, kEncF + 1) partial; the host sums the partials.
+    constexpr int NV = VEC * (kEncF + 1);
+    __shared__ float red[kWavesPerWg][LPR * NV];
+    float vals[NV];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+      for (int f = 0; f < kEncF; ++f) vals[j * (kEncF + 1) + f] = genc.w[j][f];
+      vals[j * (kEncF + 1) + kEncF] = genc.b[j];
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) vals[q] += __shfl_xor(vals[q], off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane < LPR) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) red[wv][lane * NV + q] = vals[q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LPR * NV; i += kWgThreads) {
+      const int ch = (i / NV) * VEC + (i % NV) / (kEncF + 1);
+      if (ch < C) {
+        const float tsum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+        P.enc_gpart[(static_cast<int64_t>(blockIdx.x) * C + ch) * (kEncF + 1) + (i % NV) % (kEncF + 1)] = tsum;
+      }
+    }
+  }
 }
 
 template <int MODE, int VEC, int LPR, int SW, int EA>
@@ -330,6 +385,12 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
 
 template <int MODE, int VEC, int LPR, int SW>
 void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {
+      hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 2>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
   if (P.ea || P.ea_is_z) {
     hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 1>), dim3(grid), dim3(kWgThreads), 0, s, P);
   } else {
@@ -361,11 +422,13 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
 }
 
 
-int bwd_grid(const dgcn_graph* g, int channels, bool vec4) {
+int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
   const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
   const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src), g->n_edges) : 1;
   const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
-  return round_up8(grid_for_waves(n_items));
+  int grid = round_up8(grid_for_waves(n_items));
+  if (enc && grid > kEncMaxParts) grid = kEncMaxParts;
+  return grid;
 }
 
 // Arg-max bit masks for the max backward: bit c of mask[p] says whether CSR position p is the arg-max of its destination
@@ -445,7 +508,7 @@ inline int max_mask_words(int channels) {
 }
 
 int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
-                      const float* edge_attr, int32_t channels, int32_t mode,
+                      const float* edge_attr, const EncArgs* enc, float* enc_gpart, int32_t channels, int32_t mode,
                       int32_t msg, int32_t flags, float t, float p, float eps,
                       const float* t_dev, const float* p_dev, const float* gcoef,
                       const void* aux1, const float* out, const float* gshift,
@@ -455,9 +518,11 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
                       const int32_t* t_cpos = nullptr) {
   const bool ea_is_z = (flags & DGCN_FLAG_EA_IS_Z) != 0;
   // max needs no pre-activations at all (the forward's arg-max ids carry the relu mask): edge_attr may be NULL there
-  if (ea_is_z && !edge_attr && mode != DGCN_AGGR_MAX) return DGCN_E_MODE;
+  if (ea_is_z && (enc || (!edge_attr && mode != DGCN_AGGR_MAX))) return DGCN_E_MODE;
   if (ea_is_z && !x) { x = gcoef; x_stride = channels; }        // never read: the rows of edge_attr are z_e itself
   if (!g || !x || !gcoef || !grad_x) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
+  if (enc && !enc_gpart) return DGCN_E_NULL;
   if (g->n_src < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
   if (mode < DGCN_AGGR_ADD || mode > DGCN_AGGR_POWER) return DGCN_E_MODE;
   if (msg != DGCN_MSG_IDENTITY && msg != DGCN_MSG_RELU_EPS) return DGCN_E_MODE;
@@ -488,20 +553,25 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.gcoef = gcoef; P.aux1 = aux1; P.out = out; P.grad_x = grad_x; P.grad_ea = grad_edge_attr;
   P.gshift = nullptr; P.kshift = nullptr; P.shift_ok = nullptr; P.shift_bad = 0;
   P.groot = groot;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
+  P.enc_gpart = enc_gpart;
   P.n_edges_hint = g->n_edges;
   P.maxmask = nullptr; P.mask_words = 0;
   if (maxmask) {
-    if (mode != DGCN_AGGR_MAX || edge_attr || ea_is_z || !t_cpos || channels > 256) return DGCN_E_MODE;
+    if (mode != DGCN_AGGR_MAX || edge_attr || enc || ea_is_z || !t_cpos || channels > 256) return DGCN_E_MODE;
     P.maxmask = maxmask; P.mask_words = max_mask_words(channels);
     P.g.eperm = t_cpos;            // the walk's "edge id" is the CSR position: the index of the mask rows
   }
+  if (enc && !vec4) return DGCN_E_ALIGN;
   if (mode == DGCN_AGGR_SOFTMAX && gshift && kshift && shift_ok && vec4 && aligned16(gshift) && aligned16(kshift)) {
     P.gshift = gshift; P.kshift = kshift; P.shift_ok = shift_ok;
     P.shift_bad = (flags & DGCN_FLAG_SHIFT_FLAG_IS_RANGE) ? 1 : 0;
   }
   P.ws = static_cast<float*>(workspace);
 
-  const int grid = bwd_grid(g, channels, vec4);
+  const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (mode) {
     case DGCN_AGGR_ADD: launch_bwd_mode<DGCN_AGGR_ADD>(P, vec, lpr, grid, s); break;
@@ -560,7 +630,7 @@ extern "C" int dgcn_gen_aggr_bwd_f32(const dgcn_graph* g, const float* x, int64_
                                      const float* kshift, const int32_t* shift_ok, const float* groot,
                                      float* grad_x, float* grad_edge_attr, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  return gen_aggr_bwd_impl(g, x, x_stride, edge_attr, channels, mode, msg, flags, t, p, eps, t_dev,
+  return gen_aggr_bwd_impl(g, x, x_stride, edge_attr, nullptr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev,
                            p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, grad_edge_attr,
                            workspace, workspace_bytes, stream);
 }
@@ -589,7 +659,28 @@ extern "C" int dgcn_gen_aggr_max_bwd_f32(const dgcn_graph* g, const int32_t* t_c
     default: hipLaunchKernelGGL(max_mask_build_kernel<8>, grid, wg, 0, s, argmax, g->rowptr, g->eperm, g->n_dst, channels, m); break;
   }
   if (const int rc = launch_status()) return rc;
-  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, channels, DGCN_AGGR_MAX, msg, flags, 1.f, 1.f, eps,
+  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, nullptr, nullptr, channels, DGCN_AGGR_MAX, msg, flags, 1.f, 1.f, eps,
                            nullptr, nullptr, gcoef, argmax, nullptr, nullptr, nullptr, nullptr, groot, grad_x, nullptr,
                            workspace, workspace_bytes, stream, m, t_cpos);
 }
+
+extern "C" int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels) {
+  if (!g || channels <= 0 || channels % 4 != 0 || g->n_src <= 0) return 0;
+  return bwd_grid(g, channels, true, true);
+}
+
+extern "C" int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, const float* gcoef, const void* aux1,
+                                         const float* out, const float* gshift, const float* kshift,
+                                         const int32_t* shift_ok, const float* groot, float* grad_x,
+                                         float* enc_grad_partials, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_bwd_impl(g, x, x_stride, nullptr, &enc, enc_grad_partials, channels, mode, msg, flags, t, p, eps,
+                           t_dev, p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, nullptr,
+                           workspace, workspace_bytes, stream);
+}
+

@@ -1,5 +1,5 @@
 // Shared pieces of the sparse generalized aggregation kernels (gen_aggr_fwd.hip / gen_aggr_bwd.hip): walk
-// descriptors, the per-item software pipeline helpers and the host-side layout choices.
+// descriptors, the per-item software pipeline helpers, the fused edge encoder and the host-side layout choices.
 // Everything lives in an anonymous namespace: each translation unit gets its own copy.
 // Tuning-build switches (compile-time, not defined in the shipped build): DGCN_G (edge groups per row), DGCN_FWD_U
 // (load batches in flight), DGCN_FWD_WPE / DGCN_FWD_WAVES_PER_CU (occupancy / grid), DGCN_NO_PREFETCH / DGCN_NO_PREFETCH_BWD (item
@@ -46,6 +46,9 @@ struct FwdParams {
   float* aux2;
   int32_t* range_flag;  // softmax: set to 1 when some |L_i| >= kShiftSafe (the backward then gathers two rows)
   int add_root;         // out_i += x_i (the GENConv residual h = x + m fused into the epilogue)
+  const float* enc_feat;  // EA == 2: raw edge features [E, kEncF] in original edge order; e_e = enc_w f_e + enc_b
+  const float* enc_w;     // [C, kEncF] (nn.Linear weight)
+  const float* enc_b;     // [C] or null
   int n_edges_hint;     // edges of the walk (layout choice only)
   float* ws;  // partial slots: [slot][4][C]
 };
@@ -70,6 +73,10 @@ struct BwdParams {
   const int32_t* shift_ok;  // device flag: the shifted form is numerically safe for this call iff *shift_ok != shift_bad
   int shift_bad;            // 0: flag means "ok"; 1: flag is the forward's range_flag (nonzero = NOT safe)
   const float* groot;     // [n_src, C] upstream gradient added to grad_x (backward of add_root) or null
+  const float* enc_feat;  // EA == 2: see FwdParams
+  const float* enc_w;
+  const float* enc_b;
+  float* enc_gpart;       // EA == 2: [gridDim.x][C][kEncF + 1] per-workgroup partial (dW | db)
   float* grad_x;
   float* grad_ea;
   int n_edges_hint;       // edges of the walk (layout choice only)
@@ -152,12 +159,53 @@ __device__ __forceinline__ float fast_pow(float u, float p) {  // u > 0
   return fast_exp2(p * fast_log2(u));
 }
 
+// ---- fused edge encoder (EA == 2): e_e = W f_e + b with kEncF raw features per edge -------------------------
+// GENConv(encode_edge=True) builds edge_emb = Linear(edge_feat_dim -> C)(edge_attr), an (E, C) tensor written by
+// a GEMM and read back by the aggregation (gcn_lib/sparse/torch_vertex.py:56-66).  With 8 raw features per edge
+// (ogbn-proteins) the row is cheaper to recompute per edge from 32 bytes than to load as 4C bytes.
+constexpr int kEncF = 8;
+
+template <int VEC>
+struct EncW {
+  float w[VEC][kEncF];
+  float b[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ void enc_load(EncW<VEC>& e, const float* __restrict__ W, const float* __restrict__ b,
+                                         int c0, bool act) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    e.b[j] = (act && b) ? b[c0 + j] : 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) e.w[j][f] = act ? W[(c0 + j) * kEncF + f] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void enc_feat_row(float (&fe)[kEncF], const float* __restrict__ feat, int eid) {
+  const float4* p = reinterpret_cast<const float4*>(feat + static_cast<int64_t>(eid) * kEncF);
+  const float4 a = p[0], b = p[1];
+  fe[0] = a.x; fe[1] = a.y; fe[2] = a.z; fe[3] = a.w;
+  fe[4] = b.x; fe[5] = b.y; fe[6] = b.z; fe[7] = b.w;
+}
+
+template <int VEC>
+__device__ __forceinline__ void enc_apply(float (&out)[VEC], const EncW<VEC>& e, const float (&fe)[kEncF]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float a = e.b[j];
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) a = fmaf(e.w[j][f], fe[f], a);
+    out[j] = a;
+  }
+}
+
 // Address of row `src`: a 32x32->64 multiply (one v_mad_u64_u32); the host checks 0 <= stride < 2^31.
 __device__ __forceinline__ const float* row_ptr(const float* base, int src, uint32_t stride) {
   return base + static_cast<uint64_t>(static_cast<uint32_t>(src)) * stride;
 }
 
-// EA: 0 = no edge features, 1 = dense (E, C) edge features (wide raw features: the fused edge GEMM, gen_aggr_egemm.hip)
+// EA: 0 = no edge features, 1 = dense (E, C) edge features, 2 = encoded on the fly from kEncF raw features
 // ---------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------
@@ -195,6 +243,23 @@ inline int subgroup_width(int lpr, int64_t n_items, int64_t n_edges = -1) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+struct EncArgs {
+  const float* feat;
+  const float* w;
+  const float* b;
+  int n_feat;
+};
+
+constexpr int kEncMaxParts = 1024;   // workgroups (= partial dW|db blocks) of the encoded backward
+
+inline int enc_check(const EncArgs* enc, int channels) {
+  if (!enc) return DGCN_OK;
+  if (!enc->feat || !enc->w) return DGCN_E_NULL;
+  if (enc->n_feat != kEncF || channels % 4 != 0 || channels > 256) return DGCN_E_SHAPE;
+  if (!aligned16(enc->feat) || !aligned16(enc->w)) return DGCN_E_ALIGN;
+  return DGCN_OK;
+}
 
 }  // namespace
 }  // namespace dgcn

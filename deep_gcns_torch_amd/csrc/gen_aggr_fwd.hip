@@ -75,6 +75,8 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
       const bool act = c0ch < C;
       State<VEC> st;
       state_init<MODE, VEC>(st);
+      EncW<(EA == 2 ? VEC : 1)> enc;
+      if constexpr (EA == 2) enc_load<VEC>(enc, P.enc_w, P.enc_b, c0ch, act);
 
       int mycol = col0, myeid = eid0;
       for (int blk = w.beg; any_sub<SW>(blk < w.end); blk += SW) {
@@ -100,6 +102,13 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
               }
+              if constexpr (EA == 2) {
+                float fe[kEncF], a[VEC];
+                enc_feat_row(fe, P.enc_feat, eid[u]);
+                enc_apply<VEC>(a, enc, fe);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+              }
             }
             accumulate<MODE, VEC, U, RELU, WITH_D, true>(st, v, ok, eid, eps, t2, c0, p);
           } else {
@@ -117,6 +126,13 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
                 if constexpr (EA == 1) {
                   float a[VEC];
                   load_vec<VEC>(a, P.ea + static_cast<int64_t>(eid[u]) * C + c0ch);
+#pragma unroll
+                  for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
+                }
+                if constexpr (EA == 2) {
+                  float fe[kEncF], a[VEC];
+                  enc_feat_row(fe, P.enc_feat, eid[u]);
+                  enc_apply<VEC>(a, enc, fe);
 #pragma unroll
                   for (int j = 0; j < VEC; ++j) v[u][j] += a[j];
                 }
@@ -310,6 +326,12 @@ void launch_fwd_d(const FwdParams& P, int grid, hipStream_t s) {
 
 template <int MODE, int VEC, int LPR, int SW>
 void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
+  if constexpr (VEC == 4) {
+    if (P.enc_feat) {   // fused edge encoder: float4 layouts only (the host entry point checks)
+      launch_fwd_d<MODE, VEC, LPR, SW, 2>(P, grid, s);
+      return;
+    }
+  }
   if (P.ea) {
     launch_fwd_d<MODE, VEC, LPR, SW, 1>(P, grid, s);
   } else {
@@ -342,12 +364,13 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
 
 
 int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
-                      const float* edge_attr, int32_t channels, int32_t mode,
+                      const float* edge_attr, const EncArgs* enc, int32_t channels, int32_t mode,
                       int32_t msg, int32_t flags, float t, float p, float eps,
                       const float* t_dev, const float* p_dev, float* out,
                       void* aux1, float* aux2, int32_t* range_flag, void* workspace,
                       size_t workspace_bytes, void* stream) {
   if (!g || !x || !out) return DGCN_E_NULL;
+  if (const int rc = enc_check(enc, channels)) return rc;
   if ((flags & DGCN_FLAG_ADD_ROOT) && g->n_dst > g->n_src) return DGCN_E_SHAPE;   // root rows are x[0 .. n_dst)
   if (g->n_dst < 0 || g->n_edges < 0 || channels <= 0 || x_stride < channels) return DGCN_E_SHAPE;
   if (x_stride > 0x7fffffffLL) return DGCN_E_SHAPE;   // row addresses use a 32x32->64 multiply
@@ -374,7 +397,11 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.out = out; P.aux1 = aux1; P.aux2 = aux2; P.ws = static_cast<float*>(workspace);
   P.range_flag = (mode == DGCN_AGGR_SOFTMAX) ? range_flag : nullptr;
   P.add_root = (flags & DGCN_FLAG_ADD_ROOT) ? 1 : 0;
+  P.enc_feat = enc ? enc->feat : nullptr;
+  P.enc_w = enc ? enc->w : nullptr;
+  P.enc_b = enc ? enc->b : nullptr;
   P.n_edges_hint = g->n_edges;
+  if (enc && !vec4) return DGCN_E_ALIGN;
 
   const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->n_work ? g->n_work : g->n_dst), g->n_edges) : 1;   // items walked side by side by one wave
   const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
@@ -411,6 +438,19 @@ extern "C" int dgcn_gen_aggr_fwd_f32(const dgcn_graph* g, const float* x, int64_
                                      const float* t_dev, const float* p_dev, float* out,
                                      void* aux1, float* aux2, int32_t* range_flag, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  return gen_aggr_fwd_impl(g, x, x_stride, edge_attr, channels, mode, msg, flags, t, p, eps, t_dev, p_dev,
+  return gen_aggr_fwd_impl(g, x, x_stride, edge_attr, nullptr, channels, mode, msg, flags, t, p, eps, t_dev, p_dev,
                            out, aux1, aux2, range_flag, workspace, workspace_bytes, stream);
 }
+
+extern "C" int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride,
+                                         const float* enc_feat, const float* enc_weight, const float* enc_bias,
+                                         int32_t n_feat, int32_t channels, int32_t mode, int32_t msg,
+                                         int32_t flags, float t, float p, float eps, const float* t_dev,
+                                         const float* p_dev, float* out, void* aux1, float* aux2,
+                                         int32_t* range_flag, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  const EncArgs enc{enc_feat, enc_weight, enc_bias, n_feat};
+  return gen_aggr_fwd_impl(g, x, x_stride, nullptr, &enc, channels, mode, msg, flags, t, p, eps, t_dev, p_dev, out,
+                           aux1, aux2, range_flag, workspace, workspace_bytes, stream);
+}
+

@@ -262,6 +262,12 @@ class InvertibleModuleWrapper(nn.Module):
 
     def _apply_reversible(self, f, f_inv, keep, args):
         weights = tuple(p for p in self._fn.parameters() if p.requires_grad)
+        # an argument that stands for a function of parameters (blocks.ComposedEdgeEmbedding: the model-level edge
+        # encoder) brings them along: their gradients leave through the same route as the block's own weights
+        for a in args:
+            if not isinstance(a, torch.Tensor) and hasattr(a, "parameters") and hasattr(a, "group_view"):
+                known = {id(w) for w in weights}
+                weights = weights + tuple(p for p in a.parameters() if id(p) not in known)
         if torch.is_grad_enabled() and hasattr(self._fn, "fused_backward"):
             for t in args[2:]:                        # tensors every layer receives: one delivery hook per tensor
                 if _is_shared_arg(t):

@@ -20,7 +20,9 @@ class GroupAdditiveCoupling(torch.nn.Module):
         self.group = group
 
     def _arg_chunks(self, args):
-        per_arg = [torch.chunk(a, self.group, dim=self.split_dim) for a in args]
+        # (an argument object with group_view -- blocks.ComposedEdgeEmbedding -- hands out its own group views)
+        per_arg = [[a.group_view(i, self.group) for i in range(self.group)] if hasattr(a, "group_view")
+                   else torch.chunk(a, self.group, dim=self.split_dim) for a in args]
         return list(zip(*per_arg))                      # [group][arg]
 
     def new_stashes(self, node_sized_only: bool = True):
@@ -118,6 +120,8 @@ class GroupAdditiveCoupling(torch.nn.Module):
                             s = sink_of[id(a)]
                             views.append(None if s is None else s[i])
                         call_args.append(c)
+                    elif hasattr(a, "group_view"):
+                        call_args.append(a.group_view(i, g))
                     else:
                         call_args.append(a)
                 ctxs = [sink_ctx(c, v) for c, v in zip(leaves, views) if v is not None]
@@ -136,6 +140,9 @@ class GroupAdditiveCoupling(torch.nn.Module):
                         total = gys[i] if carry is None else gys[i] + carry
                     gx[i] = total
                     params = [p for p in Fm.parameters() if p.requires_grad]
+                    for a in args:                     # parameters behind an argument object (see _arg_chunks)
+                        if not isinstance(a, torch.Tensor) and hasattr(a, "group_view"):
+                            params += [p for p in a.parameters() if all(p is not q for q in params)]
                     grads = torch.autograd.grad(out, [leaf] + leaves + params, total, allow_unused=True)
                 finally:
                     for cm in reversed(ctxs):

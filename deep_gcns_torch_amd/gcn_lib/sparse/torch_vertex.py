@@ -9,7 +9,7 @@ hot path does not name; they are exposed only when torch_geometric is importable
 import torch
 from torch import nn
 
-from ... import ops
+from ... import blocks, ops
 from ...graph import graph_of
 from .torch_edge import DilatedKnnGraph
 from .torch_message import GenMessagePassing, MsgNorm
@@ -46,7 +46,18 @@ class GENConv(GenMessagePassing):
         layer's BatchNorm1d takes (None when the row kernel did not run): its statistics pass disappears."""
         root = self.msg_norm is None and self.fusable_root() and x.dim() == 2      # h = x + m inside the kernel
         enc = None
-        if self.encode_edge and edge_attr is not None:
+        if isinstance(edge_attr, blocks.ComposedEdgeEmbedding):
+            # two Linear maps in a row on the raw edge features: composed, evaluated per edge inside the kernels
+            ce = edge_attr
+            lin = getattr(self, "edge_encoder", None)
+            if (self.encode_edge and isinstance(lin, nn.Linear) and ce.repeat == 1 and x.is_cuda and x.dim() == 2
+                    and ops.encoder_fusable(x, ce.raw, None, narrow=True)):
+                enc, edge_attr = ce.composed(lin), ce.raw
+            else:
+                edge_attr = ce.materialize()
+        if enc is not None:
+            edge_emb = edge_attr
+        elif self.encode_edge and edge_attr is not None:
             lin = self.edge_encoder
             if isinstance(lin, nn.Linear) and x.is_cuda and ops.encoder_fusable(x, edge_attr, lin.weight):
                 enc, edge_emb = (lin.weight, lin.bias), edge_attr              # Linear(hidden -> C) inside the kernels

@@ -21,6 +21,7 @@ _MODES = {
     "power": _lib.AGGR_POWER, "power_sum": _lib.AGGR_POWER,
 }
 POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
+ENC_FEATURES = 8                   # raw edge features of the per-edge encoder (kEncF in csrc/gen_aggr_common.h)
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
@@ -189,7 +190,10 @@ class _GenAggregate(torch.autograd.Function):
             enc_b = None if enc_b is None else enc_b.float().contiguous()
             if enc_feat.dim() != 2 or enc_feat.size(0) != graph.n_edges or enc_w.shape != (C, n_feat):
                 raise ValueError("fused edge encoder: features (E, F), weight (C, F)")
-            if graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
+            if n_feat == ENC_FEATURES and C % 4 == 0 and C <= 256:
+                # narrow features: every edge recomputes W f_e + b from its 32 bytes (csrc/gen_aggr_common.h, EA == 2)
+                enc_feat = enc_feat.float().contiguous()
+            elif graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
                 egemm = True
                 enc_feat = _feat_rows(enc_feat)
             else:
@@ -258,13 +262,20 @@ class _GenAggregate(torch.autograd.Function):
                     enc_feat.stride(0), enc_w.data_ptr(), _lib.ptr(enc_b), n_feat, C, mode, msg, flags, t_val, p_val,
                     eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2),
                     _lib.ptr(range_flag), _lib.ptr(z_save), ws.data_ptr(), ws_bytes, _lib.current_stream_handle(dev))
+            elif enc:
+                rc = lib.dgcn_gen_aggr_enc_fwd_f32(
+                    graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
+                    ENC_FEATURES, C, mode, msg, flags, t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                    out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
+                    _lib.current_stream_handle(dev))
             else:
                 rc = lib.dgcn_gen_aggr_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), _lib.ptr(edge_attr), C, mode, msg, flags,
                     t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param), out.data_ptr(),
                     _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
-        _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else "dgcn_gen_aggr_fwd_f32")
+        _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
+                   ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
         if record:
             stash.items.append(((graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root),
                                 (out, aux1, aux2, range_flag, z_save)))
@@ -318,7 +329,9 @@ class _GenAggregate(torch.autograd.Function):
         grad_x = grad_ea = grad_w = grad_b = grad_feat = None
         egemm = ctx.egemm
         need_dz = egemm and any(ctx.needs_input_grad[14:17])
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz:
+        enc = None if egemm else ctx.enc                  # narrow per-edge encoder: dW | db partials, no (E, C) array
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
+                (enc is not None and any(ctx.needs_input_grad[15:17])):
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
             if (edge_attr is not None or egemm) and (ctx.needs_input_grad[1] or need_dz):
@@ -341,7 +354,17 @@ class _GenAggregate(torch.autograd.Function):
                                                        _lib.current_stream_handle(dev))
                 _lib.check(rc, "dgcn_softmax_bwd_prep_f32")
             with _lib.device_ctx(dev):
-                if mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
+                if enc is not None:
+                    feat, w_enc, b_enc = enc
+                    nparts = lib.dgcn_gen_aggr_enc_bwd_num_partials(graph.c_struct, C)
+                    gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
+                    rc = lib.dgcn_gen_aggr_enc_bwd_f32(
+                        graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
+                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
+                        _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
+                        _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
+                        grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+                elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
                         graph.n_dst * C * 4 >= MAX_MASK_MIN_TABLE_BYTES and graph.n_edges > 0:
                     # arg-max bit masks per edge instead of gathered arg-max rows (big graphs: the table misses the caches)
                     mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
@@ -358,7 +381,13 @@ class _GenAggregate(torch.autograd.Function):
                         gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift), _lib.ptr(kshift),
                         _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None, grad_x.data_ptr(),
                         _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
-            _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
+            _lib.check(rc, "dgcn_gen_aggr_enc_bwd_f32" if enc is not None else "dgcn_gen_aggr_bwd_f32")
+            if enc is not None:
+                gsum = gpart.sum(0)                      # fixed-order partials -> (C, 9) = dW | db
+                if ctx.needs_input_grad[15]:
+                    grad_w = gsum[:, :ENC_FEATURES].contiguous()
+                if b_enc is not None and ctx.needs_input_grad[16]:
+                    grad_b = gsum[:, ENC_FEATURES].contiguous()
             if egemm:
                 # dz = dL/dz_e (E, C), original edge order = the gradient of the never-materialised edge embedding
                 feat, w_enc, b_enc = ctx.enc
@@ -422,18 +451,23 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
                                t_val, p_val, learn_t, learn_p, torch.is_grad_enabled(), bool(add_root))
 
 
-def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernel: F % 16 == 0, F <= 256, C % 4 == 0,
-    C <= 128 -- the ``Linear(hidden -> C)`` every reference model with edge features puts in its GENConv layers
-    (ogbn-proteins / ogbg-ppa / RevGCN: ``edge_feat_dim = hidden_channels``): an E x F x C GEMM on the matrix cores
-    inside the aggregation.  (A narrower encoder -- no reference call site has one -- takes the stock Linear + (E, C)
-    path.)"""
+def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: Optional[torch.Tensor], narrow: bool = False) -> bool:
+    """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels.
+
+    * wide features, F % 16 == 0, F <= 256, C % 4 == 0, C <= 128 -- the ``Linear(hidden -> C)`` every reference model
+      with edge features puts in its GENConv layers (ogbn-proteins / ogbg-ppa / RevGCN: ``edge_feat_dim =
+      hidden_channels``): an E x F x C GEMM on the matrix cores inside the aggregation;
+    * ``narrow=True`` (blocks.ComposedEdgeEmbedding: the model-level and the per-layer encoder composed into one
+      Linear(8 -> C)): F == 8, C % 4 == 0, C <= 256, evaluated per edge in registers.  ``weight`` may be None here (the
+      composed weight is formed by the caller)."""
     if edge_feat is None or edge_feat.dim() != 2 or x.dim() != 2 or not edge_feat.is_floating_point():
         return False
     C, F = x.size(-1), edge_feat.size(1)
-    if tuple(weight.shape) != (C, F) or torch.is_autocast_enabled():
+    if torch.is_autocast_enabled() or edge_feat.size(0) == 0:
         return False
-    if not FUSED_EDGE_GEMM or edge_feat.size(0) == 0:
+    if narrow:
+        return F == ENC_FEATURES and C % 4 == 0 and C <= 256 and (weight is None or tuple(weight.shape) == (C, F))
+    if weight is None or tuple(weight.shape) != (C, F) or not FUSED_EDGE_GEMM:
         return False
     return bool(_lib.load().dgcn_gen_aggr_egemm_supported(F, C))
 

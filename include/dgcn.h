@@ -184,6 +184,39 @@ int dgcn_gen_aggr_max_bwd_f32(const dgcn_graph* g, const int32_t* t_cpos, const 
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same aggregation with a NARROW edge encoder evaluated per edge: every edge recomputes its row
+ *   e_e = enc_weight f_e + enc_bias       (n_feat = 8 raw features, 32 bytes per edge)
+ * and no (E, C) or (E, hidden) edge array exists in either direction.  Call site: the reference's models with edge
+ * features apply TWO Linear maps in a row to the 8 raw edge features -- the model-level
+ * edge_encoder = Linear(8 -> hidden) (examples/ogb_eff/ogbn_proteins/model_rev.py:53,98; ogbn_proteins/model.py:74-78)
+ * and every GENConv's edge_encoder = Linear(hidden -> C) (gcn_lib/sparse/torch_vertex.py:56-66) -- with nothing
+ * between them: their composition W_l We (C x 8), W_l be + b_l is this entry point's (enc_weight, enc_bias); the host
+ * side forms it with autograd ops (deep_gcns_torch_amd.blocks.ComposedEdgeEmbedding), so the gradients of both Linear
+ * layers follow from the (C, 9) result of the backward by two tiny matrix products.
+ *   enc_feat    [E, n_feat] fp32 contiguous, ORIGINAL edge order; n_feat must be 8
+ *   enc_weight  [channels, n_feat], enc_bias [channels] or NULL
+ *   channels % 4 == 0, channels <= 256, 16-byte aligned pointers; anything else returns DGCN_E_SHAPE / _ALIGN.
+ * Backward: grad_x as above; the encoder gradients come out as per-workgroup partials
+ *   enc_grad_partials [dgcn_gen_aggr_enc_bwd_num_partials(g, channels)][channels][n_feat + 1]
+ * whose sum over the first axis is (d enc_weight | d enc_bias); every block is fully written.
+ */
+int dgcn_gen_aggr_enc_fwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
+                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
+                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
+                              const float* t_dev, const float* p_dev, float* out, void* aux1, float* aux2,
+                              int32_t* range_flag, void* workspace, size_t workspace_bytes, void* stream);
+
+int32_t dgcn_gen_aggr_enc_bwd_num_partials(const dgcn_graph* g, int32_t channels);
+
+int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_stride, const float* enc_feat,
+                              const float* enc_weight, const float* enc_bias, int32_t n_feat, int32_t channels,
+                              int32_t mode, int32_t msg, int32_t flags, float t, float p, float eps,
+                              const float* t_dev, const float* p_dev, const float* gcoef, const void* aux1,
+                              const float* out, const float* gshift, const float* kshift,
+                              const int32_t* shift_ok, const float* groot, float* grad_x,
+                              float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE
  * (E, hidden) edge embedding and every GENConv owns edge_encoder = Linear(edge_feat_dim = hidden -> C)
  * (gcn_lib/sparse/torch_vertex.py:56-66; examples/ogb_eff/ogbn_proteins/model_rev.py:45-55,98-107;

@@ -455,6 +455,54 @@ def test_narrow_edge_encoders_take_the_stock_path():
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("aggr,kw,C", [("softmax_sg", dict(t=0.3), 64), ("softmax", dict(t=1.0, learn_t=True), 112),
+                                       ("power", dict(p=2.0), 32), ("max", {}, 16), ("mean", {}, 256), ("max", {}, 64)])
+def test_per_edge_encoder_kernels_match_linear_then_aggregate(aggr, kw, C):
+    """The per-edge encoder kernels (dgcn_gen_aggr_enc_*: relu(x_j + W f_e + b) + eps from 8 raw features per edge, no
+    (E, C) array) that serve blocks.ComposedEdgeEmbedding -- W, b = the composition of the model-level and the per-layer
+    edge encoder -- against the two-step form (Linear, then aggregation of the (E, C) rows): outputs, gradients w.r.t.
+    x, the weight and the bias (per-workgroup partial sums), learnable t; hub rows, sub-group and padded-lane layouts."""
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    n = 4000
+    ei = synth.powerlaw_graph(n, 30_000, seed=13, exponent=2.1).to(dev)
+    E = ei.size(1)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g).to(dev)
+    feat = torch.randn(E, 8, generator=g).to(dev)
+    W = (torch.randn(C, 8, generator=g) * 0.5).to(dev)
+    b = (torch.randn(C, generator=g) * 0.5).to(dev)
+    probe = torch.randn(n, C, generator=g).to(dev)
+    kw = dict(kw)
+    if kw.get("learn_t"):
+        kw["t"] = torch.tensor([kw["t"]], device=dev, requires_grad=True)
+    assert ops.encoder_fusable(x, feat, W, narrow=True) and not ops.encoder_fusable(x, feat, W)
+
+    def run(fused):
+        xa, Wa, ba = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ta = kw.get("t")
+        if isinstance(ta, torch.Tensor):
+            ta = ta.detach().clone().requires_grad_(True)
+        k2 = dict(kw, t=ta) if ta is not None else dict(kw)
+        if fused:
+            out = ops.gen_aggregate(xa, ei, feat, aggr=aggr, edge_encoder=(Wa, ba), **k2)
+        else:
+            out = ops.gen_aggregate(xa, ei, torch.nn.functional.linear(feat, Wa, ba), aggr=aggr, **k2)
+        (out * probe).sum().backward()
+        return out.detach(), xa.grad, Wa.grad, ba.grad, (ta.grad if isinstance(ta, torch.Tensor) else None)
+
+    of, gxf, gwf, gbf, gtf = run(True)
+    oc, gxc, gwc, gbc, gtc = run(False)
+    torch.testing.assert_close(of, oc, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gxf, gxc, rtol=1e-4, atol=1e-5 * float(gxc.abs().max()))
+    torch.testing.assert_close(gwf, gwc, rtol=1e-4, atol=2e-5 * float(gwc.abs().max()))
+    torch.testing.assert_close(gbf, gbc, rtol=1e-4, atol=2e-5 * float(gbc.abs().max()))
+    if gtc is not None:
+        torch.testing.assert_close(gtf, gtc, rtol=1e-4, atol=1e-5 * float(gtc.abs().max()))
+    # shapes the fused path does not take are refused by the predicate (the module then builds the embedding)
+    assert not ops.encoder_fusable(x, torch.zeros(E, 7, device=dev), W, narrow=True)
+
+
 @pytest.mark.parametrize("C", [16, 32, 64, 100, 128, 130, 256])
 @pytest.mark.parametrize("sorted_input", [False, True])
 def test_max_backward_bit_mask_path_equals_the_row_walk(C, sorted_input, monkeypatch):

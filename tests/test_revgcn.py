@@ -33,18 +33,19 @@ def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_r
     return x + m if add_root else m
 
 
-def _build(case, dev, impl="restated"):
+def _build(case, dev, impl="restated", composed=False):
     c = case["ctor"]
     m = rev_restated.RevGCN(num_layers=c["num_layers"], hidden=c["hidden"], aggr=c["aggr"], dropout=c["dropout"],
                             learn_p=c.get("learn_p", False), p=c.get("p", 1.0), t=c.get("t", 1.0),
-                            learn_t=c.get("learn_t", False), node_table=case["node_table"].to(dev), impl=impl)
+                            learn_t=c.get("learn_t", False), node_table=case["node_table"].to(dev), impl=impl,
+                            composed_edges=composed)
     assert list(m.state_dict().keys()) == list(case["state_dict_before"].keys())
     m.load_state_dict(case["state_dict_before"])
     return m.to(dev).train()
 
 
-def _run(case, dev, impl="restated"):
-    m = _build(case, dev, impl)
+def _run(case, dev, impl="restated", composed=False):
+    m = _build(case, dev, impl, composed)
     pred, hn = m(case["x"].to(dev), case["node_index"].to(dev), case["edge_index"].to(dev),
                  case["edge_attr"].to(dev), mask=case["mask"].to(dev))
     assert tuple(pred.shape) == case["pred_shape"]
@@ -96,6 +97,24 @@ def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
         gcn_revop.KEEP_AGGREGATION = keep
     # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge
     # on another device, so the gradient gate is relative to each tensor's scale (not elementwise)
+    _check(case, hn, grads, 2e-4, 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep", [True, False])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_revgcn_with_composed_edge_encoders_matches_the_reference(case, keep):
+    """The model-level Linear(8 -> hidden) and every layer's Linear(hidden -> C) composed into one Linear(8 -> C) that the
+    aggregation kernels evaluate per edge (blocks.ComposedEdgeEmbedding: no (E, hidden) array in either direction):
+    same outputs and parameter gradients -- of BOTH Linear layers -- as the reference's real RevGCN (golden)."""
+    _install()
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
+    saved = gcn_revop.KEEP_AGGREGATION
+    gcn_revop.KEEP_AGGREGATION = keep
+    try:
+        hn, grads = _run(case, torch.device("cuda:0"), "product", composed=True)
+    finally:
+        gcn_revop.KEEP_AGGREGATION = saved
     _check(case, hn, grads, 2e-4, 2e-3)
 
 
