@@ -54,15 +54,18 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
             raise ValueError("use_checkpoint: False, True / 'aggregation', or 'full'")
         stash = None if use_checkpoint == "full" else ops.AggregationStash()
 
-        def run(h2_, h_):
+        def run(h2_, h_, ea_):
+            # (edge features are an INPUT of the checkpoint, as in the reference's checkpoint(self.gcns[layer], h2,
+            # edge_index, edge_emb): a tensor with history must not be reached through a closure, its graph would be
+            # walked once per layer)
             if stash is None:
-                out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
+                out = _conv_res(conv, h2_, edge_index, ea_, h_, want_stats)
             else:
                 with ops.stash_aggregation(stash, "replay" if torch.is_grad_enabled() else "record"):
-                    out = _conv_res(conv, h2_, edge_index, edge_attr, h_, want_stats)
+                    out = _conv_res(conv, h2_, edge_index, ea_, h_, want_stats)
             return out if want_stats else (out, None)
         # the second output (statistics) is not differentiable; checkpoint hands it through
-        hn, st = checkpoint(run, h2, h_skip, use_reentrant=True)
+        hn, st = checkpoint(run, h2, h_skip, edge_attr, use_reentrant=True)
     else:
         out = _conv_res(conv, h2, edge_index, edge_attr, h_skip, want_stats)
         hn, st = out if want_stats else (out, None)

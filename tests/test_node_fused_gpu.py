@@ -399,3 +399,50 @@ def test_aggregation_stash_refuses_a_different_recomputation():
     g0, = torch.autograd.grad(out, x, g)
     g1, = torch.autograd.grad(ref, x, g)
     assert torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("aggr,kw", [("softmax", dict(t=1.0)), ("max", {}), ("power", dict(p=1.0))])
+@pytest.mark.parametrize("use_checkpoint", [False, True])
+def test_composed_edge_embedding_in_a_res_plus_stack(aggr, kw, use_checkpoint):
+    """The ogbn-proteins DeeperGCN pattern (examples/ogb/ogbn_proteins/model.py:90,107-128): a model-level
+    Linear(8 -> hidden) edge encoder whose output every layer's GENConv encodes again with Linear(hidden -> hidden).
+    blocks.ComposedEdgeEmbedding in place of the (E, hidden) tensor: same logits and the same gradients for BOTH Linear
+    layers of every layer, with and without checkpointing."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import blocks, synth
+    from gcn_lib.sparse.torch_nn import norm_layer
+    from gcn_lib.sparse.torch_vertex import GENConv
+    dev = _dev()
+    torch.manual_seed(17)
+    N, hidden, L = 5000, 64, 4
+    ei = synth.powerlaw_graph(N, 40_000, seed=3, exponent=2.2).to(dev)
+    E = ei.size(1)
+    enc = torch.nn.Linear(8, hidden).to(dev)
+    convs = torch.nn.ModuleList([GENConv(hidden, hidden, aggr=aggr, encode_edge=True, edge_feat_dim=hidden, norm="layer",
+                                         mlp_layers=2, **kw) for _ in range(L)]).to(dev)
+    norms = torch.nn.ModuleList([norm_layer("layer", hidden) for _ in range(L)]).to(dev)
+    x0 = torch.randn(N, hidden, device=dev)
+    ea = torch.rand(E, 8, device=dev)
+    probe = torch.randn(N, hidden, device=dev)
+    params = list(enc.parameters()) + list(convs.parameters()) + list(norms.parameters())
+
+    def run(composed):
+        for p in params:
+            p.grad = None
+        emb = blocks.ComposedEdgeEmbedding(enc, ea) if composed else enc(ea)
+        h = convs[0](x0, ei, emb)
+        for layer in range(1, L):
+            h, _ = blocks.res_plus_layer(norms[layer - 1], convs[layer], h, ei, emb, p=0.0, training=True,
+                                         want_stats=False, use_checkpoint=use_checkpoint)
+        (h * probe).sum().backward()
+        return h.detach(), [None if p.grad is None else p.grad.clone() for p in params]
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    torch.testing.assert_close(o1, o0, rtol=2e-4, atol=2e-4 * float(o0.abs().max()))
+    for a, b, p in zip(g1, g0, params):
+        assert (a is None) == (b is None)
+        if b is not None:
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) / scale < 3e-3, tuple(p.shape)
