@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -341,6 +342,8 @@ def extras(dev):
             pred, _ = m(xin, nidx, eip, eattr)
             torch.nn.functional.binary_cross_entropy_with_logits(pred, yp).backward()
             opt.step()
+        gc.collect()                       # (the previous variant's model, gradients and optimiser state are gone
+        torch.cuda.empty_cache()           #  before this one's peak is taken)
         torch.cuda.reset_peak_memory_stats()
         ms = gpu_timed(rev_step, 3, 1)
         rev[name] = dict(ms_per_step=ms, ms_per_layer=ms / layers, edges_per_s=Ep * layers * 2 / (ms * 1e-3),
