@@ -192,6 +192,10 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError("fused edge encoder: features (E, F), weight (C, F)")
             if n_feat == ENC_FEATURES and C % 4 == 0 and C <= 256:
                 # narrow features: every edge recomputes W f_e + b from its 32 bytes (csrc/gen_aggr_common.h, EA == 2)
+                if track and ctx.needs_input_grad[14]:
+                    #  the per-edge kernels produce dW | db only: refuse rather than return no gradient
+                    raise ValueError("the per-edge encoder path has no gradient w.r.t. the raw edge features: pass them "
+                                     "detached (blocks.ComposedEdgeEmbedding does) or encode them first")
                 enc_feat = enc_feat.float().contiguous()
             elif graph.n_edges > 0 and lib.dgcn_gen_aggr_egemm_supported(n_feat, C):
                 egemm = True
@@ -466,7 +470,8 @@ def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: Optional[t
     if torch.is_autocast_enabled() or edge_feat.size(0) == 0:
         return False
     if narrow:
-        return F == ENC_FEATURES and C % 4 == 0 and C <= 256 and (weight is None or tuple(weight.shape) == (C, F))
+        return (F == ENC_FEATURES and C % 4 == 0 and C <= 256 and not edge_feat.requires_grad
+                and (weight is None or tuple(weight.shape) == (C, F)))
     if weight is None or tuple(weight.shape) != (C, F) or not FUSED_EDGE_GEMM:
         return False
     return bool(_lib.load().dgcn_gen_aggr_egemm_supported(F, C))

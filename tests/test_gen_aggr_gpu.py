@@ -501,6 +501,11 @@ def test_per_edge_encoder_kernels_match_linear_then_aggregate(aggr, kw, C):
         torch.testing.assert_close(gtf, gtc, rtol=1e-4, atol=1e-5 * float(gtc.abs().max()))
     # shapes the fused path does not take are refused by the predicate (the module then builds the embedding)
     assert not ops.encoder_fusable(x, torch.zeros(E, 7, device=dev), W, narrow=True)
+    # raw features that require grad: the predicate says no, the op refuses loudly (no silent None gradient)
+    fr = feat.clone().requires_grad_(True)
+    assert not ops.encoder_fusable(x, fr, W, narrow=True)
+    with pytest.raises(ValueError, match="no gradient w.r.t. the raw edge features"):
+        ops.gen_aggregate(x, ei, fr, aggr=aggr, edge_encoder=(W, b), **{k: v for k, v in kw.items() if k != "t" or not isinstance(v, torch.Tensor)})
 
 
 @pytest.mark.parametrize("C", [16, 32, 64, 100, 128, 130, 256])
