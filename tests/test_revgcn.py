@@ -62,17 +62,21 @@ def _check(case, hn, grads, rtol, gtol):
         assert err < gtol, f"{k}: max error {err:.3e} of the gradient scale"
 
 
-@pytest.mark.parametrize("impl", ["restated", "product"])
+@pytest.mark.parametrize("impl", ["restated", "product", "product_composed"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
 def test_restated_reversible_wrapper_matches_reference_on_cpu(case, impl):
     """impl='product': the package's eff_gcn_modules.rev (one grad-enabled evaluation per coupling function, shared
-    edge-embedding gradient accumulated across layers) must give the reference's values as well."""
+    edge-embedding gradient accumulated across layers) must give the reference's values as well.
+    'product_composed': the model hands the layers a blocks.ComposedEdgeEmbedding instead of the (E, hidden) tensor --
+    on CPU tensors every GENConv materialises it, which exercises the object's way through the reversible wrapper
+    (group views, the model-level encoder's parameters riding with the block weights) without the kernels."""
     _install()
     from gcn_lib.sparse import torch_message
     saved = torch_message.GenMessagePassing.propagate
     torch_message.GenMessagePassing.propagate = _oracle_propagate
     try:
-        hn, grads = _run(case, torch.device("cpu"), impl)
+        hn, grads = _run(case, torch.device("cpu"), "product" if impl == "product_composed" else impl,
+                         composed=impl == "product_composed")
     finally:
         torch_message.GenMessagePassing.propagate = saved
     _check(case, hn, grads, 1e-4, 2e-4)
