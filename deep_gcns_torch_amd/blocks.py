@@ -110,7 +110,8 @@ class ComposedEdgeEmbedding:
         if edge_attr.dim() != 2 or edge_attr.size(1) != encoder.in_features:
             raise ValueError("edge_attr must be (E, encoder.in_features)")
         self.encoder = encoder
-        self.raw = edge_attr.detach()
+        # (the same tensor object for every group view / layer: per-tensor caches of the kernels' host side hit)
+        self.raw = edge_attr.detach() if edge_attr.requires_grad else edge_attr
         self.repeat = int(repeat)
         self._full = None
 
