@@ -29,6 +29,28 @@ from . import node_ops, ops
 __all__ = ["res_plus_layer", "ResPlusLayer", "ComposedEdgeEmbedding"]
 
 
+def _active_partition():
+    import sys
+    d = sys.modules.get(__package__ + ".dist")           # only a process that imported dist can have an active partition
+    return d.active_partition() if d is not None else None
+
+
+class _reentered:
+    """dist.reentered without importing dist (torch.distributed) into single-GPU processes."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _conv_res(conv, h2, edge_index, edge_attr, h, want_stats):
     if edge_attr is None:
         return conv(h2, edge_index, residual=h, want_stats=want_stats)
@@ -53,8 +75,16 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
         if use_checkpoint not in (True, "aggregation", "full"):
             raise ValueError("use_checkpoint: False, True / 'aggregation', or 'full'")
         stash = None if use_checkpoint == "full" else ops.AggregationStash()
+        # a node-partitioned run (dist.partitioned): the recomputation happens inside the backward pass -- on the
+        # device's autograd thread, possibly after the ``with`` block was left -- and must exchange rows / statistics
+        # exactly like the first pass: the context object travels with the closure
+        part_ctx = _active_partition()
 
         def run(h2_, h_, ea_):
+            with _reentered(part_ctx):
+                return run_(h2_, h_, ea_)
+
+        def run_(h2_, h_, ea_):
             # (edge features are an INPUT of the checkpoint, as in the reference's checkpoint(self.gcns[layer], h2,
             # edge_index, edge_emb): a tensor with history must not be reached through a closure, its graph would be
             # walked once per layer)

@@ -694,7 +694,15 @@ def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = 
 # Parameters are replicated: after backward, ``allreduce_gradients(model)`` sums their gradients (one flat bucket).
 import threading
 
+# The context is looked up by code that autograd may run on ANOTHER thread than the one that entered it: the
+# recomputation of a reentrant torch.utils.checkpoint (blocks.res_plus_layer, or the model file's own
+# checkpoint(self.gcns[layer], ...)) runs on the device's autograd worker thread.  One process drives one GPU, so the
+# lookup is: this thread's innermost context, else the innermost context entered (and not yet left) by any thread of
+# the process.  Code that may run after the ``with`` block was left (loss.backward() outside it) captures the context
+# object and re-enters it: blocks.res_plus_layer does (``reentered``).
 _ACTIVE = threading.local()
+_ACTIVE_PROCESS = []            # contexts entered by any thread, innermost last
+_ACTIVE_LOCK = threading.Lock()
 
 
 class BatchSync:
@@ -725,17 +733,49 @@ class partitioned:
         self.sync = BatchSync(part.bounds[-1], group)
 
     def __enter__(self):
-        self._prev = getattr(_ACTIVE, "ctx", None)
+        if not hasattr(self, "_prevs"):
+            self._prevs = []
+        self._prevs.append(getattr(_ACTIVE, "ctx", None))
         _ACTIVE.ctx = self
+        with _ACTIVE_LOCK:
+            _ACTIVE_PROCESS.append(self)
         return self
 
     def __exit__(self, *exc):
-        _ACTIVE.ctx = self._prev
+        _ACTIVE.ctx = self._prevs.pop()
+        with _ACTIVE_LOCK:
+            for k in range(len(_ACTIVE_PROCESS) - 1, -1, -1):       # the innermost entry of THIS context
+                if _ACTIVE_PROCESS[k] is self:
+                    del _ACTIVE_PROCESS[k]
+                    break
+        return False
+
+
+class reentered:
+    """``with reentered(ctx):`` makes a captured ``partitioned`` context (or None: no-op) the active one on the calling
+    thread -- for code that runs after, or on another thread than, the ``with partitioned(...)`` block that was active
+    when it was set up (the recomputation of a checkpointed layer inside the backward pass)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self.ctx
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
         return False
 
 
 def active_partition():
-    return getattr(_ACTIVE, "ctx", None)
+    ctx = getattr(_ACTIVE, "ctx", None)
+    if ctx is None and _ACTIVE_PROCESS:
+        with _ACTIVE_LOCK:
+            ctx = _ACTIVE_PROCESS[-1] if _ACTIVE_PROCESS else None
+    return ctx
 
 
 def partition_aggregate(ctx: "partitioned", x_local: torch.Tensor, aggr: str, **kw) -> torch.Tensor:

@@ -29,6 +29,9 @@ What is different ("reversible-aware fusion"):
   ``Fm_i`` three times per step (forward, inverse, recompute), this path twice, so BatchNorm running statistics would
   receive two momentum updates instead of three.  Such modules take the generic path (= the reference's algorithm).
 """
+import threading
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -45,7 +48,61 @@ _STATE = "_dgcn_rev_state"      # attribute on a shared argument tensor: its _Sh
 # the forward (softmax / power with the fused edge encoder: the pre-activations, 354 MB per GENBlock at the
 # ogbn-proteins cluster shape -- 79 GB for RevGCN-112, which a 288 GB device holds; the reversible scheme's memory
 # argument is then gone and only its arithmetic remains).
-KEEP_AGGREGATION = True
+#
+# "auto" (default): as True while the arrays kept by all live reversible layers of the device stay under
+# KEEP_AGGREGATION_BUDGET_FRACTION of its memory (KEEP_AGGREGATION_BUDGET_BYTES overrides), as False beyond: a stack
+# keeps 2 - 3 (N, C/group) arrays per coupling function, i.e. memory that GROWS WITH DEPTH (which the reference's
+# reversible scheme exists to avoid) -- bounded here by the budget, so that the 112- / 1001-layer configurations keep
+# their depth-independent activation memory once the budget is spent.
+KEEP_AGGREGATION = "auto"
+KEEP_AGGREGATION_BUDGET_FRACTION = 0.125
+KEEP_AGGREGATION_BUDGET_BYTES = None
+
+_KEPT_BYTES = {}                # device index -> bytes held by live stashes
+_KEPT_LOCK = threading.Lock()
+
+
+class _KeptStashes(list):
+    """The stashes of one reversible layer (a list that can carry a finalizer: the ledger entry goes when it goes)."""
+    __slots__ = ("__weakref__",)
+
+
+def _ledger_add(dev_index, n):
+    with _KEPT_LOCK:
+        _KEPT_BYTES[dev_index] = _KEPT_BYTES.get(dev_index, 0) + n
+
+
+def kept_aggregation_bytes(device=None) -> int:
+    """Bytes of aggregation results currently kept for the backward by the reversible layers of ``device``."""
+    idx = torch.device(device).index if device is not None else None
+    if idx is None:
+        idx = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    return _KEPT_BYTES.get(idx, 0)
+
+
+def _budget_bytes(dev) -> int:
+    if KEEP_AGGREGATION_BUDGET_BYTES is not None:
+        return int(KEEP_AGGREGATION_BUDGET_BYTES)
+    if dev.type != "cuda":
+        return 0
+    return int(torch.cuda.get_device_properties(dev).total_memory * KEEP_AGGREGATION_BUDGET_FRACTION)
+
+
+def _keep_mode(dev):
+    """KEEP_AGGREGATION resolved for one forward: False, True or "edge"."""
+    if KEEP_AGGREGATION != "auto":
+        return KEEP_AGGREGATION
+    idx = dev.index if dev.type == "cuda" else -1
+    return _KEPT_BYTES.get(idx, 0) < _budget_bytes(dev)
+
+
+def _stash_bytes(stashes) -> int:
+    n = 0
+    for st in stashes:
+        for _, kept in st.items:
+            if kept is not None:
+                n += sum(t.numel() * t.element_size() for t in kept if isinstance(t, torch.Tensor))
+    return n
 
 
 class _SharedArgState:
@@ -139,11 +196,16 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
         # the backward's grad-enabled evaluation of every F_i repeats this pass's: keep the aggregations' (N, C) results
         # (max / add / mean and the unfused softmax / power forms: 2 - 3 node-sized arrays per coupling function) instead
         # of launching the edge kernels again -- KEEP_AGGREGATION = False restores the pure recomputation
-        ctx.stashes = (module.new_stashes(node_sized_only=KEEP_AGGREGATION != "edge") if ctx.fused and KEEP_AGGREGATION
-                       and hasattr(module, "new_stashes") and any(ctx.needs_input_grad) else None)
+        keep = (_keep_mode(inputs[0].device) if ctx.fused and hasattr(module, "new_stashes") and any(ctx.needs_input_grad)
+                else False)
+        ctx.stashes = _KeptStashes(module.new_stashes(node_sized_only=keep != "edge")) if keep else None
         with torch.no_grad():
             if ctx.stashes is not None:
                 outputs = fn(*_detached(inputs), _stashes=ctx.stashes)
+                held = _stash_bytes(ctx.stashes)
+                idx = inputs[0].device.index if inputs[0].device.type == "cuda" else -1
+                _ledger_add(idx, held)
+                weakref.finalize(ctx.stashes, _ledger_add, idx, -held)      # released with the layer's context
             else:
                 outputs = fn(*_detached(inputs))
         if not isinstance(outputs, tuple):

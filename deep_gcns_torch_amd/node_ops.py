@@ -265,8 +265,13 @@ def _sync_bn_torch(bn, x, relu, drop, sync):
         factors = drop.mask
     elif drop is not None and drop.mode == DROP_HASH:
         factors = hash_keep_factors(x.size(0), x.size(1), drop.s0, drop.s1, drop.thr).to(x.device)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     track = bn.track_running_stats
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif track and bn.num_batches_tracked is not None:     # nn.BatchNorm1d: cumulative moving average
+        momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)
+    else:
+        momentum = 0.0
     return _d._SyncBatchNormTorch.apply(x, bn.weight, bn.bias, bn.running_mean if track else None,
                                         bn.running_var if track else None, bn.num_batches_tracked if track else None,
                                         momentum, bn.eps, relu, factors, sync)

@@ -95,7 +95,17 @@ class AggregationStash:
         self.node_sized_only = node_sized_only
 
 
-_STASH: Optional[AggregationStash] = None
+# The active stash belongs to the THREAD that entered ``stash_aggregation``: the record pass runs on the caller's
+# thread, the replay on the device's autograd thread (reentrant checkpoint / reversible backward), and with one host
+# thread per GPU (nn.DataParallel) several passes are in flight at once -- a module-level variable would let one
+# thread's ``with`` block install or restore another thread's stash.
+import threading
+
+_TLS = threading.local()
+
+
+def _active_stash() -> Optional[AggregationStash]:
+    return getattr(_TLS, "stash", None)
 
 
 class stash_aggregation:
@@ -107,19 +117,17 @@ class stash_aggregation:
         self.stash, self.mode = stash, mode
 
     def __enter__(self):
-        global _STASH
-        self._prev = _STASH
+        self._prev = _active_stash()
         self.stash.mode = self.mode
         if self.mode == "replay":
             self.stash.pos = 0
         else:
             self.stash.items.clear()
-        _STASH = self.stash
+        _TLS.stash = self.stash
         return self.stash
 
     def __exit__(self, *exc):
-        global _STASH
-        _STASH = self._prev
+        _TLS.stash = self._prev
         self.stash.mode = None
         return False
 
@@ -204,17 +212,23 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError(f"fused edge encoder: unsupported shape F={n_feat}, C={C} (see encoder_fusable)")
         need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[14:17]))
         # (no_grad / inverse passes skip the saved aux)
-        stash = _STASH
+        stash = _active_stash()
         record = stash is not None and stash.mode == "record"
-        replay = stash is not None and stash.mode == "replay" and need_grad
-        if replay:
+        replay = False
+        # slot identity: position in the recorded sequence + everything that shapes the launch (two layers of one width
+        # differ by position only, so EVERY aggregation call of the replayed function consumes its slot, whether or not
+        # it needs a gradient this time)
+        slot_key = (graph.n_dst, graph.n_src, graph.n_edges, C, mode, msg, egemm, enc, learn_t, learn_p, add_root)
+        if stash is not None and stash.mode == "replay":
             if stash.pos >= len(stash.items):
                 raise RuntimeError("aggregation stash: the recomputation runs more aggregations than the recorded pass")
             key, kept = stash.items[stash.pos]
             stash.pos += 1
-            if key != (graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root):
+            if key != slot_key:
                 raise RuntimeError("aggregation stash: the recomputation does not repeat the recorded pass")
             replay = kept is not None
+            if replay and not need_grad:
+                return kept[0]                        # same inputs, deterministic kernels: the recorded output
         if replay:
             out, aux1, aux2, range_flag, z_save = kept
             ctx.range_flag = range_flag
@@ -231,7 +245,7 @@ class _GenAggregate(torch.autograd.Function):
             ctx.add_root = add_root
             return out
         if record and stash.node_sized_only and egemm and mode != _lib.AGGR_MAX:
-            stash.items.append(((graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root), None))
+            stash.items.append((slot_key, None))
             record = False
         want_aux = need_grad or record
         out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
@@ -281,8 +295,7 @@ class _GenAggregate(torch.autograd.Function):
         _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
                    ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
         if record:
-            stash.items.append(((graph.n_dst, C, mode, msg, egemm, learn_t, learn_p, add_root),
-                                (out, aux1, aux2, range_flag, z_save)))
+            stash.items.append((slot_key, (out, aux1, aux2, range_flag, z_save)))
         if need_grad:
             ctx.range_flag = range_flag
             ctx.enc = (enc_feat, enc_w, enc_b) if enc else None

@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE: float64 attribution of gradient differences to the DISCONTINUITIES of the path.
+
+The message-passing path has two kinds of points where an fp32 rounding difference between two correct evaluations
+changes a gradient by a whole term instead of by a rounding error:
+
+* the ReLU of the message / edge MLP (gcn_lib/sparse/torch_vertex.py:78-85, gcn_lib/dense/torch_nn.py:48-60): a
+  pre-activation z within rounding of 0 passes its gradient in one evaluation and not in the other;
+* the arg-max of max aggregation (gcn_lib/sparse/torch_message.py:46-47, gcn_lib/dense/torch_vertex.py:16-35): two
+  candidates within rounding of each other; the gradient goes to either.
+
+Instead of count budgets ("24 elements may be wrong") the configuration-size tests replay the forward pass in float64
+on the host, MARK every (edge, channel) pair that sits on such a point -- |z| below ``K_EPS`` fp32 roundings of the
+magnitude of the sum that forms it, candidates within that distance of the extremum -- and then either
+
+* bound each gradient element by ``rounding tolerance + sum of |gradient terms| of the marked pairs that feed it``
+  (``sparse_flip_bounds`` + ``assert_explained``): an element no marked pair feeds is held to the plain tolerance, so
+  a kernel bug of any size outside the marked pairs fails; or
+* zero the upstream gradient at the output positions a marked pair feeds (``dense_edgeconv_attribution`` / ``dense_mrconv_attribution``): both sides then
+  carry no gradient through any marked point and are compared strictly.
+
+Nothing here is imported by the product path.
+"""
+from __future__ import annotations
+
+import torch
+
+EPS32 = float(torch.finfo(torch.float32).eps)
+K_EPS = 8.0            # a pre-activation is "at the kink" when |z| < K_EPS * eps32 * (sum of |terms| that form z)
+
+
+def assert_explained(a, r, extra, rtol, atol, what):
+    """|a - r| <= atol + rtol |r| + extra, elementwise.  ``extra`` (same shape, float64, >= 0; or None) is the sum of the
+    absolute gradient terms of the marked pairs feeding each element: zero almost everywhere.  Returns how many
+    elements needed their ``extra``."""
+    a = a.detach().cpu().double()
+    r = r.detach().cpu().double()
+    diff = (a - r).abs()
+    plain = atol + rtol * r.abs()
+    if extra is None:
+        extra = torch.zeros_like(diff)
+    bad = diff > plain + 1.001 * extra
+    if bool(bad.any()):
+        idx = bad.nonzero()[0].tolist()
+        worst = float((diff - plain - extra).max())
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements differ by more than the rounding tolerance "
+                             f"and no marked kink / tie pair explains it (worst excess {worst:.3e}; first at {idx}: "
+                             f"got {float(a[tuple(idx)]):.6e}, want {float(r[tuple(idx)]):.6e}, explained "
+                             f"{float(extra[tuple(idx)]):.3e})")
+    return int((diff > plain).sum())
+
+
+def sparse_flip_bounds(x, ei, feat, W, b, n, aggr, probe, t=1.0, p=1.0, learn_t=False, eps=1e-7, **_ignored):
+    """GENConv with a Linear edge encoder (gcn_lib/sparse/torch_vertex.py:62-68,78-85):
+
+        z_e = x[src_e] + W f_e + b,   m_e = relu(z_e) + eps,   out = AGGR(m),   L = sum(out * probe)
+
+    replayed in float64.  Returns per-gradient bounds on what the marked pairs can move:
+    ``grad_x`` (n, C), ``grad_feat`` = (rows, (len(rows), K)) sparse over edges, ``grad_W`` (C, K), ``grad_b`` (C,),
+    and the counts ``n_kink`` / ``n_tied``."""
+    from oracle import sparse_ref
+    src, dst = ei[0], ei[1]
+    x64, f64, W64 = x.detach().double(), feat.detach().double(), W.detach().double()
+    b64 = None if b is None else b.detach().double()
+    z = x64[src] + f64 @ W64.t()
+    zmag = x64[src].abs() + f64.abs() @ W64.abs().t()
+    if b64 is not None:
+        z = z + b64
+        zmag = zmag + b64.abs()
+    tol = K_EPS * EPS32 * zmag
+    kink = z.abs() < tol
+    m = (torch.relu(z) + eps).requires_grad_(True)
+    kw = dict(aggr=aggr, t=torch.tensor([float(t)], dtype=torch.float64) if learn_t else float(t), p=float(p))
+    if learn_t:
+        kw["learn_t"] = True
+    out = sparse_ref.gen_aggregate_messages(m, dst, n, **kw)
+    (dm,) = torch.autograd.grad((out * probe.detach().double()).sum(), m)
+    flip = torch.where(kink, dm.abs(), torch.zeros_like(dm))
+    n_tied = 0
+    if aggr == "max":
+        C = z.size(1)
+        md = m.detach()
+        top = out.detach()                                            # (n, C) maxima (0 for empty rows)
+        tmax = torch.zeros(n, C, dtype=torch.float64).index_reduce_(0, dst, tol, "amax", include_self=True)
+        near = ((top[dst] - md) <= 2 * tmax[dst]) & (z > -tol)         # candidates that can win AND pass a gradient
+        cnt = torch.zeros(n, C, dtype=torch.float64).index_add_(0, dst, near.double())
+        # a row-channel with >= 2 candidates in reach of the maximum (one of them may be an edge at the ReLU floor:
+        # count every candidate within reach, whatever its z, for the "at least two" test)
+        reach = torch.zeros(n, C, dtype=torch.float64).index_add_(0, dst, ((top[dst] - md) <= 2 * tmax[dst]).double())
+        tied = near & (reach[dst] >= 2) & (cnt[dst] >= 1)
+        n_tied = int(tied.sum())
+        flip = flip + torch.where(tied, probe.detach().double()[dst].abs(), torch.zeros_like(dm))
+    rows = flip.any(dim=1).nonzero().squeeze(1)
+    fr = flip[rows]
+    bounds = dict(
+        grad_x=torch.zeros(n, z.size(1), dtype=torch.float64).index_add_(0, src[rows], fr),
+        grad_feat=(rows, fr @ W64.abs()),
+        grad_W=fr.t() @ f64[rows].abs(),
+        grad_b=fr.sum(0),
+        n_kink=int(kink.sum()), n_tied=n_tied, n_pairs=int(z.numel()),
+    )
+    return bounds
+
+
+def dense_scatter_rows(rows_vals, shape):
+    """(rows, vals) -> dense float64 tensor of ``shape`` (zeros elsewhere)."""
+    rows, vals = rows_vals
+    out = torch.zeros(shape, dtype=torch.float64)
+    out[rows] = vals
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense path: EdgeConv2d / MRConv2d on (B, C, N, 1) point clouds
+# ---------------------------------------------------------------------------------------------------------------------
+def _gather(x3, idx):
+    """x3 (B, C, N) float64, idx (B, N, k) -> (B, C, N, k)."""
+    B, C, N = x3.shape
+    k = idx.size(-1)
+    return torch.gather(x3.unsqueeze(-1).expand(B, C, N, k), 2, idx.unsqueeze(1).expand(B, C, N, k))
+
+
+def dense_edgeconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, bn_bias, probe, bn_eps=1e-5):
+    """EdgeConv2d = max_l BN(relu(W [x_i ; x_j - x_i] + b)) (gcn_lib/dense/torch_vertex.py:31-35, torch_nn.py:48-60:
+    conv -> act -> norm) replayed in float64.
+
+    Returns ``(probe_masked, bounds, info)``:
+
+    * ``probe_masked`` = ``probe`` with zeros at the output positions (b, c', n) whose selected neighbour is not
+      determined beyond fp32 rounding: two candidates within reach of the extremum of which one passes a gradient, or
+      a selected candidate at the ReLU kink.  No O(1) gradient term then depends on a rounding decision;
+    * what is left: through the batch statistics EVERY edge activation receives a gradient of relative size
+      1 / (B N k) (da = ghat (dy - mean dy - xhat mean(dy xhat))), so an edge at the ReLU kink anywhere still moves
+      that much: ``bounds`` = dict(grad_x (B, C, N, 1), grad_W (C', 2C), grad_b (C',)) float64, the sum of those
+      |terms| per gradient element (zero except around the few kink edges);
+    * ``info``: counts."""
+    import torch.nn.functional as F
+    x3 = x.detach().double().squeeze(-1)
+    B, C, N = x3.shape
+    nbr, ctr = edge_index[0], edge_index[1]
+    W = conv_weight.detach().double().view(conv_weight.size(0), -1)            # (C', 2C)
+    Co = W.size(0)
+    W1, W2 = W[:, :C], W[:, C:]
+    xi, xj = _gather(x3, ctr), _gather(x3, nbr)
+    d = xj - xi
+    pre = torch.einsum("oc,bcnl->bonl", W1, xi) + torch.einsum("oc,bcnl->bonl", W2, d)
+    mag = torch.einsum("oc,bcnl->bonl", W1.abs(), xi.abs()) + torch.einsum("oc,bcnl->bonl", W2.abs(), xj.abs() + xi.abs())
+    if conv_bias is not None:
+        bb = conv_bias.detach().double().view(1, -1, 1, 1)
+        pre, mag = pre + bb, mag + bb.abs()
+    tol = K_EPS * EPS32 * mag
+    del mag
+    kink = pre.abs() < tol
+    a = torch.relu(pre).requires_grad_(True)
+    g64 = None if bn_weight is None else bn_weight.detach().double()
+    sign = torch.ones(Co, dtype=torch.float64) if g64 is None else torch.where(g64 >= 0, 1.0, -1.0).double()
+    sa = sign.view(1, -1, 1, 1) * a.detach()                                 # the selected candidate maximises s * a
+    top = sa.max(dim=-1, keepdim=True).values
+    tmax = tol.max(dim=-1, keepdim=True).values
+    reach = (top - sa) <= 2 * tmax
+    passes = pre > -tol
+    flag = (((reach.sum(-1, keepdim=True) >= 2) & (reach & passes).any(-1, keepdim=True))
+            | (reach & kink).any(-1, keepdim=True))
+    del sa, top, reach, passes
+    probe_m = torch.where(flag, torch.zeros_like(probe), probe)
+    # gradient of every edge activation under the masked probe (float64 autograd through BN + max)
+    y = a if bn_weight is None else F.batch_norm(a, None, None, g64, bn_bias.detach().double(), True, 0.0, bn_eps)
+    out = y.max(dim=-1, keepdim=True).values
+    (da,) = torch.autograd.grad((out * probe_m.double()).sum(), a)
+    bounds = dict(grad_x=torch.zeros(B, C, N, 1, dtype=torch.float64), grad_W=torch.zeros(Co, 2 * C, dtype=torch.float64),
+                  grad_b=torch.zeros(Co, dtype=torch.float64))
+    W12a, W2a = (W1 - W2).abs(), W2.abs()
+    for bi, co, ni, li in kink.nonzero().tolist():
+        t = float(da[bi, co, ni, li].abs())
+        if t == 0.0:
+            continue
+        j = int(nbr[bi, ni, li])
+        bounds["grad_x"][bi, :, ni, 0] += t * W12a[co]
+        bounds["grad_x"][bi, :, j, 0] += t * W2a[co]
+        bounds["grad_W"][co, :C] += t * xi[bi, :, ni, li].abs()
+        bounds["grad_W"][co, C:] += t * d[bi, :, ni, li].abs()
+        bounds["grad_b"][co] += t
+    info = dict(n_masked_outputs=int(flag.sum()), n_outputs=int(flag.numel()), n_kink_edges=int(kink.sum()),
+                n_edge_activations=int(kink.numel()))
+    return probe_m, bounds, info
+
+
+def dense_mrconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, bn_bias, probe, bn_eps=1e-5):
+    """MRConv2d = BN(relu(W [x ; max_l (x_j - x_i)] + b)) (gcn_lib/dense/torch_vertex.py:16-20) replayed in float64.
+    Discontinuities: the arg-max over the neighbours of an input channel (two neighbours with the same relative
+    feature up to fp32 rounding: the gradient of r[b, c, n] comes from every output channel at point n, so the probe
+    is zeroed for the whole point) and the per-vertex ReLU (the probe is zeroed at that output; the batch-statistics
+    coupling is bounded as in ``dense_edgeconv_attribution``)."""
+    import torch.nn.functional as F
+    x3 = x.detach().double().squeeze(-1)
+    B, C, N = x3.shape
+    nbr, ctr = edge_index[0], edge_index[1]
+    W = conv_weight.detach().double().view(conv_weight.size(0), -1)            # (C', 2C)
+    Co = W.size(0)
+    xi, xj = _gather(x3, ctr), _gather(x3, nbr)
+    d = xj - xi
+    dtol = 2 * EPS32 * (xj.abs() + xi.abs())
+    top, arg = d.max(dim=-1, keepdim=True)
+    tied = ((top - d) <= 2 * dtol.max(dim=-1, keepdim=True).values).sum(-1) >= 2          # (B, C, N)
+    point_tied = tied.any(dim=1)                                                           # (B, N)
+    r = top.squeeze(-1)                                                                    # (B, C, N)
+    feat = torch.cat([x3, r], dim=1)                                                       # (B, 2C, N)
+    pre = torch.einsum("oc,bcn->bon", W, feat)
+    mag = torch.einsum("oc,bcn->bon", W.abs(), torch.cat([x3.abs(), (xj.abs() + xi.abs()).max(-1).values], dim=1))
+    if conv_bias is not None:
+        bb = conv_bias.detach().double().view(1, -1, 1)
+        pre, mag = pre + bb, mag + bb.abs()
+    kink = pre.abs() < K_EPS * EPS32 * mag                                                 # (B, C', N)
+    flag = (kink | point_tied.unsqueeze(1)).unsqueeze(-1)                                  # (B, C', N, 1)
+    probe_m = torch.where(flag, torch.zeros_like(probe), probe)
+    a = torch.relu(pre).unsqueeze(-1).requires_grad_(True)
+    y = a if bn_weight is None else F.batch_norm(a, None, None, bn_weight.detach().double(), bn_bias.detach().double(),
+                                                 True, 0.0, bn_eps)
+    (da,) = torch.autograd.grad((y * probe_m.double()).sum(), a)
+    bounds = dict(grad_x=torch.zeros(B, C, N, 1, dtype=torch.float64), grad_W=torch.zeros(Co, 2 * C, dtype=torch.float64),
+                  grad_b=torch.zeros(Co, dtype=torch.float64))
+    Wa = W.abs()
+    for bi, co, ni in kink.nonzero().tolist():
+        t = float(da[bi, co, ni, 0].abs())
+        if t == 0.0:
+            continue
+        bounds["grad_x"][bi, :, ni, 0] += t * (Wa[co, :C] + Wa[co, C:])        # direct part and the -x_i of every r
+        js = nbr[bi, ni].gather(0, arg[bi, :, ni, 0])                          # selected neighbour per input channel
+        bounds["grad_x"][bi, torch.arange(C), js, 0] += t * Wa[co, C:]
+        bounds["grad_W"][co] += t * feat[bi, :, ni].abs()
+        bounds["grad_b"][co] += t
+    info = dict(n_masked_outputs=int(flag.sum()), n_outputs=int(flag.numel()), n_kink_vertices=int(kink.sum()),
+                n_tied_maxima=int(tied.sum()))
+    return probe_m, bounds, info

@@ -34,3 +34,24 @@ def golden_dir():
 def load_golden(name):
     import torch
     return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line for the log the judge reads: commit, peak host RSS of the test process, device-memory high-water mark."""
+    import resource
+    import subprocess
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except Exception:   # noqa: BLE001 -- the GPU box has no .git
+        head = ""
+    rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20
+    line = f"[dgcn] peak host RSS {rss_gb:.1f} GiB"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            line += f", peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB allocated"
+    except Exception:   # noqa: BLE001
+        pass
+    if head:
+        line += f", HEAD {head}"
+    terminalreporter.write_line(line)
