@@ -28,25 +28,48 @@ EPS32 = float(torch.finfo(torch.float32).eps)
 K_EPS = 8.0            # a pre-activation is "at the kink" when |z| < K_EPS * eps32 * (sum of |terms| that form z)
 
 
-def assert_explained(a, r, extra, rtol, atol, what):
-    """|a - r| <= atol + rtol |r| + extra, elementwise.  ``extra`` (same shape, float64, >= 0; or None) is the sum of the
-    absolute gradient terms of the marked pairs feeding each element: zero almost everywhere.  Returns how many
-    elements needed their ``extra``."""
-    a = a.detach().cpu().double()
-    r = r.detach().cpu().double()
-    diff = (a - r).abs()
-    plain = atol + rtol * r.abs()
-    if extra is None:
-        extra = torch.zeros_like(diff)
-    bad = diff > plain + 1.001 * extra
-    if bool(bad.any()):
-        idx = bad.nonzero()[0].tolist()
-        worst = float((diff - plain - extra).max())
-        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements differ by more than the rounding tolerance "
-                             f"and no marked kink / tie pair explains it (worst excess {worst:.3e}; first at {idx}: "
-                             f"got {float(a[tuple(idx)]):.6e}, want {float(r[tuple(idx)]):.6e}, explained "
-                             f"{float(extra[tuple(idx)]):.3e})")
-    return int((diff > plain).sum())
+def assert_explained(a, r, extra, rtol, atol, what, chunk_rows=1 << 16):
+    """|a - r| <= atol + rtol |r| + extra, elementwise.  ``extra`` (same shape, float64, >= 0; a ``(rows, values)`` pair
+    for a tensor that is zero except on a few rows; or None) is the sum of the absolute gradient terms of the marked
+    pairs feeding each element: zero almost everywhere.  Returns how many elements needed their ``extra``."""
+    a = a.detach().cpu()
+    r = r.detach().cpu()
+    assert a.shape == r.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(r.shape)}"
+    if isinstance(extra, tuple):
+        rows, vals = extra
+        sparse_rows = {int(i): k for k, i in enumerate(rows.tolist())}
+    else:
+        sparse_rows = None
+    if a.dim() == 0:
+        a, r = a.view(1), r.view(1)
+        extra = None if extra is None else extra.view(1)
+    used = 0
+    n0 = a.size(0)
+    for lo in range(0, n0, chunk_rows):                     # (E, K) tensors: bounded float64 temporaries
+        hi = min(lo + chunk_rows, n0)
+        ac, rc = a[lo:hi].double(), r[lo:hi].double()
+        diff = (ac - rc).abs()
+        plain = atol + rtol * rc.abs()
+        if sparse_rows is not None:
+            ex = torch.zeros_like(diff)
+            hit = [(i - lo, k) for i, k in sparse_rows.items() if lo <= i < hi]
+            if hit:
+                ex[torch.tensor([h[0] for h in hit])] = vals[torch.tensor([h[1] for h in hit])].double()
+        elif extra is None:
+            ex = torch.zeros_like(diff)
+        else:
+            ex = extra[lo:hi].double()
+        bad = diff > plain + 1.001 * ex
+        if bool(bad.any()):
+            idx = bad.nonzero()[0].tolist()
+            worst = float((diff - plain - ex)[bad].max())
+            at = tuple(idx)
+            raise AssertionError(f"{what}: {int(bad.sum())} elements (rows {lo}..{hi}) differ by more than the rounding "
+                                 f"tolerance and no marked kink / tie pair explains it (worst excess {worst:.3e}; first at "
+                                 f"{[idx[0] + lo] + idx[1:]}: got {float(ac[at]):.6e}, want {float(rc[at]):.6e}, "
+                                 f"explained {float(ex[at]):.3e})")
+        used += int((diff > plain).sum())
+    return used
 
 
 def sparse_flip_bounds(x, ei, feat, W, b, n, aggr, probe, t=1.0, p=1.0, learn_t=False, eps=1e-7, **_ignored):
@@ -99,14 +122,6 @@ def sparse_flip_bounds(x, ei, feat, W, b, n, aggr, probe, t=1.0, p=1.0, learn_t=
         n_kink=int(kink.sum()), n_tied=n_tied, n_pairs=int(z.numel()),
     )
     return bounds
-
-
-def dense_scatter_rows(rows_vals, shape):
-    """(rows, vals) -> dense float64 tensor of ``shape`` (zeros elsewhere)."""
-    rows, vals = rows_vals
-    out = torch.zeros(shape, dtype=torch.float64)
-    out[rows] = vals
-    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -187,9 +202,10 @@ def dense_edgeconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight,
 def dense_mrconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, bn_bias, probe, bn_eps=1e-5):
     """MRConv2d = BN(relu(W [x ; max_l (x_j - x_i)] + b)) (gcn_lib/dense/torch_vertex.py:16-20) replayed in float64.
     Discontinuities: the arg-max over the neighbours of an input channel (two neighbours with the same relative
-    feature up to fp32 rounding: the gradient of r[b, c, n] comes from every output channel at point n, so the probe
-    is zeroed for the whole point) and the per-vertex ReLU (the probe is zeroed at that output; the batch-statistics
-    coupling is bounded as in ``dense_edgeconv_attribution``)."""
+    feature up to fp32 rounding) and the per-vertex ReLU.  The probe is zeroed at the kink outputs and at every output
+    of a point with a tied maximum; what the batch statistics still send through those points (a gradient of relative
+    size 1 / (B N) for every vertex) is bounded: ``bounds['grad_x']`` holds |d r[b, c, n]| for BOTH tied neighbours and
+    the |terms| of the kink vertices, ``grad_W`` / ``grad_b`` those of the kink vertices."""
     import torch.nn.functional as F
     x3 = x.detach().double().squeeze(-1)
     B, C, N = x3.shape
@@ -200,25 +216,33 @@ def dense_mrconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, b
     d = xj - xi
     dtol = 2 * EPS32 * (xj.abs() + xi.abs())
     top, arg = d.max(dim=-1, keepdim=True)
-    tied = ((top - d) <= 2 * dtol.max(dim=-1, keepdim=True).values).sum(-1) >= 2          # (B, C, N)
+    reach = (top - d) <= 2 * dtol.max(dim=-1, keepdim=True).values                         # (B, C, N, k)
+    tied = reach.sum(-1) >= 2                                                              # (B, C, N)
     point_tied = tied.any(dim=1)                                                           # (B, N)
-    r = top.squeeze(-1)                                                                    # (B, C, N)
+    r = top.squeeze(-1).clone().requires_grad_(True)                                       # (B, C, N)
     feat = torch.cat([x3, r], dim=1)                                                       # (B, 2C, N)
     pre = torch.einsum("oc,bcn->bon", W, feat)
     mag = torch.einsum("oc,bcn->bon", W.abs(), torch.cat([x3.abs(), (xj.abs() + xi.abs()).max(-1).values], dim=1))
     if conv_bias is not None:
         bb = conv_bias.detach().double().view(1, -1, 1)
         pre, mag = pre + bb, mag + bb.abs()
-    kink = pre.abs() < K_EPS * EPS32 * mag                                                 # (B, C', N)
+    kink = pre.detach().abs() < K_EPS * EPS32 * mag                                        # (B, C', N)
     flag = (kink | point_tied.unsqueeze(1)).unsqueeze(-1)                                  # (B, C', N, 1)
     probe_m = torch.where(flag, torch.zeros_like(probe), probe)
-    a = torch.relu(pre).unsqueeze(-1).requires_grad_(True)
+    a = torch.relu(pre).unsqueeze(-1)
+    a.retain_grad()
     y = a if bn_weight is None else F.batch_norm(a, None, None, bn_weight.detach().double(), bn_bias.detach().double(),
                                                  True, 0.0, bn_eps)
-    (da,) = torch.autograd.grad((y * probe_m.double()).sum(), a)
+    (y * probe_m.double()).sum().backward()
+    da, dr = a.grad, r.grad
     bounds = dict(grad_x=torch.zeros(B, C, N, 1, dtype=torch.float64), grad_W=torch.zeros(Co, 2 * C, dtype=torch.float64),
                   grad_b=torch.zeros(Co, dtype=torch.float64))
+    for bi, ci, ni in tied.nonzero().tolist():             # the gradient of r[b, c, n] reaches either tied neighbour
+        t = float(dr[bi, ci, ni].abs())
+        for li in reach[bi, ci, ni].nonzero().squeeze(1).tolist():
+            bounds["grad_x"][bi, ci, int(nbr[bi, ni, li]), 0] += t
     Wa = W.abs()
+    featd = feat.detach()
     for bi, co, ni in kink.nonzero().tolist():
         t = float(da[bi, co, ni, 0].abs())
         if t == 0.0:
@@ -226,7 +250,7 @@ def dense_mrconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, b
         bounds["grad_x"][bi, :, ni, 0] += t * (Wa[co, :C] + Wa[co, C:])        # direct part and the -x_i of every r
         js = nbr[bi, ni].gather(0, arg[bi, :, ni, 0])                          # selected neighbour per input channel
         bounds["grad_x"][bi, torch.arange(C), js, 0] += t * Wa[co, C:]
-        bounds["grad_W"][co] += t * feat[bi, :, ni].abs()
+        bounds["grad_W"][co] += t * featd[bi, :, ni].abs()
         bounds["grad_b"][co] += t
     info = dict(n_masked_outputs=int(flag.sum()), n_outputs=int(flag.numel()), n_kink_vertices=int(kink.sum()),
                 n_tied_maxima=int(tied.sum()))

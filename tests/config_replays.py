@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE: CPU-oracle replays of whole models at the BASELINE configuration sizes.
+
+A replay of DeeperGCN-28 on the full ogbn-arxiv shape costs minutes of host time (28 layers x the reference's
+scatter_softmax chain over 2.48 M edges x 128 channels), so it is run ONCE, in the build container, by
+
+    python -m tests.golden.make_config_goldens          (from the repository root)
+
+and what the GPU tests need of it is committed under tests/golden/config_*.pt: the oracle's outputs on a seeded sample of
+rows, float64 column sums and norms of the FULL output, the hidden features after every layer on a smaller sample
+(to localise a failure), and checksums of the seeded inputs and parameters (the test regenerates them and refuses to
+compare if they differ).  ``DGCN_LIVE_ORACLE=1`` makes the tests replay the oracle on the spot instead.
+"""
+import os
+
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+DEEPERGCN_KW = dict(num_layers=28, in_channels=128, hidden=128, num_tasks=40, aggr="softmax_sg", t=0.1, norm="batch",
+                    mlp_layers=1)
+N_OUT_ROWS, N_HID_ROWS = 8192, 256
+
+
+def deepergcn_inputs(size):
+    """Seeded inputs of tests/test_config_sizes_gpu.py::test_deepergcn28_full_depth_forward."""
+    from deep_gcns_torch_amd import synth
+    if size == "full_arxiv":
+        sh = synth.SHAPES["arxiv"]
+        n = sh["n"]
+        ei = synth.undirected_random_graph(n, sh["n_undirected"], sh["seed"])
+        assert ei.size(1) == 2_484_941
+    elif size == "quarter_powerlaw":
+        n = 42336
+        ei = synth.powerlaw_graph(n, 289_000, seed=3)               # symmetrised + self loops: E = 620,336
+    else:
+        raise ValueError(size)
+    x = torch.randn(n, 128, generator=torch.Generator().manual_seed(33))
+    return n, ei, x
+
+
+def checksums(x, ei, state_dict):
+    return dict(x=float(x.double().sum()), x_abs=float(x.double().abs().sum()), ei=int(ei.sum()),
+                ei_w=int((ei[0] * 3 + ei[1] * 7).sum() % (2 ** 61)),
+                params=float(sum(v.double().abs().sum() for v in state_dict.values() if v.is_floating_point())))
+
+
+def sample_rows(n, count, seed):
+    return torch.randperm(n, generator=torch.Generator().manual_seed(seed))[:min(count, n)].sort().values
+
+
+def oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_root=False, edge_encoder=None):
+    """GenMessagePassing.propagate through the oracle's aggregation (gcn_lib/sparse/torch_message.py:44-85)."""
+    from oracle import sparse_ref
+    m = sparse_ref.gen_propagate(x, edge_index, edge_attr, aggr=self.aggr, t=getattr(self, "t", 1.0))
+    return x + m if add_root else m
+
+
+def deepergcn_oracle_forward(model, x, ei, hidden_rows=None):
+    """Forward of a CPU ``arch_restated.DeeperGCN`` with the aggregation done by the oracle; returns (log-probs,
+    [hidden features after layer l on ``hidden_rows`` for l = 1..L])."""
+    from gcn_lib.sparse import torch_message
+    hidden = []
+    hooks = []
+    if hidden_rows is not None:
+        for nm in model.norms:
+            hooks.append(nm.register_forward_pre_hook(lambda mod, inp: hidden.append(inp[0].detach()[hidden_rows].clone())))
+    saved = torch_message.GenMessagePassing.propagate
+    torch_message.GenMessagePassing.propagate = oracle_propagate
+    try:
+        model.train()
+        with torch.no_grad():
+            ref = model(x, ei)
+    finally:
+        torch_message.GenMessagePassing.propagate = saved
+        for h in hooks:
+            h.remove()
+    return ref, hidden
+
+
+def fixture_path(size):
+    return os.path.join(GOLDEN, f"config_deepergcn28_{size}.pt")

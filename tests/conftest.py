@@ -55,3 +55,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if head:
         line += f", HEAD {head}"
     terminalreporter.write_line(line)
+
+
+def pytest_collection_modifyitems(config, items):
+    """Cheap per-kernel parity tests first, the configuration-size replays (host-side oracle work) last: a failure in a
+    kernel shows up in seconds and a lost box costs the slow part only."""
+    def late(item):
+        return ("test_config_sizes_gpu" in item.nodeid) + 2 * ("at_the_cluster_shape" in item.nodeid)
+    items.sort(key=late)                                  # stable: everything else keeps its order

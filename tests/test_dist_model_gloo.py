@@ -26,12 +26,12 @@ def _inputs():
     return ei, x, y
 
 
-def _model(norm, mlp_layers, fused):
+def _model(norm, mlp_layers, fused, layers=LAYERS, checkpoint="reference"):
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
     torch.manual_seed(11)
-    m = arch_restated.DeeperGCN(num_layers=LAYERS, in_channels=CIN, hidden=HID, num_tasks=NCLS, aggr="softmax_sg", t=0.5,
-                                norm=norm, mlp_layers=mlp_layers, fused_layers=fused)
+    m = arch_restated.DeeperGCN(num_layers=layers, in_channels=CIN, hidden=HID, num_tasks=NCLS, aggr="softmax_sg", t=0.5,
+                                norm=norm, mlp_layers=mlp_layers, fused_layers=fused, checkpoint=checkpoint)
     return m.double().train()
 
 
@@ -41,7 +41,7 @@ def _oracle_propagate(self, edge_index, size=None, x=None, edge_attr=None, add_r
     return x + m if add_root else m
 
 
-def _worker(rank, world, port, scheme, norm, mlp_layers, fused, q):
+def _worker(rank, world, port, scheme, norm, mlp_layers, fused, q, layers=LAYERS, checkpoint="reference", bwd="inside"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,12 +49,33 @@ def _worker(rank, world, port, scheme, norm, mlp_layers, fused, q):
         torch.set_num_threads(2)
         from deep_gcns_torch_amd import dist as ddist
         ei, x, y = _inputs()
-        m = _model(norm, mlp_layers, fused)
+        m = _model(norm, mlp_layers, fused, layers, checkpoint)
+        assert m.checkpoint_grad == (layers > 7 and checkpoint != "never")
         part = ddist.build_partition(ei, N, HID, rank, world, scheme=scheme)
         xl, yl = x[part.lo:part.hi], y[part.lo:part.hi]
         with ddist.partitioned(part, local_aggregate=_oracle_local):
             out = m(xl, ei)
             loss = torch.nn.functional.nll_loss(out, yl, reduction="sum") / N
+            if bwd == "inside":
+                loss.backward()
+            elif bwd == "thread":
+                # what the device's autograd worker does to the recomputation of a reentrant checkpoint: it runs on a
+                # thread that never entered the context
+                import threading
+                err = []
+
+                def run():
+                    try:
+                        loss.backward()
+                    except BaseException as exc:   # noqa: BLE001 -- re-raised on the main thread
+                        err.append(exc)
+                th = threading.Thread(target=run)
+                th.start()
+                th.join()
+                if err:
+                    raise err[0]
+        if bwd == "outside":                 # loss.backward() after the with block: the layers captured the context
+            assert ddist.active_partition() is None
             loss.backward()
         ddist.allreduce_gradients(m)
         grads = {k: p.grad for k, p in m.named_parameters()}
@@ -81,9 +102,15 @@ def test_partitioned_deepergcn_equals_single_process(scheme, norm, mlp_layers, f
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single process, same model, plain (unpartitioned) oracle aggregation
+    _compare_with_single_process(res, norm, mlp_layers)
+
+
+def _compare_with_single_process(res, norm, mlp_layers, layers=LAYERS, checkpoint="never"):
+    # single process, same model, plain (unpartitioned) oracle aggregation (with the reference's checkpointing when the
+    # workers used it: a BatchNorm inside a recomputed MLP updates its running statistics twice per step, as in the
+    # reference)
     ei, x, y = _inputs()
-    m = _model(norm, mlp_layers, False)
+    m = _model(norm, mlp_layers, False, layers, checkpoint)
     from gcn_lib.sparse import torch_message
     saved = torch_message.GenMessagePassing.propagate
     torch_message.GenMessagePassing.propagate = _oracle_propagate
@@ -101,3 +128,30 @@ def test_partitioned_deepergcn_equals_single_process(scheme, norm, mlp_layers, f
         if "running" in k:
             for r in res:
                 torch.testing.assert_close(_unpack(r[4][k]), b, rtol=1e-9, atol=1e-11, msg=k)
+
+
+@pytest.mark.parametrize("fused,checkpoint,bwd,mlp_layers", [
+    (True, "reference", "thread", 2),          # res_plus_layer, aggregation results kept, BatchNorm inside the recomputed MLP
+    (True, "reference_full", "outside", 2),    # everything recomputed, backward after the context was left
+    (True, "reference", "outside", 1),
+    (False, "reference", "thread", 2),         # the model file's own checkpoint(self.gcns[layer], h2, edge_index)
+])
+@_retry_rendezvous()
+def test_partitioned_checkpointed_stack_recomputes_inside_the_partition(fused, checkpoint, bwd, mlp_layers):
+    """10 layers: the reference's gradient checkpointing is on (num_layers > 7).  The recomputation runs inside the
+    backward pass -- on another thread than the one that entered ``dist.partitioned``, or after the block was left --
+    and must go through the partition's exchange and the cross-rank BatchNorm sums like the first pass (ADVICE r3:
+    a thread-local context made it build a graph from the placeholder edge_index instead)."""
+    world, layers = 2, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "allgather", "batch", mlp_layers, fused, q, layers,
+                                               checkpoint, bwd)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _compare_with_single_process(res, "batch", mlp_layers, layers, "reference")

@@ -28,11 +28,14 @@ def _ref(x, ei, feat, W, b, n, aggr, kw):
 
 
 def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=False, rtol=1e-4, dead_channels=0,
-              kink_budget=0):
-    """``kink_budget``: how many gradient elements may be off by a whole term.  A pre-activation z = x_j + W f_e + b
-    within fp32 rounding of 0 lands on either side of the ReLU depending on the summation order of the GEMM (six-product
-    matrix-pipe sum here, a BLAS on the host): that edge then passes its gradient in one evaluation and not in the other.
-    With E x C = 88 M pre-activations at the cluster shape about one in 1e7 is that close to the kink."""
+              attribute=False):
+    """``attribute``: at the cluster shape (E x C = 88 M pre-activations) about one pre-activation in 1e6 lies within
+    fp32 rounding of the ReLU kink -- z = x_j + W f_e + b lands on either side depending on the summation order of the
+    GEMM (six-product matrix-pipe sum here, a BLAS on the host), that edge then passes its gradient in one evaluation
+    and not in the other -- and max aggregation meets near-ties.  The forward is replayed in float64 on the host, the
+    (edge, channel) pairs on a kink / in a tie are marked, and every gradient element is held to the rounding tolerance
+    PLUS the |gradient terms| of the marked pairs that feed it (tests/attribution.py): zero for all but a few hundred
+    elements, and derived from the data, not a budget."""
     from deep_gcns_torch_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(seed)
@@ -78,23 +81,25 @@ def _run_case(ei, n, C, K, aggr, kw, seed=0, strided=False, bias=True, add_root=
                             add_root=add_root, **kd)
     (out * probe.to(dev)).sum().backward()
 
+    extra = {}
+    if attribute:
+        import attribution
+        bounds = attribution.sparse_flip_bounds(x, ei, full[:, K:] if strided else full, W, b, n, aggr, probe,
+                                                t=kw.get("t", 1.0), p=kw.get("p", 1.0), learn_t=learn_t)
+        # the marking is neither empty nor degenerate: a few pairs per million
+        assert 0 < bounds["n_kink"] <= 2e-5 * bounds["n_pairs"], bounds["n_kink"]
+        rows, vals = bounds["grad_feat"]
+        if strided:                 # the gradient of the (E, 2K) parent: nothing reaches the other group's columns
+            vals = torch.cat([torch.zeros_like(vals), vals], dim=1)
+        extra = dict(grad_x=bounds["grad_x"], grad_feat=(rows, vals), grad_W=bounds["grad_W"], grad_b=bounds["grad_b"])
+
     def close(a, r, what, rt=rtol, scale_atol=2e-5):
         r = r.to(torch.float32)
         atol = scale_atol * max(float(r.abs().max()), 1e-6)
         a = a.detach().cpu()
-        if kink_budget and what in ("grad_W", "grad_b", "grad_p", "grad_t"):
-            # a kink edge moves one whole term of these sums (its g * f_e lands in, or leaves, one row of dW): gate the
-            # tensor as a whole
-            err = float((a - r).double().norm() / r.double().norm().clamp_min(1e-30))
-            assert err < 1e-3, f"{what}: relative L2 error {err:.2e}"
-            return
-        if kink_budget and what in ("grad_x", "grad_feat"):
-            bad = (a - r).abs() > atol + rt * r.abs()
-            n_bad = int(bad.sum())
-            assert n_bad <= kink_budget * (K if what == "grad_feat" else 1), f"{what}: {n_bad} elements off"
-            ok = ~bad                                    # the rest: relative L2 error without the kink elements
-            err = float((a[ok] - r[ok]).double().norm() / r[ok].double().norm().clamp_min(1e-30))
-            assert err < 1e-4, f"{what}: relative L2 error {err:.2e}"
+        if attribute:
+            import attribution
+            attribution.assert_explained(a, r, extra.get(what), rt, atol, what)
             return
         torch.testing.assert_close(a, r, rtol=rt, atol=atol, msg=lambda m: f"{what}: {m}")
 
@@ -206,7 +211,7 @@ def test_config5_layer_at_the_cluster_shape_against_the_oracle(aggr, kw):
     s = synth.SHAPES["proteins_cluster"]
     ei = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"])
     assert ei.size(1) == 791225 and s["n"] == 13253
-    _run_case(ei, s["n"], 112, 224, aggr, dict(kw), seed=5, strided=True, kink_budget=24)
+    _run_case(ei, s["n"], 112, 224, aggr, dict(kw), seed=5, strided=True, attribute=True)
 
 
 def test_non_finite_and_tiny_operands_contract():

@@ -499,6 +499,19 @@ def test_per_edge_encoder_kernels_match_linear_then_aggregate(aggr, kw, C):
     torch.testing.assert_close(gbf, gbc, rtol=1e-4, atol=2e-5 * float(gbc.abs().max()))
     if gtc is not None:
         torch.testing.assert_close(gtf, gtc, rtol=1e-4, atol=1e-5 * float(gtc.abs().max()))
+    # ... and against the ORACLE (oracle/sparse_ref.py on the host: the reference's edge_encoder -> message -> aggregate
+    # chain, gcn_lib/sparse/torch_vertex.py:56-68), not only against this package's own unfused path
+    from oracle import sparse_ref
+    xr, Wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, W, b))
+    kr = {k: (v.detach().cpu().clone().requires_grad_(True) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    ref = sparse_ref.gen_propagate(xr, ei.cpu(), torch.nn.functional.linear(feat.cpu(), Wr, br), aggr=aggr, dim_size=n, **kr)
+    (ref * probe.cpu()).sum().backward()
+    torch.testing.assert_close(of.cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gxf.cpu(), xr.grad, rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(gwf.cpu(), Wr.grad, rtol=1e-4, atol=1e-4 * float(Wr.grad.abs().max()))
+    torch.testing.assert_close(gbf.cpu(), br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+    if gtc is not None:
+        torch.testing.assert_close(gtf.cpu(), kr["t"].grad, rtol=1e-4, atol=1e-4 * float(kr["t"].grad.abs().max()))
     # shapes the fused path does not take are refused by the predicate (the module then builds the embedding)
     assert not ops.encoder_fusable(x, torch.zeros(E, 7, device=dev), W, narrow=True)
     # raw features that require grad: the predicate says no, the op refuses loudly (no silent None gradient)
