@@ -64,7 +64,7 @@ def _oracle_step(n, nu, seed, channels, t):
     return ei.size(1), step
 
 
-def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 30.0):
+def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 30.0, counts=(8, 32, 64, 0)):
     """The oracle (CPU restatement of the reference path, oracle/sparse_ref.py) timed on this host's cores.
 
     Sample: the ogbn-ARXIV-shaped graph (N=169,343, E=2,484,941) at the workload's channel width and aggregator --
@@ -79,7 +79,7 @@ def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 30.
     E, step = _oracle_step(s["n"], s["n_undirected"], s["seed"], channels, t)
     sweep = {}
     t_start = time.perf_counter()
-    for th in sorted({min(8, ncores), min(32, ncores), min(64, ncores), ncores}):
+    for th in sorted({min(c or ncores, ncores) for c in counts}):
         if time.perf_counter() - t_start > budget_s:
             break
         torch.set_num_threads(th)
@@ -127,12 +127,12 @@ def _hbm_roofline(algorithmic_bytes, ms, kernel):
                 algorithmic_bytes_per_launch=algorithmic_bytes, timed="wall clock around the launches (not HIP events)")
 
 
-def _cpu_thread_sweep(fn, ncores, budget_s=40.0):
+def _cpu_thread_sweep(fn, ncores, budget_s=40.0, counts=(8, 32, 64, 0)):
     """Best wall time of ``fn`` over thread counts 8 / 32 / 64 / all (torch's CPU kernels stop scaling early; 256
     oversubscribed threads were several times slower than 8 on this path in round 2)."""
     sweep = {}
     t_start = time.perf_counter()
-    for th in sorted({min(8, ncores), min(32, ncores), min(64, ncores), ncores}):
+    for th in sorted({min(c or ncores, ncores) for c in counts}):
         if sweep and time.perf_counter() - t_start > budget_s:
             break
         torch.set_num_threads(th)
@@ -144,7 +144,21 @@ def _cpu_thread_sweep(fn, ncores, budget_s=40.0):
     return best, sweep
 
 
-def extras(dev):
+def _variant(dev, make, step_of, iters, warmup):
+    """{ms_per_step, peak_mem_gb} of one model variant: built, timed, torn down; the peak is what the variant needs above
+    what was resident before it was built (inputs, cached graphs of the other sections)."""
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    m, opt = make()
+    ms = gpu_timed(step_of(m, opt), iters, warmup)
+    peak = (torch.cuda.max_memory_allocated(dev) - base) / 2 ** 30
+    del m, opt
+    return dict(ms_per_step=ms, peak_mem_gb=peak)
+
+
+def extras(dev, level="default"):
     """Driver-timed numbers of the other BASELINE configurations (single GPU, synthetic inputs, random-init weights),
     each timed like the headline (wall clock around K steps, synchronised) and with the CPU oracle beside it where a
     bounded CPU sample exists.  Model architectures: tests/arch_restated.py / tests/rev_restated.py (the reference's
@@ -186,32 +200,56 @@ def extras(dev):
                                                            "wrong ceiling for this shape, see DESIGN.md 5b"),
                                     cpu_baseline="this exact workload is the sample of the top-level cpu_baseline")
 
+    full = level == "full"
+    sect = {}
+    t_sect = time.perf_counter()
+    VARIANTS = (("reference_loop", dict()), ("reference_loop_install_fuse_models", dict(_fuse=True)),
+                ("res_plus_layer_full_recompute", dict(fused_layers=True, checkpoint="reference_full")),
+                ("res_plus_layer_keep_aggregation", dict(fused_layers=True)),
+                ("res_plus_layer_no_checkpoint", dict(fused_layers=True, checkpoint="never")))
+    VARIANT_NOTE = ("reference_loop = the model file's own layer loop (torch.utils.checkpoint around GENConv) on this gcn_lib; "
+                    "reference_loop_install_fuse_models = the SAME unchanged class after deep_gcns_torch_amd.install("
+                    "fuse_models=True) / fuse.fuse_model (its forward routed through res_plus_layer, full recompute); "
+                    "res_plus_layer_full_recompute = the loop body through deep_gcns_torch_amd.blocks.res_plus_layer "
+                    "(INTEGRATION.md), checkpointing LIKE THE REFERENCE: the backward recomputes the whole convolution, "
+                    "aggregation included -- the like-for-like number, reported as ms_per_step; "
+                    "res_plus_layer_keep_aggregation = the recomputation re-runs the node-wise part only and takes the "
+                    "aggregation's (N, C) results from the first pass (2-3 node-sized arrays per layer stay alive: see "
+                    "peak_mem_gb -- NOT the reference's memory behaviour); res_plus_layer_no_checkpoint = no checkpointing "
+                    "at all (nothing of size (E, C) exists here: a layer keeps (N, C) arrays only)")
     xa = torch.randn(s["n"], 128, device=dev)
     ya = torch.randint(0, 40, (s["n"],), device=dev)
-    d28 = {}
-    for name, kw in (("reference_loop", dict()), ("res_plus_layer", dict(fused_layers=True)),
-                     ("res_plus_layer_full_recompute", dict(fused_layers=True, checkpoint="reference_full")),
-                     ("res_plus_layer_no_checkpoint", dict(fused_layers=True, checkpoint="never"))):
-        m = arch_restated.DeeperGCN(num_layers=28, in_channels=128, hidden=128, num_tasks=40, dropout=0.5, **kw).to(dev).train()
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
-        def arxiv_step():
-            opt.zero_grad(set_to_none=True)
-            torch.nn.functional.nll_loss(m(xa, ei), ya).backward()
-            opt.step()
-        d28[name] = gpu_timed(arxiv_step, 5, 2)
-        del m, opt
+    def deeper(layers, cin, ncls, xin, yin, graph_ei):
+        res = {}
+        for name, kw in VARIANTS:
+            def make(kw=kw):
+                kw = dict(kw)
+                fuse_it = kw.pop("_fuse", False)
+                m = arch_restated.DeeperGCN(num_layers=layers, in_channels=cin, hidden=128, num_tasks=ncls, dropout=0.5, **kw).to(dev).train()
+                if fuse_it:
+                    from deep_gcns_torch_amd import fuse
+                    fuse.fuse_model(m)
+                return m, torch.optim.Adam(m.parameters(), lr=1e-3)
+
+            def step_of(m, opt):
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    torch.nn.functional.nll_loss(m(xin, graph_ei), yin).backward()
+                    opt.step()
+                return step
+            res[name] = _variant(dev, make, step_of, 5 if full else 3, 2)
+        return res
+    d28 = deeper(28, 128, 40, xa, ya, ei)
     out["deepergcn28_arxiv_train_step"] = dict(
         workload="DeeperGCN-28 GENConv softmax_sg 'res+' (ogbn_arxiv/model.py; BatchNorm, dropout 0.5 as the reference's "
-                 "defaults -- round 2 timed the loop WITHOUT dropout), full graph, fwd+bwd+Adam.  reference_loop = the model "
-                 "file's layer loop on this gcn_lib; res_plus_layer = the loop body through deep_gcns_torch_amd.blocks "
-                 "(INTEGRATION.md) with the reference's checkpointing, the recomputation re-running the node-wise part and "
-                 "taking the aggregation's (N, C) outputs from the first pass; *_full_recompute = the recomputation runs the "
-                 "aggregation again too (what torch.utils.checkpoint around GENConv does); *_no_checkpoint = no "
-                 "checkpointing (nothing of size (E, C) exists here: a layer keeps (N, C) arrays only)",
-        ms_per_step=d28["res_plus_layer"], ms_per_step_variants=d28,
-        edges_per_s=ei.size(1) * 28 / (d28["res_plus_layer"] * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
+                 "defaults), full graph, fwd+bwd+Adam.  " + VARIANT_NOTE,
+        ms_per_step=d28["res_plus_layer_full_recompute"]["ms_per_step"], variants=d28,
+        edges_per_s=ei.size(1) * 28 / (d28["res_plus_layer_full_recompute"]["ms_per_step"] * 1e-3), cpu_baseline=None,
+        cpu_baseline_note=CPU_NOTE)
     del g, x, go
+    sect["arxiv"] = time.perf_counter() - t_sect
+    t_sect = time.perf_counter()
 
     # ---- config 4 as the reference trains it: DeeperGCN-14 on one of 10 RANDOM node clusters of ogbn-products ---------
     # (examples/ogb/ogbn_products/main.py:120-124: random_partition_graph + induced sub-graph: a tenth of the nodes keeps a
@@ -221,25 +259,16 @@ def extras(dev):
     ei_c = synth.undirected_random_graph(n_c, sp["n_undirected"] // 100, sp["seed"] + 1, device=dev)
     xc = torch.randn(n_c, 100, device=dev)
     yc = torch.randint(0, 47, (n_c,), device=dev)
-    d14 = {}
-    for name, kw in (("reference_loop", dict()), ("res_plus_layer", dict(fused_layers=True)),
-                     ("res_plus_layer_full_recompute", dict(fused_layers=True, checkpoint="reference_full")),
-                     ("res_plus_layer_no_checkpoint", dict(fused_layers=True, checkpoint="never"))):
-        m = arch_restated.DeeperGCN(num_layers=14, in_channels=100, hidden=128, num_tasks=47, dropout=0.5, **kw).to(dev).train()
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-
-        def products_cluster_step():
-            opt.zero_grad(set_to_none=True)
-            torch.nn.functional.nll_loss(m(xc, ei_c), yc).backward()
-            opt.step()
-        d14[name] = gpu_timed(products_cluster_step, 5, 2)
-        del m, opt
+    d14 = deeper(14, 100, 47, xc, yc, ei_c)
     out["deepergcn14_products_cluster_train_step"] = dict(
         workload=f"DeeperGCN-14 GENConv softmax_sg hidden=128 dropout 0.5 (ogbn_products/model.py) on one random cluster of "
                  f"10: N={n_c} E={ei_c.size(1)}, fwd+bwd+Adam (variants as in deepergcn28_arxiv_train_step)",
-        ms_per_step=d14["res_plus_layer"], ms_per_step_variants=d14,
-        edges_per_s=ei_c.size(1) * 14 / (d14["res_plus_layer"] * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
+        ms_per_step=d14["res_plus_layer_full_recompute"]["ms_per_step"], variants=d14,
+        edges_per_s=ei_c.size(1) * 14 / (d14["res_plus_layer_full_recompute"]["ms_per_step"] * 1e-3), cpu_baseline=None,
+        cpu_baseline_note=CPU_NOTE)
     del xc, yc, ei_c
+    sect["products_cluster"] = time.perf_counter() - t_sect
+    t_sect = time.perf_counter()
 
     # ---- config 2 layer and model (B=8, N=4096, k=16, C=64) ------------------------------------------------------------
     B, N, C, k = 8, 4096, 64, 16
@@ -280,8 +309,9 @@ def extras(dev):
     def cpu_conv():
         xr = xc.clone().requires_grad_(True)
         dense_ref.edgeconv2d(xr, holder["ei"], ref_conv).backward(god_c)
-    th_knn, sw_knn = _cpu_thread_sweep(cpu_knn, ncores)
-    th_fb, sw_fb = _cpu_thread_sweep(cpu_conv, ncores)
+    counts = (8, 32, 64, 0) if full else (8, 32)       # 32 threads won every sweep of rounds 2-3 on the 256-thread hosts
+    th_knn, sw_knn = _cpu_thread_sweep(cpu_knn, ncores, counts=counts)
+    th_fb, sw_fb = _cpu_thread_sweep(cpu_conv, ncores, counts=counts)
     t_knn, t_fb = sw_knn[th_knn], sw_fb[th_fb]
     dense["cpu_baseline"] = dict(value=B * N * k / (t_knn + t_fb), unit="edges/s", cores=max(th_knn, th_fb), kind="port",
                                  sample=f"the same layer (kNN K=224 + EdgeConv2d fwd+bwd, B={B} N={N} C={C} k={k}), best of a "
@@ -293,20 +323,26 @@ def extras(dev):
     out["dense_layer"] = dense
     del conv, blk, xg, god
 
-    m = arch_restated.DenseDeepGCN(n_blocks=28, channels=64, k=16, in_channels=9, n_classes=13).to(dev).train()
     xin = torch.cat([torch.rand(8, 3, 4096, 1), torch.rand(8, 6, 4096, 1)], 1).to(dev)
     yd = torch.randint(0, 13, (8, 4096), device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
-    def dense_step():
-        opt.zero_grad(set_to_none=True)
-        torch.nn.functional.cross_entropy(m(xin), yd).backward()
-        opt.step()
-    ms = gpu_timed(dense_step, 5, 2)
+    def make_dense():
+        m = arch_restated.DenseDeepGCN(n_blocks=28, channels=64, k=16, in_channels=9, n_classes=13).to(dev).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def dense_step_of(m, opt):
+        def dense_step():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(xin), yd).backward()
+            opt.step()
+        return dense_step
+    r28 = _variant(dev, make_dense, dense_step_of, 5, 2)
     out["resgcn28_train_step"] = dict(workload="sem_seg_dense ResGCN-28 (B=8 x 4096 points, k=16, dilation 1..27), "
-                                               "fwd+bwd+Adam", ms_per_step=ms,
-                                      edges_per_s=8 * 4096 * 16 * 28 / (ms * 1e-3), cpu_baseline=None, cpu_baseline_note=CPU_NOTE)
-    del m, opt
+                                               "fwd+bwd+Adam", ms_per_step=r28["ms_per_step"], peak_mem_gb=r28["peak_mem_gb"],
+                                      edges_per_s=8 * 4096 * 16 * 28 / (r28["ms_per_step"] * 1e-3), cpu_baseline=None,
+                                      cpu_baseline_note=CPU_NOTE)
+    sect["dense"] = time.perf_counter() - t_sect
+    t_sect = time.perf_counter()
 
     # ---- config 5: RevGCN (hidden 224, group 2) on the ogbn-proteins cluster shape ----------------------------------
     s = synth.SHAPES["proteins_cluster"]
@@ -319,39 +355,47 @@ def extras(dev):
     eattr = torch.rand(Ep, 8, device=dev)
     yp = (torch.rand(Np, 112, device=dev) > 0.5).float()
     rev = {}
-    for name, layers, impl, fused, aggr in (
-            ("revgcn112_product", 112, "product", True, "max"), ("revgcn8_product", 8, "product", True, "max"),
-            ("revgcn112_product_composed_edge_encoders", 112, "product_composed", True, "max"),
+    rows = [("revgcn8_product", 8, "product", True, "max"),
+            ("revgcn8_model_file_install_fuse_models", 8, "product_modelfile_fused", True, "max"),
             ("revgcn8_product_composed_edge_encoders", 8, "product_composed", True, "max"),
-            ("revgcn8_power_product_composed_edge_encoders", 8, "product_composed", True, "power"),
-            ("revgcn8_product_pure_recompute", 8, "product_pure", True, "max"),
             ("revgcn8_reference_algorithm_stock_gemm", 8, "restated", False, "max"),
             # BASELINE.json words config 5 with power-mean aggregation (the reference's commands use max): both
             ("revgcn8_power_product", 8, "product", True, "power"),
-            ("revgcn8_power_product_keep_edge_state", 8, "product_edge", True, "power"),
-            ("revgcn8_power_reference_algorithm_stock_gemm", 8, "restated", False, "power")):
-        gc.collect()                       # the previous variant's model, gradients and optimiser state are gone;
-        torch.cuda.empty_cache()           # what is still allocated (inputs, cached graphs of the earlier sections) is the
-        base_bytes = torch.cuda.memory_allocated()      # baseline the model's own peak is measured above
+            ("revgcn8_power_reference_algorithm_stock_gemm", 8, "restated", False, "power")]
+    if full:
+        rows += [("revgcn112_product", 112, "product", True, "max"),
+                 ("revgcn112_product_composed_edge_encoders", 112, "product_composed", True, "max"),
+                 ("revgcn8_power_product_composed_edge_encoders", 8, "product_composed", True, "power"),
+                 ("revgcn8_product_pure_recompute", 8, "product_pure", True, "max"),
+                 ("revgcn8_power_product_keep_edge_state", 8, "product_edge", True, "power")]
+    keep_default = gcn_revop.KEEP_AGGREGATION
+    for name, layers, impl, fused, aggr in rows:
         ops.FUSED_EDGE_GEMM = fused
-        gcn_revop.KEEP_AGGREGATION = {"product_pure": False, "product_edge": "edge"}.get(impl, True)
-        m = rev_restated.RevGCN(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
-                                impl="product" if impl.startswith("product_") else impl,
-                                composed_edges=impl == "product_composed").to(dev).train()
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        gcn_revop.KEEP_AGGREGATION = {"product_pure": False, "product_edge": "edge"}.get(impl, keep_default)
 
-        def rev_step():
-            opt.zero_grad(set_to_none=True)
-            pred, _ = m(xin, nidx, eip, eattr)
-            torch.nn.functional.binary_cross_entropy_with_logits(pred, yp).backward()
-            opt.step()
-        torch.cuda.reset_peak_memory_stats()
-        ms = gpu_timed(rev_step, 3, 1)
-        rev[name] = dict(ms_per_step=ms, ms_per_layer=ms / layers, edges_per_s=Ep * layers * 2 / (ms * 1e-3),
-                         peak_mem_gb=(torch.cuda.max_memory_allocated() - base_bytes) / 2 ** 30)
-        del m, opt
+        def make(layers=layers, impl=impl, aggr=aggr):
+            cls = rev_restated.RevGCNModelFile if impl == "product_modelfile_fused" else rev_restated.RevGCN
+            m = cls(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
+                    impl="product" if impl.startswith("product_") else impl,
+                    composed_edges=impl == "product_composed").to(dev).train()
+            if impl == "product_modelfile_fused":       # the model file's own forward, fused from outside
+                from deep_gcns_torch_amd import fuse
+                fuse.fuse_model(m)
+            return m, torch.optim.Adam(m.parameters(), lr=1e-3)
+
+        def step_of(m, opt):
+            def rev_step():
+                opt.zero_grad(set_to_none=True)
+                pred = m(xin, nidx, eip, eattr)
+                pred = pred[0] if isinstance(pred, tuple) else pred
+                torch.nn.functional.binary_cross_entropy_with_logits(pred, yp).backward()
+                opt.step()
+            return rev_step
+        v = _variant(dev, make, step_of, 3, 1)
+        rev[name] = dict(ms_per_step=v["ms_per_step"], ms_per_layer=v["ms_per_step"] / layers,
+                         edges_per_s=Ep * layers * 2 / (v["ms_per_step"] * 1e-3), peak_mem_gb=v["peak_mem_gb"])
     ops.FUSED_EDGE_GEMM = True
-    gcn_revop.KEEP_AGGREGATION = True
+    gcn_revop.KEEP_AGGREGATION = keep_default
     rev["speedup_per_layer_vs_reference_algorithm_on_stock_gemm"] = (
         rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_product"]["ms_per_layer"])
     rev["speedup_per_layer_composed_edge_encoders_vs_reference_algorithm"] = (
@@ -384,10 +428,31 @@ def extras(dev):
                               fp32_equivalent_TFLOPs=2.0 * Ep * 224 * 112 / (ms_eg * 1e-3) / 1e12,
                               note="six bf16 MFMAs per fp32 product block: matrix-pipe work = 6x the fp32-equivalent flops "
                                    "against the 2500 TF dense bf16 peak; MFMA-busy from counters: profiles/")
+    # the per-edge encoder kernels (blocks.ComposedEdgeEmbedding: W' f_e + b' from the 8 raw features inside the walk)
+    f8 = torch.rand(Ep, 8, device=dev)
+    W8, b8 = (torch.randn(112, 8, device=dev) / 3).requires_grad_(True), torch.randn(112, device=dev).requires_grad_(True)
+    xq = xg.clone().requires_grad_(True)
+    gq = torch.randn(Np, 112, device=dev)
+    with torch.no_grad():
+        ms_enc_f = gpu_timed(lambda: ops.gen_aggregate(xg, gE, f8, aggr="max", edge_encoder=(W8, b8)), 30, 5)
+    ms_enc_fb = gpu_timed(lambda: torch.autograd.grad(ops.gen_aggregate(xq, gE, f8, aggr="max", edge_encoder=(W8, b8)),
+                                                      [xq, W8, b8], gq), 30, 5)
+    enc_f_bytes = Ep * (32 + 4 + 112 * 4) + Np * 112 * 8          # raw features + id + gathered x row; out + arg-max ids
+    enc_b_bytes = Ep * (32 + 4 + 112 * 4 * 2) + Np * 112 * 12     # + gathered g row (or arg-max row); grad_x written
+    rev["enc_layer"] = dict(ms_fwd=ms_enc_f, ms_fwd_bwd=ms_enc_fb,
+                            roofline_fwd=_hbm_roofline(enc_f_bytes, ms_enc_f, "gen_aggr_fwd_kernel<MAX,...,EA=2> (the x rows "
+                                                       "(5.9 MB) are L2-resident: the gathers are cache traffic, the HBM peak "
+                                                       "is the wrong ceiling -- the launch is latency-bound, DESIGN.md 4.13)"),
+                            roofline_bwd=_hbm_roofline(enc_b_bytes, max(ms_enc_fb - ms_enc_f, 1e-6),
+                                                       "gen_aggr_bwd_kernel<...,EA=2> (fwd+bwd minus fwd)"))
     del gE, xg, fg
     rev["cpu_baseline"] = None
     rev["cpu_baseline_note"] = CPU_NOTE
     out["revgcn_proteins"] = rev
+    sect["proteins"] = time.perf_counter() - t_sect
+    out["section_seconds"] = sect
+    out["level"] = level + (" (RevGCN-112, keep-edge-state / pure-recompute variants and the 64- / all-thread CPU sweeps: "
+                            "--extras full)" if not full else "")
     return out
 
 
@@ -489,6 +554,9 @@ def main():
     ap.add_argument("--t", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `extra` block (other configurations)")
+    ap.add_argument("--extras", default="default", choices=["none", "default", "full"],
+                    help="the `extra` block: default = one driver-sized pass over configurations 2, 3, 4 (cluster), 5; full "
+                         "adds RevGCN-112, the keep-edge-state / pure-recompute variants and the wide CPU thread sweeps")
     ap.add_argument("--fwd-only", action="store_true", help="profiling aid: skip the backward")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the RCCL multi-rank path even with one rank (sanity check)")
@@ -785,11 +853,14 @@ def main():
         if world > 1:
             res["config"]["note"] = "no multi-GPU curve had been measured when this was written (1-GPU gpurun boxes only)"
         if world == 1 and not partitioned and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t)
-        if world == 1 and not partitioned and not args.no_extras and args.shape == "products":
+            res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t,
+                                               counts=(8, 32, 64, 0) if args.extras == "full" else (8, 32))
+        if world == 1 and not partitioned and not args.no_extras and args.extras != "none" and args.shape == "products":
+            del x, x_full, g_full, graph
+            gc.collect()
             torch.cuda.empty_cache()
             try:
-                res["extra"] = extras(dev)
+                res["extra"] = extras(dev, args.extras)
             except Exception as exc:   # noqa: BLE001 -- the headline line must still come out
                 res["extra"] = {"error": repr(exc)[:300]}
         print(json.dumps(res), flush=True)

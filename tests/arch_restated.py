@@ -50,6 +50,7 @@ class DeeperGCN(torch.nn.Module):
         from gcn_lib.sparse.torch_vertex import GENConv
         self.num_layers = num_layers
         self.dropout = dropout
+        self.block = "res+"                      # ogbn_arxiv/model.py:16 (args.block; the README's command uses res+)
         self.fused_layers = fused_layers
         # the reference checkpoints the convolutions of deep softmax / power stacks because torch_scatter keeps several
         # (E, C) temporaries per layer alive; "never" = what a user of this package can do instead: nothing of size

@@ -180,3 +180,27 @@ class RevGCN(nn.Module):
         hn = self.last_norm(h)
         out = F.dropout(F.relu(hn), p=self.dropout, training=self.training)
         return self.node_pred_linear(out), hn
+
+
+class RevGCNModelFile(RevGCN):
+    """``RevGCN`` with the forward of the reference's model FILE (examples/ogb_eff/ogbn_proteins/model_rev.py:85-112):
+    signature ``(x, node_index, edge_index, edge_attr, epoch=-1)``, the dropout mask drawn inside, the prediction
+    returned alone -- what ``deep_gcns_torch_amd.fuse`` sees when the example script imports ``model_rev``."""
+
+    def forward(self, x, node_index, edge_index, edge_attr, epoch=-1):
+        node_features_1st = self.node_features[node_index]
+        if self.use_one_hot_encoding:
+            node_features = torch.cat((node_features_1st, self.node_one_hot_encoder(x)), dim=1)
+        else:
+            node_features = node_features_1st
+        h = self.node_features_encoder(node_features)
+        edge_emb = self.edge_encoder(edge_attr)
+        edge_emb = torch.cat([edge_emb] * self.group, dim=-1)
+        m = torch.zeros_like(h).bernoulli_(1 - self.dropout)
+        mask = m.requires_grad_(False) / (1 - self.dropout)
+        h = self.gcns[0](h, edge_index, mask, edge_emb)
+        for layer in range(1, self.num_layers):
+            h = self.gcns[layer](h, edge_index, mask, edge_emb)
+        h = F.relu(self.last_norm(h))
+        h = F.dropout(h, p=self.dropout, training=self.training)
+        return self.node_pred_linear(h)

@@ -95,3 +95,75 @@ def test_unsupported_options_fail_loudly(dropin):
         GraphConv(8, 8, "gat")
     with pytest.raises(NotImplementedError):
         GraphConv(8, 8, "bogus")
+
+
+@needs_ref
+def test_install_fuse_models_patches_the_real_model_files_on_import(dropin, tmp_path):
+    """What an example script does -- ``sys.path[0]`` is its own directory, ``from model import DeeperGCN`` /
+    ``from model_rev import RevGCN`` -- after ``install(fuse_models=True)``: the classes of the UNCHANGED files get the
+    fused forward (and keep their own as the fallback), the state_dict is the file's, and an instance that does not
+    qualify (CPU tensors here) runs the file's own loop."""
+    import os
+    import types
+    import deep_gcns_torch_amd
+    from deep_gcns_torch_amd import fuse
+    deep_gcns_torch_amd.install(reference_root=ref_models.REF, fuse_models=True)
+    if "torch_geometric" not in sys.modules:               # rev_layer.py's import block starts with torch_geometric
+        tgnn = types.ModuleType("torch_geometric.nn")
+        for n in ("GCNConv", "SAGEConv", "GATConv"):
+            setattr(tgnn, n, type(n, (torch.nn.Module,), {}))
+        tg = types.ModuleType("torch_geometric")
+        tg.nn = tgnn
+        sys.modules["torch_geometric"], sys.modules["torch_geometric.nn"] = tg, tgnn
+    try:
+        for sub, modname, clsname, repl in (("examples/ogb/ogbn_arxiv", "model", "DeeperGCN", fuse._deepergcn_forward),
+                                            ("examples/ogb/ogbn_products", "model", "DeeperGCN", fuse._deepergcn_forward),
+                                            ("examples/ogb_eff/ogbn_proteins", "model_rev", "RevGCN", fuse._revgcn_forward)):
+            d = os.path.join(ref_models.REF, sub)
+            for name in (modname, "__init__"):
+                sys.modules.pop(name, None)
+            sys.path.insert(0, d)
+            try:
+                with redirect_stdout(io.StringIO()):
+                    mod = __import__(modname)
+            finally:
+                sys.path.remove(d)
+            cls = getattr(mod, clsname)
+            assert mod.__file__.startswith(d)
+            assert cls.forward is repl and callable(cls.__dict__[fuse._ORIG])
+            for name in (modname, "__init__"):
+                sys.modules.pop(name, None)
+        # other model files (ogbn_proteins/model.py: forward(x, node_index, edge_index, edge_attr) of a DeeperGCN with
+        # edge encoders per layer) keep their forward
+        d = os.path.join(ref_models.REF, "examples/ogb/ogbn_proteins")
+        sys.path.insert(0, d)
+        try:
+            with redirect_stdout(io.StringIO()):
+                mod = __import__("model")
+        finally:
+            sys.path.remove(d)
+            for name in ("model", "__init__"):
+                sys.modules.pop(name, None)
+        assert fuse._ORIG not in mod.DeeperGCN.__dict__
+    finally:
+        fuse.disable_import_hook()
+    # the classes loaded by path (not through the hook) are fused explicitly; state_dict and CPU fallback
+    with redirect_stdout(io.StringIO()):
+        m = ref_models.arxiv_deepergcn(3)
+    before = list(m.state_dict())
+    fuse.fuse_model(m)
+    assert list(m.state_dict()) == before and type(m).__name__ == "DeeperGCN"
+    x, ei = torch.randn(20, 128), torch.randint(0, 20, (2, 60))
+    assert not fuse._deepergcn_qualifies(m, x, ei)          # CPU tensors: the file's own loop runs
+    from gcn_lib.sparse import torch_message
+    import config_replays
+    saved = torch_message.GenMessagePassing.propagate
+    torch_message.GenMessagePassing.propagate = config_replays.oracle_propagate
+    try:
+        m.eval()
+        with torch.no_grad():
+            out = m(x, ei)
+            ref = type(m).__dict__[fuse._ORIG](m, x, ei)
+    finally:
+        torch_message.GenMessagePassing.propagate = saved
+    assert torch.equal(out, ref)
