@@ -57,7 +57,10 @@ def test_fused_deepergcn_equals_the_model_files_loop(layers, norm, mlp_layers, m
         fuse.CHECKPOINT = saved
     torch.testing.assert_close(out_f, out_p, rtol=1e-4, atol=1e-5)
     for (k, a), (_, b) in zip(fused.named_parameters(), plain.named_parameters()):
-        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-5 * max(1.0, float(b.grad.abs().max())), msg=k)
+        # two fp32 evaluations of the same function (different kernels, different summation orders) through `layers`
+        # normalised layers: elementwise, relative to the tensor's own scale
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()),
+                                   msg=lambda m, k=k: f"{k}: {m}")
     for (k, a), (_, b) in zip(fused.named_buffers(), plain.named_buffers()):
         if "running" in k and ".mlp." not in k:          # (a BatchNorm inside a recomputed MLP updates twice per step)
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6, msg=k)
@@ -102,6 +105,7 @@ def test_fused_revgcn_equals_the_model_files_forward(aggr):
     torch.testing.assert_close(out_f, out_p, rtol=2e-4, atol=2e-4)
     for (k, a), (_, b) in zip(fused.named_parameters(), plain.named_parameters()):
         assert a.grad is not None, k
-        torch.testing.assert_close(a.grad, b.grad, rtol=2e-3, atol=2e-4 * max(1.0, float(b.grad.abs().max())), msg=k)
+        torch.testing.assert_close(a.grad, b.grad, rtol=2e-3, atol=2e-4 * max(1.0, float(b.grad.abs().max())),
+                                   msg=lambda m, k=k: f"{k}: {m}")
     # integer edge features (no Linear composition possible): the file's own forward
     assert not fuse._revgcn_qualifies(fused, x, ea.long())
