@@ -658,7 +658,184 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(const KnnParams 
   }
 }
 
-template <int R>
+// ---- wave-wide helpers of the bucket select ---------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes (the DPP network of wave_sum, every lane keeps its partial)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return v;
+}
+
+// wave-wide minimum, returned wave-uniform (lanes a DPP step does not write keep the identity)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  constexpr int kId = static_cast<int>(0xFFFFFFFFu);
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x111, 0xf, 0xf, false)));
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x112, 0xf, 0xf, false)));
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x114, 0xf, 0xf, false)));
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x118, 0xf, 0xf, false)));
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x142, 0xa, 0xf, false)));
+  v = min(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(kId, static_cast<int>(v), 0x143, 0xc, 0xf, false)));
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- bucket select: the Kout order statistics of a candidate list, no threshold search, no sort ----------------------
+// A dilated graph emits the neighbours of rank 0, d, 2d, ... only (gcn_lib/dense/torch_edge.py:26-28): k = K / d order
+// statistics of the candidate list, not its K sorted winners.  The 32-step bisection for the K-th key, the compaction of
+// the winners and the bitonic sort of up to 512 (key, id) pairs (~3,000 of the kernel's ~5,900 vector instructions per
+// wave at K = 432, profiles/r03_knn_filter_bf16_counters.md) are replaced by one counting pass:
+//   1. the keys are mapped monotonically onto NB = CAP buckets between the second-smallest key and the largest (the
+//      smallest is the query point itself at distance ~0, an outlier of the key range; it gets bucket 0);
+//   2. an LDS histogram and its prefix sum give every bucket its rank range [p_b, p_b + n_b);
+//   3. lane j < Kout finds the bucket that holds rank j d by binary search in the prefix array; the few candidates of
+//      those <= Kout buckets are copied into per-bucket lists;
+//   4. the lane picks the (j d - p_b)-th smallest (key, id) of its bucket's list (n_b is 1-3 on real data) and writes
+//      output position j.
+// Ranks are ranks in (key, id) order -- ties by lowest point id, as in the exact path -- and the list holds every key
+// <= tau_r, so the element of rank r < K of the list is the element of rank r of the row.  Anything unusual (more than
+// 32 outputs per row, a bucket holding more than 16 candidates -- duplicate points --, more than TCAP list entries)
+// returns false and the caller runs the bisection + sort path on the same registers.
+// scratch: the row's own list storage, CAP words at ``sa`` (prefix array) and CAP words at ``sb`` (byte map bucket ->
+// slot, slot tables, lists); the candidates are in registers by now.
+template <int R, int CAP>
+__device__ __forceinline__ bool bucket_select(const KnnParams& P, const uint32_t (&ck)[R], const uint32_t (&ci)[R], int cnt,
+                                              uint32_t* sa, uint32_t* sb, int b, int i, int lane) {
+  constexpr int NB = CAP;                     // buckets
+  constexpr int W = NB / kWave;               // prefix entries per lane in the scan
+  constexpr int TCAP = CAP / 4;               // list entries over all target buckets
+  constexpr int kMaxPerBucket = 16;
+  constexpr int kMaxOut = 32;
+  const int Kout = P.Kout, d = P.dilation;
+  if (Kout > kMaxOut) return false;           // wave-uniform
+  uint32_t* pref = sa;                                              // [NB]
+  unsigned char* slot_of = reinterpret_cast<unsigned char*>(sb);    // [NB] bytes
+  uint32_t* soff = sb + NB / 4;                                     // [32]
+  uint32_t* scnt = soff + kMaxOut;                                  // [32]
+  unsigned long long* list = reinterpret_cast<unsigned long long*>(scnt + kMaxOut);   // [TCAP] (key << 32 | id)
+
+  // 1. key range: smallest, second-smallest distinct, largest
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool valid = r * kWave + lane < cnt;
+    mn = min(mn, ck[r]);                      // (padding keys are 0xFFFFFFFF)
+    mx = max(mx, valid ? ck[r] : 0u);
+  }
+  const uint32_t kmin = wave_min_u32(mn);
+  const uint32_t hi = ~wave_min_u32(~mx);
+  uint32_t m2 = 0xFFFFFFFFu;
+#pragma unroll
+  for (int r = 0; r < R; ++r) m2 = min(m2, ck[r] > kmin ? ck[r] : 0xFFFFFFFFu);
+  uint32_t lo = wave_min_u32(m2);
+  if (lo > hi) lo = kmin;                     // every valid key equals kmin
+  const uint32_t span = hi - lo;
+  // bucket(key) = key < lo ? 0 : 1 + floor((key - lo) * inv / 2^32) <= NB - 1, monotone in key
+  float invf = static_cast<float>(NB - 2) * 4294967296.f / (static_cast<float>(span) + 1.f) * (1.f - 1.f / 4194304.f);
+  invf = fminf(invf, 4294967040.f);
+  const uint32_t inv = static_cast<uint32_t>(invf);
+
+  // 2. histogram
+  {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < W; q += 4) *reinterpret_cast<uint4*>(pref + lane * W + q) = z;
+    if (NB / 4 >= 4 * kWave) *reinterpret_cast<uint4*>(sb + lane * 4) = make_uint4(~0u, ~0u, ~0u, ~0u);
+    else *reinterpret_cast<uint2*>(sb + lane * 2) = make_uint2(~0u, ~0u);
+  }
+  wave_lds_sync();
+  uint32_t bk[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool valid = r * kWave + lane < cnt;
+    const uint32_t off = ck[r] - lo;
+    bk[r] = ck[r] < lo ? 0u : min(1u + __umulhi(off, inv), static_cast<uint32_t>(NB - 1));
+    if (valid) atomicAdd(&pref[bk[r]], 1u);
+  }
+  wave_lds_sync();
+  // prefix sum: lane l owns buckets [l W, l W + W)
+  {
+    uint32_t c[W];
+#pragma unroll
+    for (int q = 0; q < W; q += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(pref + lane * W + q);
+      c[q] = v.x; c[q + 1] = v.y; c[q + 2] = v.z; c[q + 3] = v.w;
+    }
+    uint32_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) { const uint32_t t = c[q]; c[q] = tot; tot += t; }
+    const uint32_t base = static_cast<uint32_t>(wave_scan_incl(static_cast<int>(tot))) - tot;
+#pragma unroll
+    for (int q = 0; q < W; q += 4)
+      *reinterpret_cast<uint4*>(pref + lane * W + q) = make_uint4(base + c[q], base + c[q + 1], base + c[q + 2], base + c[q + 3]);
+  }
+  wave_lds_sync();
+
+  // 3. lane j: the bucket of rank j d
+  const bool active = lane < Kout;
+  const uint32_t rank = static_cast<uint32_t>(active ? lane * d : 0);
+  int bj = 0;
+#pragma unroll
+  for (int step = NB / 2; step >= 1; step >>= 1)
+    if (pref[bj + step] <= rank) bj += step;
+  const uint32_t pj = pref[bj];
+  const uint32_t nxt = (bj + 1 < NB) ? pref[min(bj + 1, NB - 1)] : static_cast<uint32_t>(cnt);
+  const uint32_t nj = nxt - pj;
+  if (!active) bj = -1 - lane;                // distinct from every bucket and from each other
+  const int prev = __shfl_up(bj, 1);
+  const bool first = active && (lane == 0 || bj != prev);
+  if (__ballot(active && nj > static_cast<uint32_t>(kMaxPerBucket))) return false;
+  const unsigned long long mfirst = __ballot(first);
+  const int slot = __popcll(mfirst & ((2ull << lane) - 1ull)) - 1;        // slot of my bucket (first lanes: their own)
+  const int vcnt = first ? static_cast<int>(nj) : 0;
+  const int incl = wave_scan_incl(vcnt);
+  if (__builtin_amdgcn_readlane(incl, 63) > TCAP) return false;
+  if (first) {
+    slot_of[bj] = static_cast<unsigned char>(slot);
+    soff[slot] = static_cast<uint32_t>(incl - vcnt);
+    scnt[slot] = 0u;
+  }
+  wave_lds_sync();
+  // the candidates of the target buckets -> their bucket's list
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool valid = r * kWave + lane < cnt;
+    if (valid) {
+      const uint32_t sl = slot_of[bk[r]];
+      if (sl != 0xFFu) {
+        const uint32_t pos = soff[sl] + atomicAdd(&scnt[sl], 1u);
+        list[pos] = (static_cast<unsigned long long>(ck[r]) << 32) | ci[r];
+      }
+    }
+  }
+  wave_lds_sync();
+  // 4. the (rank - p_b)-th smallest of the bucket's list
+  if (active) {
+    const uint32_t off = soff[slot];
+    const uint32_t q = rank - pj;
+    unsigned long long ans = 0ull;
+    for (uint32_t u = 0; u < nj; ++u) {
+      const unsigned long long xu = list[off + u];
+      uint32_t below = 0;
+      for (uint32_t v = 0; v < nj; ++v) below += list[off + v] < xu ? 1u : 0u;
+      if (below == q) ans = xu;
+    }
+    const int64_t o = (static_cast<int64_t>(b) * P.N + i) * Kout + lane;
+    P.nn_out[o] = static_cast<int64_t>(static_cast<uint32_t>(ans));
+    if (P.ctr_out) P.ctr_out[o] = i;
+  }
+  return true;
+}
+
+template <int R, int CAP>
 __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* ckey, uint32_t* cidx, int cnt,
                                                   int b, int i, int lane) {
   const int K = P.K;
@@ -671,6 +848,10 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();  // candidates live in registers before their LDS slots are reused
+#ifndef KNNF_NO_BUCKET_SELECT
+  if (bucket_select<R, CAP>(P, ck, ci, cnt, ckey, cidx, b, i, lane)) return;
+  wave_lds_sync();
+#endif
   const uint32_t tau = kth_smallest<R>(ck, K);
   const int n_lt = count_below<R>(ck, tau, false);
   const int need_eq = K - n_lt;
@@ -881,11 +1062,11 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_kernel(const KnnParam
     }
     uint32_t* ck = ckey + rr * kFCap;
     uint32_t* ci = cidx + rr * kFCap;
-    if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
-    else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
-    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
-    else if (c <= 12 * kWave) filter_select_row<12>(P, ck, ci, c, b, i, lane);
-    else filter_select_row<16>(P, ck, ci, c, b, i, lane);
+    if (c <= 2 * kWave) filter_select_row<2, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (c <= 4 * kWave) filter_select_row<4, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (c <= 12 * kWave) filter_select_row<12, kFCap>(P, ck, ci, c, b, i, lane);
+    else filter_select_row<16, kFCap>(P, ck, ci, c, b, i, lane);
   }
 }
 
@@ -1139,11 +1320,11 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
     }
     uint32_t* ck = ckey + rr * kFCap;
     uint32_t* ci = cidx + rr * kFCap;
-    if (c <= 2 * kWave) filter_select_row<2>(P, ck, ci, c, b, i, lane);
-    else if (c <= 4 * kWave) filter_select_row<4>(P, ck, ci, c, b, i, lane);
-    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8>(P, ck, ci, c, b, i, lane);
-    else if (c <= 12 * kWave) filter_select_row<12>(P, ck, ci, c, b, i, lane);
-    else filter_select_row<16>(P, ck, ci, c, b, i, lane);
+    if (c <= 2 * kWave) filter_select_row<2, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (c <= 4 * kWave) filter_select_row<4, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (kFCap <= 8 * kWave || c <= 8 * kWave) filter_select_row<8, kFCap>(P, ck, ci, c, b, i, lane);
+    else if (c <= 12 * kWave) filter_select_row<12, kFCap>(P, ck, ci, c, b, i, lane);
+    else filter_select_row<16, kFCap>(P, ck, ci, c, b, i, lane);
   }
 }
 

@@ -59,7 +59,8 @@ def test_fused_deepergcn_equals_the_model_files_loop(layers, norm, mlp_layers, m
     for (k, a), (_, b) in zip(fused.named_parameters(), plain.named_parameters()):
         # two fp32 evaluations of the same function (different kernels, different summation orders) through `layers`
         # normalised layers: elementwise, relative to the tensor's own scale
-        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()),
+        # (a bias in front of a BatchNorm has a zero gradient: fp32 noise of 1e-9 on both sides, hence the floor)
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()) + 1e-7,
                                    msg=lambda m, k=k: f"{k}: {m}")
     for (k, a), (_, b) in zip(fused.named_buffers(), plain.named_buffers()):
         if "running" in k and ".mlp." not in k:          # (a BatchNorm inside a recomputed MLP updates twice per step)
