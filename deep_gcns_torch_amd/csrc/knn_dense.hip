@@ -1137,8 +1137,8 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
   constexpr int TM = kFTM;
   const int N = P.N, K = P.K;
   float* sq = reinterpret_cast<float*>(smem);                       // [16]
-  uint32_t* tau = reinterpret_cast<uint32_t*>(sq + TM);             // [16]
-  int* cnt = reinterpret_cast<int*>(tau + TM);                      // [16]
+  float* tauf = sq + TM;                                            // [16] threshold as a distance
+  int* cnt = reinterpret_cast<int*>(tauf + TM);                     // [16]
   uint32_t* ckey = reinterpret_cast<uint32_t*>(cnt + TM);           // [16][kFCap]
   uint32_t* cidx = ckey + TM * kFCap;                               // [16][kFCap]
 
@@ -1240,11 +1240,65 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
     }
     __syncthreads();
     {
+      // tau_r = an upper bound of the sample_rank-th smallest of the 512 sample keys, one bucket of a 256-bucket
+      // histogram wide (a threshold may overshoot by a couple of samples; the 20-step bisection that used to find it
+      // exactly cost 1,240 vector instructions per wave, 40 % of the K = 16 kernel): key range, histogram in LDS,
+      // prefix sum, the lane whose eight buckets hold the rank.  The range starts at the SECOND-smallest key: one row
+      // in eight has the query point itself among its samples (distance ~0: a key far below all others), which would
+      // stretch the buckets to several units of distance; keys below the range share bucket 0.
       uint32_t ks[8];
+      uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ks[q] = skeys[wave * 512 + q * kWave + lane];
-      const uint32_t tv = kth_smallest<8, 12>(ks, P.sample_rank);     // 12 low mantissa bits of a threshold do not matter
-      if (lane == 0) tau[wave] = tv;
+      for (int q = 0; q < 8; ++q) {
+        ks[q] = skeys[wave * 512 + q * kWave + lane];
+        mn = min(mn, ks[q]);
+        mx = max(mx, ks[q] == 0xFFFFFFFFu ? 0u : ks[q]);            // (padding of a last, partly filled tile)
+      }
+      mn = wave_min_u32(mn);
+      mx = ~wave_min_u32(~mx);
+      uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lo = min(lo, ks[q] > mn ? ks[q] : 0xFFFFFFFFu);
+      lo = wave_min_u32(lo);
+      if (lo > mx) lo = mn;                                         // every sample has the same key
+      const uint32_t span = mx - lo;
+      const int shift = max(0, 24 - static_cast<int>(__builtin_clz(span | 1u)));   // (span >> shift) < 256
+      uint32_t* hist = cidx + wave * 512;                           // [512] in the (still unused) id lists
+      *reinterpret_cast<uint4*>(hist + lane * 8) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(hist + lane * 8 + 4) = make_uint4(0u, 0u, 0u, 0u);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (ks[q] != 0xFFFFFFFFu) atomicAdd(&hist[ks[q] < lo ? 0u : 1u + ((ks[q] - lo) >> shift)], 1u);
+      wave_lds_sync();
+      uint32_t hc[8];
+      {
+        const uint4 h0 = *reinterpret_cast<const uint4*>(hist + lane * 8);
+        const uint4 h1 = *reinterpret_cast<const uint4*>(hist + lane * 8 + 4);
+        hc[0] = h0.x; hc[1] = h0.y; hc[2] = h0.z; hc[3] = h0.w; hc[4] = h1.x; hc[5] = h1.y; hc[6] = h1.z; hc[7] = h1.w;
+      }
+      uint32_t tot = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tot += hc[q];
+      const uint32_t incl = static_cast<uint32_t>(wave_scan_incl(static_cast<int>(tot)));
+      const uint32_t rank = static_cast<uint32_t>(P.sample_rank);
+      const bool mine = incl - tot < rank && rank <= incl;          // exactly one lane (rank <= the valid samples)
+      uint32_t run = incl - tot, bq = 8u * lane + 7u;
+#pragma unroll
+      for (int q = 7; q >= 0; --q) {                                // first bucket whose inclusive prefix reaches the rank
+        uint32_t upto = run;
+#pragma unroll
+        for (int u = 0; u <= q; ++u) upto += hc[u];
+        if (rank <= upto) bq = 8u * lane + q;
+      }
+      const unsigned long long mm = __ballot(mine);
+      const int src = mm ? static_cast<int>(__builtin_ctzll(mm)) : 63;
+      bq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bq), src));
+      // bucket 0 = keys below lo; bucket b >= 1 = keys lo + ((b - 1) << shift) .. lo + (b << shift) - 1
+      const unsigned long long edge = static_cast<unsigned long long>(lo) + (static_cast<unsigned long long>(bq) << shift) - 1ull;
+      const uint32_t tv = mm ? static_cast<uint32_t>(min(edge, 0xFFFFFFFEull)) : 0xFFFFFFFEu;
+      // the float with that key (key_of is monotone: distance <= tauf  <=>  key <= tv)
+      if (lane == 0) tauf[wave] = __uint_as_float((tv & 0x80000000u) ? (tv & 0x7FFFFFFFu) : ~tv);
     }
     __syncthreads();
   }
@@ -1275,34 +1329,28 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       in[t] = c < N;
       sj[t] = in[t] ? sqn[c] : 0.f;
     }
+    // Append the candidates below the row's threshold.  The compare runs on the distance itself (tauf = the float
+    // whose key is tau: float order == key order) and a hit takes its list position from ONE LDS atomic of its own:
+    // no ballot / prefix arithmetic per (row, tile) -- the lists are unordered sets, the select ranks by (key, id).
+    // (25 -> ~9 vector instructions per row-tile pair; at K = 16 two percent of the pairs are hits and whole
+    // hit-blocks are skipped.)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
-      const uint32_t tr = tau[r];
+      const float tf = tauf[r];
+      const float sr = sq[r];
       const int self = P.exclude_self ? i0 + r : -1;
-      uint32_t key[4];
-      bool hit[4];
-      unsigned long long m[4];
-      const unsigned long long grp = 0xFFFFull << (16 * lk);  // this row's lanes
-      int tot = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        key[t] = key_of((sq[r] + (-2.f * acc[t][reg])) + sj[t]);
-        hit[t] = in[t] && key[t] <= tr && (col0 + 16 * t + li) != self;
-        m[t] = __ballot(hit[t]) & grp;
-        tot += __popcll(m[t]);
-      }
-      int base = 0;
-      if (li == 0 && tot) base = atomicAdd(&cnt[r], tot);
-      base = __shfl(base, lk * 16);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int pos = base + __popcll(m[t] & below);
-        if (hit[t] && pos < kFCap) {
-          ckey[r * kFCap + pos] = key[t];
-          cidx[r * kFCap + pos] = static_cast<uint32_t>(col0 + 16 * t + li);
+        const float dist = (sr + (-2.f * acc[t][reg])) + sj[t];
+        const int c = col0 + 16 * t + li;
+        if (in[t] && dist <= tf && c != self) {
+          const int pos = atomicAdd(&cnt[r], 1);
+          if (pos < kFCap) {
+            ckey[r * kFCap + pos] = key_of(dist);
+            cidx[r * kFCap + pos] = static_cast<uint32_t>(c);
+          }
         }
-        base += __popcll(m[t]);
       }
     }
   }
