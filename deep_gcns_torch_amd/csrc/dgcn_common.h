@@ -57,6 +57,8 @@ template <int VEC>
 __device__ __forceinline__ void store_vec_i(int32_t* __restrict__ p, const int (&r)[VEC]) {
   if constexpr (VEC == 4) {
     *reinterpret_cast<int4*>(p) = make_int4(r[0], r[1], r[2], r[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<int2*>(p) = make_int2(r[0], r[1]);
   } else {
     *p = r[0];
   }
@@ -67,6 +69,9 @@ __device__ __forceinline__ void load_vec_i(int (&r)[VEC], const int32_t* __restr
   if constexpr (VEC == 4) {
     const int4 t = *reinterpret_cast<const int4*>(p);
     r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const int2 t = *reinterpret_cast<const int2*>(p);
+    r[0] = t.x; r[1] = t.y;
   } else {
     r[0] = *p;
   }

@@ -312,6 +312,225 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_kernel(const BwdParam
   gen_aggr_bwd_body<MODE, VEC, LPR, SW, EA>(P);
 }
 
+// ---------------------------------------------------------------------------------------
+// backward with the per-edge encoder (EA == 2), wave-uniform walk (see enc_fwd_body in gen_aggr_fwd.hip)
+// ---------------------------------------------------------------------------------------
+// One source row (or hub piece) per wave, all 64 lanes on the channels of ONE edge at a time.  Per 64-edge block lane l
+// stages edge blk + l: destination id, original edge id, its 32 bytes of raw features (parked in LDS, read back as two
+// broadcast ds_read_b128 when the edge is processed).  Per edge: the destination's coefficient row(s) are gathered
+// (g, plus log-sum-exp / arg-max ids / outputs by aggregator), z = x_s + W f_e + b is recomputed from registers,
+// dz accumulates into grad_x[s] and into this wave's dW | db sums.  The rows of the NEXT batch are requested before the
+// current batch is processed.
+template <int MODE, int VEC>
+__device__ __forceinline__ void enc_bwd_body(const BwdParams& P) {
+  constexpr bool SHIFTED = MODE == kModeSoftmaxShifted;
+  constexpr bool SOFT = MODE == DGCN_AGGR_SOFTMAX;
+  constexpr bool MAXM = MODE == DGCN_AGGR_MAX;
+  // edges per batch.  One gathered row per edge (add / mean / power / shifted softmax): batches of four, the next
+  // batch's rows requested before the current one is processed (U = 8 needs 174 VGPRs); two or three rows per edge
+  // (max: arg-max ids + g; softmax: g + log-sum-exp [+ out]): one batch at a time, four waves per SIMD hide the rest
+  constexpr int U = 4;
+  constexpr bool DB = !(SOFT || MAXM);
+  constexpr int NV = VEC * (kEncF + 1);
+  __shared__ __attribute__((aligned(16))) float sfeat[kWavesPerWg][kWave * kEncF];
+  __shared__ float red[kWavesPerWg][kWave * NV];
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  const int C = P.C;
+  const int c0 = lane * VEC;
+  const bool act = c0 < C;
+  const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
+  const int total_waves = gridDim.x * kWavesPerWg;
+  const int wave0 = virtual_block() * kWavesPerWg + wv;
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const int msg = P.msg;
+  const bool learn_t = SOFT && P.learn_t != 0;
+  const bool p_is_one = p == 1.f;
+  EncW<VEC> enc, genc;
+  enc_load<VEC>(enc, P.enc_w, P.enc_b, c0, act);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    genc.b[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) genc.w[j][f] = 0.f;
+  }
+  float ksh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) ksh[j] = 0.f;
+  if constexpr (SHIFTED) {
+    if (act) load_vec<VEC>(ksh, P.kshift + c0);
+  }
+
+  struct Stage { int col, eid; float4 f0, f1; };
+  auto stage_load = [&](const Work& w, int blk) -> Stage {
+    Stage sg;
+    sg.col = 0; sg.eid = 0;
+    sg.f0 = make_float4(0.f, 0.f, 0.f, 0.f); sg.f1 = sg.f0;
+    if (lane < w.end - blk) {
+      sg.col = P.g.col[blk + lane];
+      sg.eid = P.g.eperm ? P.g.eperm[blk + lane] : blk + lane;
+      const float4* fp = reinterpret_cast<const float4*>(P.enc_feat + static_cast<int64_t>(sg.eid) * kEncF);
+      sg.f0 = fp[0]; sg.f1 = fp[1];
+    }
+    return sg;
+  };
+  struct Rows { float gc[U][VEC], a1[U][VEC], oo[U][VEC]; int ai[U][VEC]; };
+
+  float* sf = sfeat[wv];
+  Work w = fetch_work<kWave>(P.g, wave0, n_items);
+  Stage sg = stage_load(w, w.beg);
+  for (int item = wave0; item < n_items; item += total_waves) {
+    const Work wn = fetch_work<kWave>(P.g, item + total_waves, n_items);
+    float xs[VEC], acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; }
+    if (act && w.row >= 0) load_vec<VEC>(xs, P.x + static_cast<int64_t>(w.row) * P.x_stride + c0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) xs[j] += enc.b[j];                    // z = (x_s + b) + W f_e
+    for (int blk = w.beg; blk < w.end || blk == w.beg; blk += kWave) {
+      const int nb = max(0, min(kWave, w.end - blk));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                 // the previous block's feature reads are done
+      *reinterpret_cast<float4*>(sf + lane * kEncF) = sg.f0;
+      *reinterpret_cast<float4*>(sf + lane * kEncF + 4) = sg.f1;
+      const int mycol = sg.col, myeid = sg.eid;
+      const bool last_blk = blk + kWave >= w.end;
+      sg = last_blk ? stage_load(wn, wn.beg) : stage_load(w, blk + kWave);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      auto load_batch = [&](Rows& R, int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { R.gc[u][j] = 0.f; R.a1[u][j] = 0.f; R.oo[u][j] = 0.f; R.ai[u][j] = -1; }
+          if (s0 + u < nb) {                                             // wave-uniform
+            const int dst = __builtin_amdgcn_readlane(mycol, s0 + u);
+            if (act) {
+              const int64_t ro = static_cast<int64_t>(dst) * C + c0;
+              if constexpr (SHIFTED) {
+                load_vec<VEC>(R.gc[u], P.gshift + ro);
+              } else {
+                load_vec<VEC>(R.gc[u], P.gcoef + ro);
+              }
+              if constexpr (SOFT) {
+                load_vec<VEC>(R.a1[u], static_cast<const float*>(P.aux1) + ro);
+                if (learn_t) load_vec<VEC>(R.oo[u], P.out + ro);
+              }
+              if constexpr (MAXM) load_vec_i<VEC>(R.ai[u], static_cast<const int32_t*>(P.aux1) + ro);
+            }
+          }
+        }
+      };
+      auto fold_batch = [&](const Rows& R, int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (s0 + u < nb) {                                             // wave-uniform
+            int eid = 0;
+            if constexpr (MAXM) eid = __builtin_amdgcn_readlane(myeid, s0 + u);
+            const float4 fa = *reinterpret_cast<const float4*>(sf + (s0 + u) * kEncF);   // broadcast reads
+            const float4 fb = *reinterpret_cast<const float4*>(sf + (s0 + u) * kEncF + 4);
+            const float fe[kEncF] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              float z = xs[j];
+#pragma unroll
+              for (int f = 0; f < kEncF; ++f) z = fmaf(enc.w[j][f], fe[f], z);
+              const float m = msg_apply(z, msg, eps);
+              const float r = (msg == DGCN_MSG_RELU_EPS) ? (z > 0.f ? 1.f : 0.f) : 1.f;
+              float k;
+              if constexpr (SOFT) {
+                float wgt = fast_exp(t * m - R.a1[u][j]);
+                if (learn_t) wgt *= 1.f + t * (m - R.oo[u][j]);
+                k = R.gc[u][j] * wgt;
+              } else if constexpr (SHIFTED) {
+                k = R.gc[u][j] * fast_exp(t * m - ksh[j]);
+              } else if constexpr (MODE == DGCN_AGGR_POWER) {
+                const bool in = (m >= kPowLo) && (m <= kPowHi);
+                const float uu = fminf(fmaxf(m, kPowLo), kPowHi);
+                k = in ? (p_is_one ? R.gc[u][j] : R.gc[u][j] * fast_pow(uu, p - 1.f)) : 0.f;
+              } else if constexpr (MAXM) {
+                k = (R.ai[u][j] == eid) ? R.gc[u][j] : 0.f;
+              } else {
+                k = R.gc[u][j];
+              }
+              const float dz = r * k;
+              acc[j] += dz;
+              genc.b[j] += dz;
+#pragma unroll
+              for (int f = 0; f < kEncF; ++f) genc.w[j][f] = fmaf(dz, fe[f], genc.w[j][f]);
+            }
+          }
+        }
+      };
+      if constexpr (DB) {
+        if (nb > 0) {
+          Rows ra, rb;
+          load_batch(ra, 0);
+          for (int s0 = 0; s0 < nb; s0 += 2 * U) {
+            if (s0 + U < nb) load_batch(rb, s0 + U);
+            fold_batch(ra, s0);
+            if (s0 + U < nb) {
+              if (s0 + 2 * U < nb) load_batch(ra, s0 + 2 * U);
+              fold_batch(rb, s0 + U);
+            }
+          }
+        }
+      } else {
+        for (int s0 = 0; s0 < nb; s0 += U) {
+          Rows ra;
+          load_batch(ra, s0);
+          fold_batch(ra, s0);
+        }
+      }
+      if (last_blk) break;
+    }
+    if (act && w.row >= 0) {
+      if (w.slot >= 0) {
+        store_vec<VEC>(P.ws + static_cast<int64_t>(w.slot) * C + c0, acc);
+      } else {
+        if (P.groot) {
+          float gr[VEC];
+          load_vec<VEC>(gr, P.groot + static_cast<int64_t>(w.row) * C + c0);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += gr[j];
+        }
+        store_vec<VEC>(P.grad_x + static_cast<int64_t>(w.row) * C + c0, acc);
+      }
+    }
+    w = wn;
+  }
+
+  // dW | db of this workgroup: the four waves through LDS in a fixed order, one (C, kEncF + 1) partial per workgroup
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+    for (int f = 0; f < kEncF; ++f) red[wv][lane * NV + j * (kEncF + 1) + f] = genc.w[j][f];
+    red[wv][lane * NV + j * (kEncF + 1) + kEncF] = genc.b[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kWave * NV; i += kWgThreads) {
+    const int ch = (i / NV) * VEC + (i % NV) / (kEncF + 1);
+    if (ch < C) {
+      const float tsum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+      P.enc_gpart[(static_cast<int64_t>(blockIdx.x) * C + ch) * (kEncF + 1) + (i % NV) % (kEncF + 1)] = tsum;
+    }
+  }
+}
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_enc_bwd_kernel(const BwdParams P) {
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+    if (P.gshift != nullptr && !P.learn_t && ((*P.shift_ok != 0) != (P.shift_bad != 0))) {
+      enc_bwd_body<kModeSoftmaxShifted, VEC>(P);
+      return;
+    }
+  }
+  enc_bwd_body<MODE, VEC>(P);
+}
+
 // Per-destination coefficient of the power-mean / mean backward, one streaming pass instead
 // of five elementwise torch kernels:  out[i,c] = g[i,c] * r^(1/p - 1) * [lo <= q <= hi] / max(deg_i, 1),
 // r = clamp(q, lo, hi), q = the forward's pre-clamp mean (aux1); q == nullptr gives the MEAN form g / max(deg, 1).
@@ -359,30 +578,31 @@ __global__ __launch_bounds__(kWgThreads) void softmax_bwd_prep_kernel(const floa
 }
 
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const BwdParams P) {
+  // one wave per (split row, block of 64 channels); the pieces of a row own consecutive items and slots
+  // (graph_build.hip work_fill_kernel): no dependent index loads, eight partial rows in flight, summed in piece order
   const int lane = lane_id();
   const int C = P.C;
-  const int n_work = P.g.n_work;
+  const int cblocks = (C + kWave - 1) / kWave;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  if (wave >= P.g.n_split) return;
-  const int i0 = uni(P.g.split_item[wave]);
+  if (wave >= P.g.n_split * cblocks) return;
+  const int i0 = uni(P.g.split_item[wave / cblocks]);
   const int row = uni(P.g.work_row[i0]);
-  int i1 = i0;
-  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
-  for (int c = lane; c < C; c += kWave) {
-    float acc = 0.f;
-    int i = i0;
-    for (; i + 4 <= i1; i += 4) {          // four partial rows in flight, summed in item order (a hub row has dozens)
-      const float v0 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i])) * C + c];
-      const float v1 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 1])) * C + c];
-      const float v2 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 2])) * C + c];
-      const float v3 = P.ws[static_cast<int64_t>(uni(P.g.work_slot[i + 3])) * C + c];
-      acc += v0; acc += v1; acc += v2; acc += v3;
-    }
-    for (; i < i1; ++i) acc += P.ws[static_cast<int64_t>(uni(P.g.work_slot[i])) * C + c];
-    P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
+  const int slot0 = uni(P.g.work_slot[i0]);
+  const int rbeg = uni(P.g.rowptr[row]), rend = uni(P.g.rowptr[row + 1]);
+  const int chunk = uni(P.g.work_end[i0]) - uni(P.g.work_beg[i0]);
+  const int npieces = (rend - rbeg + chunk - 1) / chunk;
+  const int c = (wave % cblocks) * kWave + lane;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int i = 0; i < npieces; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (i + k < npieces) ? P.ws[static_cast<int64_t>(slot0 + i + k) * C + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k];
   }
+  P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
 }
-
 template <int MODE, int VEC, int LPR, int SW>
 void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
   if constexpr (VEC == 4) {
@@ -400,7 +620,10 @@ void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
 
 template <int MODE>
 void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
-  if (vec == 4) {
+  if (vec == 4 && P.enc_feat && P.C >= 64 && P.C <= 256) {      // wave-uniform encoder walk (as in the forward)
+    if (P.C <= 128) hipLaunchKernelGGL((gen_aggr_enc_bwd_kernel<MODE, 2>), dim3(grid), dim3(kWgThreads), 0, s, P);
+    else hipLaunchKernelGGL((gen_aggr_enc_bwd_kernel<MODE, 4>), dim3(grid), dim3(kWgThreads), 0, s, P);
+  } else if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
     const int sw_sel = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows, P.n_edges_hint);
@@ -416,7 +639,8 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
     launch_bwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
-    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
+    const int mwaves = P.g.n_split * ((P.C + kWave - 1) / kWave);
+    const int mg = (mwaves + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL(gen_aggr_bwd_merge_kernel, dim3(mg), dim3(kWgThreads), 0, s, P);
   }
 }

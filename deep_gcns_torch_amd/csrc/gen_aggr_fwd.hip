@@ -247,38 +247,275 @@ __global__ __launch_bounds__(kWgThreads) DGCN_FWD_OCC void gen_aggr_fwd_kernel(c
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// forward with the per-edge encoder (EA == 2), wave-uniform walk
+// ---------------------------------------------------------------------------------------
+// blocks.ComposedEdgeEmbedding hands every GENConv of the reversible ogbn-proteins models 8 raw features per edge and
+// a composed Linear(8 -> C) (C = hidden / group = 112 at the reference's width): per edge 32 bytes of features, one
+// gathered 4C-byte row of x, C x 8 multiply-adds.  The general row walk above spends 164 registers on it (three waves
+// per SIMD), keeps eight edges in flight per wave and alternates load and arithmetic phases: 69 % of its wave cycles
+// wait (profiles/r03_revgcn8_composed_kernel_breakdown.md).  Here ONE row (or hub piece) per wave, all 64 lanes on
+// the channels of one edge at a time (VEC = 2 channels per lane up to C = 128, 4 up to 256), so that everything that
+// depends on the edge alone is wave-uniform:
+//   * 64 edges are staged per block: lane l fetches the column id, the edge id and the 32-byte feature row of edge
+//     blk + l (one coalesced and one 32-byte gathered load per lane) and parks the features in LDS; an edge's features
+//     then reach all lanes as two broadcast ds_read_b128 right before they are used -- no registers held across the
+//     memory wait, no per-lane copy of ids (v_readlane with a scalar index);
+//   * the x rows of the NEXT batch of eight edges are requested before the current batch is folded (two register
+//     sets), and the next block's staging loads are in flight during the current block;
+//   * the encoder's weights are loaded once per wave (the lane's channels never change), not once per row.
+// ~90 registers: five or six waves per SIMD, 16 row loads in flight each.
+constexpr int kEncBlk = kWave;
+
+template <int MODE, int VEC, bool WITH_D>
+__device__ __forceinline__ void enc_fwd_finish(const FwdParams& P, const Work& w, State<VEC>& st, int c0ch, float eps_r,
+                                               float p, uint32_t xs32) {
+  const int C = P.C;
+  if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if constexpr (WITH_D) st.d[j] = fmaf(eps_r, fmaf(eps_r, st.b[j], 2.f * st.c[j]), st.d[j]);
+      st.c[j] = fmaf(eps_r, st.b[j], st.c[j]);
+    }
+  }
+  if (w.slot >= 0) {
+    float* ws = P.ws + (static_cast<int64_t>(w.slot) * 4) * C + c0ch;
+    if constexpr (MODE == DGCN_AGGR_MAX) {
+      float fi[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) fi[j] = __int_as_float(st.idx[j]);
+      store_vec<VEC>(ws, st.a);
+      store_vec<VEC>(ws + C, fi);
+    } else {
+      store_vec<VEC>(ws, st.a);
+      store_vec<VEC>(ws + C, st.b);
+      store_vec<VEC>(ws + 2 * C, st.c);
+      store_vec<VEC>(ws + 3 * C, st.d);
+    }
+    return;
+  }
+  const int64_t o = static_cast<int64_t>(w.row) * C + c0ch;
+  const float deg = static_cast<float>(w.end - w.beg);
+  float res[VEC], x1[VEC], x2[VEC];
+  int xi[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    x1[j] = 0.f; x2[j] = 0.f; xi[j] = -1;
+    if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
+      const bool any = st.b[j] > 0.f;
+      const float inv = any ? 1.f / st.b[j] : 0.f;
+      res[j] = st.c[j] * inv;
+      x1[j] = any ? (st.a[j] + fast_log2(st.b[j])) * 0.6931471805599453f : 0.f;
+      x2[j] = st.d[j] * inv;
+      if (P.range_flag && !(fabsf(x1[j]) < kShiftSafe)) atomicOr(P.range_flag, 1);  // rare
+    } else if constexpr (MODE == DGCN_AGGR_POWER) {
+      const float q = st.b[j] / fmaxf(deg, 1.f);
+      const float r = fminf(fmaxf(q, kPowLo), kPowHi);
+      res[j] = fast_pow(r, 1.f / p);
+      x1[j] = q;
+      x2[j] = st.d[j];
+    } else if constexpr (MODE == DGCN_AGGR_MAX) {
+      res[j] = st.idx[j] >= 0 ? st.a[j] : 0.f;
+      xi[j] = st.idx[j];
+    } else if constexpr (MODE == DGCN_AGGR_MEAN) {
+      res[j] = st.b[j] / fmaxf(deg, 1.f);
+    } else {
+      res[j] = st.b[j];
+    }
+  }
+  if (P.add_root) {
+    float xr[VEC];
+    load_vec<VEC>(xr, row_ptr(P.x, w.row, xs32) + c0ch);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) res[j] += xr[j];
+  }
+  store_vec<VEC>(P.out + o, res);
+  if constexpr (MODE == DGCN_AGGR_MAX) {
+    if (P.aux1) store_vec_i<VEC>(static_cast<int32_t*>(P.aux1) + o, xi);
+  } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
+    if (P.aux1) store_vec<VEC>(static_cast<float*>(P.aux1) + o, x1);
+    if (P.aux2) store_vec<VEC>(P.aux2 + o, x2);
+  }
+}
+
+template <int MODE, int VEC, bool RELU, bool WITH_D>
+__device__ __forceinline__ void enc_fwd_body(const FwdParams& P) {
+  constexpr int U = 8;                       // edges per batch (two batches of row loads in flight)
+  __shared__ __attribute__((aligned(16))) float sfeat[kWavesPerWg][kEncBlk * kEncF];
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  const int C = P.C;
+  const int c0ch = lane * VEC;
+  const bool act = c0ch < C;
+  const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
+  const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
+  const int total_waves = gridDim.x * kWavesPerWg;
+  const int wave0 = virtual_block() * kWavesPerWg + wv;
+  const float t = P.t_dev ? *P.t_dev : P.t;
+  const float p = P.p_dev ? *P.p_dev : P.p;
+  const float eps = P.eps;
+  const float eps_r = RELU ? eps : 0.f;
+  const float t2 = t * 1.4426950408889634f;
+  const float c0 = t2 * eps_r;
+  EncW<VEC> enc;
+  enc_load<VEC>(enc, P.enc_w, P.enc_b, c0ch, act);
+
+  // staging loads of one 64-edge block: this lane's edge
+  struct Stage { int col, eid; float4 f0, f1; };
+  auto stage_load = [&](const Work& w, int blk) -> Stage {
+    Stage s;
+    s.col = 0; s.eid = 0;
+    s.f0 = make_float4(0.f, 0.f, 0.f, 0.f); s.f1 = s.f0;
+    if (lane < w.end - blk) {
+      s.col = P.g.col[blk + lane];
+      s.eid = P.g.eperm ? P.g.eperm[blk + lane] : blk + lane;
+      const float4* fp = reinterpret_cast<const float4*>(P.enc_feat + static_cast<int64_t>(s.eid) * kEncF);
+      s.f0 = fp[0]; s.f1 = fp[1];
+    }
+    return s;
+  };
+
+  float* sf = sfeat[wv];
+  Work w = fetch_work<kWave>(P.g, wave0, n_items);
+  Stage sg = stage_load(w, w.beg);
+  for (int item = wave0; item < n_items; item += total_waves) {
+    const Work wn = fetch_work<kWave>(P.g, item + total_waves, n_items);
+    State<VEC> st;
+    state_init<MODE, VEC>(st);
+    for (int blk = w.beg; blk < w.end || blk == w.beg; blk += kEncBlk) {
+      const int nb = max(0, min(kEncBlk, w.end - blk));
+      // park this block's features (a wave's LDS operations complete in order: the previous block's reads are done),
+      // request the next block's -- or the next item's first block
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      *reinterpret_cast<float4*>(sf + lane * kEncF) = sg.f0;
+      *reinterpret_cast<float4*>(sf + lane * kEncF + 4) = sg.f1;
+      const int mycol = sg.col, myeid = sg.eid;
+      const bool last_blk = blk + kEncBlk >= w.end;
+      sg = last_blk ? stage_load(wn, wn.beg) : stage_load(w, blk + kEncBlk);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      float va[U][VEC], vb[U][VEC];
+      auto load_batch = [&](float (&v)[U][VEC], int s0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[u][j] = 0.f;
+          if (s0 + u < nb) {                                     // wave-uniform
+            const int src = __builtin_amdgcn_readlane(mycol, s0 + u);
+            if (act) load_vec<VEC>(v[u], row_ptr(P.x, src, xs32) + c0ch);
+          }
+        }
+      };
+      auto fold_batch = [&](float (&v)[U][VEC], int s0) {
+        bool ok[U];
+        int eid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ok[u] = s0 + u < nb;
+          eid[u] = 0;
+          if (ok[u]) {
+            if constexpr (MODE == DGCN_AGGR_MAX) eid[u] = __builtin_amdgcn_readlane(myeid, s0 + u);
+            const float4 a = *reinterpret_cast<const float4*>(sf + (s0 + u) * kEncF);       // broadcast reads
+            const float4 b = *reinterpret_cast<const float4*>(sf + (s0 + u) * kEncF + 4);
+            const float fe[kEncF] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            float e[VEC];
+            enc_apply<VEC>(e, enc, fe);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[u][j] += e[j];
+          }
+        }
+        if (s0 + U <= nb) accumulate<MODE, VEC, U, RELU, WITH_D, true>(st, v, ok, eid, eps, t2, c0, p);
+        else accumulate<MODE, VEC, U, RELU, WITH_D, false>(st, v, ok, eid, eps, t2, c0, p);
+      };
+      if (nb > 0) {
+        load_batch(va, 0);
+        for (int s0 = 0; s0 < nb; s0 += 2 * U) {
+          if (s0 + U < nb) load_batch(vb, s0 + U);
+          fold_batch(va, s0);
+          if (s0 + U < nb) {
+            if (s0 + 2 * U < nb) load_batch(va, s0 + 2 * U);
+            fold_batch(vb, s0 + U);
+          }
+        }
+      }
+      if (last_blk) break;
+    }
+    if (act && w.row >= 0) enc_fwd_finish<MODE, VEC, WITH_D>(P, w, st, c0ch, eps_r, p, xs32);
+    w = wn;
+  }
+}
+
+template <int MODE, int VEC, bool WITH_D>
+__global__ __launch_bounds__(kWgThreads) void gen_aggr_enc_fwd_kernel(const FwdParams P) {
+  if (P.msg == DGCN_MSG_RELU_EPS) {
+    enc_fwd_body<MODE, VEC, true, WITH_D>(P);
+  } else {
+    enc_fwd_body<MODE, VEC, false, WITH_D>(P);
+  }
+}
+
+template <int MODE, int VEC>
+void launch_enc_fwd(const FwdParams& P, int grid, hipStream_t s) {
+  constexpr bool CAN_D = MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER;
+  if constexpr (CAN_D) {
+    if (P.aux2) {
+      hipLaunchKernelGGL((gen_aggr_enc_fwd_kernel<MODE, VEC, true>), dim3(grid), dim3(kWgThreads), 0, s, P);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gen_aggr_enc_fwd_kernel<MODE, VEC, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
+}
+
 // Merge the partial slots of split (hub) rows: one wave per split row (its first work item is listed in
 // split_item), lanes over channels, slots folded in work-list order -> deterministic.
 template <int MODE>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const FwdParams P) {
   const int lane = lane_id();
   const int C = P.C;
-  const int n_work = P.g.n_work;
+  // one wave per (split row, block of 64 channels): the pieces of a row own CONSECUTIVE items and slots
+  // (graph_build.hip work_fill_kernel), so nothing here depends on a loaded index; the partial states are fetched
+  // four pieces at a time and folded in piece order -> deterministic
+  const int cblocks = (C + kWave - 1) / kWave;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
-  if (wave >= P.g.n_split) return;
+  if (wave >= P.g.n_split * cblocks) return;
   const float p = P.p_dev ? *P.p_dev : P.p;
-  const int i0 = uni(P.g.split_item[wave]);
+  const int i0 = uni(P.g.split_item[wave / cblocks]);
   const int row = uni(P.g.work_row[i0]);
-  const float deg = static_cast<float>(P.g.rowptr[row + 1] - P.g.rowptr[row]);
-  int i1 = i0;
-  while (i1 < n_work && uni(P.g.work_row[i1]) == row) ++i1;
-  for (int c = lane; c < C; c += kWave) {
+  const int slot0 = uni(P.g.work_slot[i0]);
+  const int rbeg = uni(P.g.rowptr[row]), rend = uni(P.g.rowptr[row + 1]);
+  const float deg = static_cast<float>(rend - rbeg);
+  const int chunk = uni(P.g.work_end[i0]) - uni(P.g.work_beg[i0]);          // every piece but the last is this long
+  const int npieces = (rend - rbeg + chunk - 1) / chunk;
+  {
+    const int c = (wave % cblocks) * kWave + lane;
+    if (c >= C) return;
     State<1> st;
     state_init<MODE, 1>(st);
-    for (int i = i0; i < i1; ++i) {
-      const float* ws = P.ws + (static_cast<int64_t>(P.g.work_slot[i]) * 4) * C + c;
-      State<1> o;
-      state_init<MODE, 1>(o);
-      if constexpr (MODE == DGCN_AGGR_MAX) {
-        o.a[0] = ws[0];
-        o.idx[0] = __float_as_int(ws[C]);
-      } else {
-        o.a[0] = ws[0];
-        o.b[0] = ws[C];
-        o.c[0] = ws[2 * C];
-        o.d[0] = ws[3 * C];
+    constexpr int NQ = (MODE == DGCN_AGGR_MAX) ? 2 : 4;
+    for (int i = 0; i < npieces; i += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* ws = P.ws + (static_cast<int64_t>(slot0 + min(i + k, npieces - 1)) * 4) * C + c;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[k][q] = ws[static_cast<int64_t>(q) * C];
       }
-      state_merge<MODE, 1>(st, o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i + k < npieces) {
+          State<1> o;
+          state_init<MODE, 1>(o);
+          o.a[0] = v[k][0];
+          if constexpr (MODE == DGCN_AGGR_MAX) {
+            o.idx[0] = __float_as_int(v[k][1]);
+          } else {
+            o.b[0] = v[k][1]; o.c[0] = v[k][2]; o.d[0] = v[k][3];
+          }
+          state_merge<MODE, 1>(st, o);
+        }
+      }
     }
     const int64_t o = static_cast<int64_t>(row) * C + c;
     float res, x1 = 0.f, x2 = 0.f;
@@ -339,9 +576,14 @@ void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
   }
 }
 
+// the wave-uniform encoder walk serves rows of 64 .. 256 channels (at least half of the lanes busy)
+inline bool enc_uniform_walk(const FwdParams& P, int vec) { return vec == 4 && P.enc_feat && P.C >= 64 && P.C <= 256; }
+
 template <int MODE>
 void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
-  if (vec == 4) {
+  if (enc_uniform_walk(P, vec)) {
+    if (P.C <= 128) launch_enc_fwd<MODE, 2>(P, grid, s); else launch_enc_fwd<MODE, 4>(P, grid, s);
+  } else if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
     const int sw_sel = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows, P.n_edges_hint);
@@ -357,7 +599,8 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
     launch_fwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
-    const int mg = (P.g.n_split + kWavesPerWg - 1) / kWavesPerWg;
+    const int mwaves = P.g.n_split * ((P.C + kWave - 1) / kWave);
+    const int mg = (mwaves + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL((gen_aggr_fwd_merge_kernel<MODE>), dim3(mg), dim3(kWgThreads), 0, s, P);
   }
 }

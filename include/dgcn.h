@@ -74,7 +74,10 @@ typedef struct dgcn_graph {
   const int32_t* t_col;    /* [E]       destination node of CSC position e                */
   const int32_t* t_eperm;  /* [E]       original edge id of CSC position e                */
   /* Optional work list that splits high-degree rows into chunks (deterministic hub
-   * handling).  n_work == 0 means "one work item per row".                               */
+   * handling).  n_work == 0 means "one work item per row".  Layout contract (what
+   * dgcn_graph_work_list produces and the merge kernels rely on): the pieces of a split
+   * row are CONSECUTIVE items with CONSECUTIVE slot ids, in edge order, all pieces but
+   * the last of equal length.                                                            */
   int32_t n_work;
   int32_t n_slots;         /* number of partial-result slots used by split rows            */
   const int32_t* work_row; /* [n_work] row of each item                                    */

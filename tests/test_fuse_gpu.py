@@ -56,15 +56,67 @@ def test_fused_deepergcn_equals_the_model_files_loop(layers, norm, mlp_layers, m
     finally:
         fuse.CHECKPOINT = saved
     torch.testing.assert_close(out_f, out_p, rtol=1e-4, atol=1e-5)
-    for (k, a), (_, b) in zip(fused.named_parameters(), plain.named_parameters()):
-        # two fp32 evaluations of the same function (different kernels, different summation orders) through `layers`
-        # normalised layers: elementwise, relative to the tensor's own scale
-        # (a bias in front of a BatchNorm has a zero gradient: fp32 noise of 1e-9 on both sides, hence the floor)
-        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * float(b.grad.abs().max()) + 1e-7,
-                                   msg=lambda m, k=k: f"{k}: {m}")
-    for (k, a), (_, b) in zip(fused.named_buffers(), plain.named_buffers()):
-        if "running" in k and ".mlp." not in k:          # (a BatchNorm inside a recomputed MLP updates twice per step)
-            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6, msg=k)
+    # Gradients.  A deep stack cannot be compared with its float64 evaluation (or two fp32 evaluations with each other)
+    # elementwise: a ReLU whose pre-activation lies within fp32 rounding of zero takes different branches in two
+    # evaluations, and one flipped element moves a weight gradient by percents (attribution.ReluDecisions).  The
+    # yardstick is the float64 evaluation of the model file's loop on the host (oracle aggregation) ALONG THE DEVICE
+    # RUN'S ReLU DECISIONS, one replay per route: every parameter gradient of both routes must match its replay to fp32
+    # rounding.
+    import attribution
+    import config_replays
+    from gcn_lib.sparse import torch_message
+
+    def float64_along(decisions):
+        ref = copy.deepcopy(plain).cpu().double()
+        for q in ref.parameters():
+            q.grad = None
+        ref.checkpoint_grad = False
+        saved_prop = torch_message.GenMessagePassing.propagate
+
+        def propagate(self, *a, **k):             # (the message ReLU lives inside the aggregation: not a replayed site)
+            with decisions.suspended():
+                return config_replays.oracle_propagate(self, *a, **k)
+        torch_message.GenMessagePassing.propagate = propagate
+        try:
+            with decisions.replaying():
+                torch.nn.functional.nll_loss(ref(x.cpu().double(), ei.cpu()), y.cpu()).backward()
+        finally:
+            torch_message.GenMessagePassing.propagate = saved_prop
+        return dict(ref.named_parameters())
+
+    for route, model in (("model file's loop", plain), ("fused route", fused)):
+        for q in model.parameters():
+            q.grad = None
+        dec = attribution.ReluDecisions()
+        saved_mode = fuse.CHECKPOINT
+        fuse.CHECKPOINT = mode
+        try:
+            # the recomputation of a checkpointed layer repeats its ReLU sites: record the first (no-grad) visit only
+            model_ckpt = model.checkpoint_grad
+            model.checkpoint_grad = False
+            with dec.recording():
+                loss = torch.nn.functional.nll_loss(model(x, ei), y)
+            model.checkpoint_grad = model_ckpt
+            for q in model.parameters():
+                q.grad = None
+            torch.nn.functional.nll_loss(model(x, ei), y).backward()       # the route as shipped, checkpointing on
+        finally:
+            fuse.CHECKPOINT = saved_mode
+        ref_params = float64_along(dec)
+        worst = 0.0
+        for k, a in model.named_parameters():
+            r = ref_params[k].grad
+            scale = float(r.abs().max())
+            if scale < 1e-9:               # (a bias in front of a BatchNorm: the true gradient is zero, fp32 noise here)
+                assert float(a.grad.abs().max()) < 1e-6, k
+                continue
+            err = float((a.grad.cpu().double() - r).abs().max()) / scale
+            worst = max(worst, err)
+            # fp32 rounding through up to 20 normalised layers (measured: <= 1.1e-4 for the 10-layer stacks, 4e-6 for
+            # the 4-layer one, the model file's own loop and the fused route alike)
+            assert err < 3e-4, f"{route}, {k}: {err:.2e} of max |grad| away from the float64 gradient along its own branches"
+        print(f"[fuse {layers}-{norm}-{mlp_layers}-{mode}] {route}: {dec.n_decisions()} ReLU decisions replayed, worst "
+              f"gradient error {worst:.2e} of max |grad|")
     # an instance that does not qualify takes the model file's own forward: another block type, CPU tensors
     fused.block = "plain"
     assert not fuse._deepergcn_qualifies(fused, x, ei)
