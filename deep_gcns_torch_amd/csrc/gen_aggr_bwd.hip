@@ -6,6 +6,8 @@
 
 #include "gen_aggr_common.h"
 
+extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
+
 namespace dgcn {
 namespace {
 
@@ -340,8 +342,6 @@ __device__ __forceinline__ void enc_bwd_body(const BwdParams& P) {
   const int c0 = lane * VEC;
   const bool act = c0 < C;
   const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
-  const int total_waves = gridDim.x * kWavesPerWg;
-  const int wave0 = virtual_block() * kWavesPerWg + wv;
   const float t = P.t_dev ? *P.t_dev : P.t;
   const float p = P.p_dev ? *P.p_dev : P.p;
   const float eps = P.eps;
@@ -379,10 +379,13 @@ __device__ __forceinline__ void enc_bwd_body(const BwdParams& P) {
   struct Rows { float gc[U][VEC], a1[U][VEC], oo[U][VEC]; int ai[U][VEC]; };
 
   float* sf = sfeat[wv];
-  Work w = fetch_work<kWave>(P.g, wave0, n_items);
+  ItemQueue q;
+  int item = q.first(P.ticket);
+  Work w = fetch_work<kWave>(P.g, item, n_items);
   Stage sg = stage_load(w, w.beg);
-  for (int item = wave0; item < n_items; item += total_waves) {
-    const Work wn = fetch_work<kWave>(P.g, item + total_waves, n_items);
+  while (item < n_items) {
+    const int next = q.next(P.ticket);
+    const Work wn = fetch_work<kWave>(P.g, next, n_items);
     float xs[VEC], acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { xs[j] = 0.f; acc[j] = 0.f; }
@@ -501,6 +504,7 @@ __device__ __forceinline__ void enc_bwd_body(const BwdParams& P) {
       }
     }
     w = wn;
+    item = next;
   }
 
   // dW | db of this workgroup: the four waves through LDS in a fixed order, one (C, kEncF + 1) partial per workgroup
@@ -594,12 +598,12 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
   const int c = (wave % cblocks) * kWave + lane;
   if (c >= C) return;
   float acc = 0.f;
-  for (int i = 0; i < npieces; i += 8) {
-    float v[8];
+  for (int i = 0; i < npieces; i += 16) {
+    float v[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (i + k < npieces) ? P.ws[static_cast<int64_t>(slot0 + i + k) * C + c] : 0.f;
+    for (int k = 0; k < 16; ++k) v[k] = (i + k < npieces) ? P.ws[static_cast<int64_t>(slot0 + i + k) * C + c] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc += v[k];
+    for (int k = 0; k < 16; ++k) acc += v[k];
   }
   P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
 }
@@ -756,7 +760,12 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   if (!g->t_rowptr || (g->n_edges > 0 && (!g->t_col || !g->t_eperm))) return DGCN_E_NULL;
   if (g->t_n_work && (!g->t_work_row || !g->t_work_beg || !g->t_work_end || !g->t_work_slot)) return DGCN_E_NULL;
   if (g->t_n_work && g->t_n_split > 0 && !g->t_split_item) return DGCN_E_NULL;
-  if (workspace_bytes < dgcn_gen_aggr_bwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
+  {
+    const size_t full = dgcn_gen_aggr_bwd_workspace_bytes(g, channels);
+    const bool walk = enc && channels % 4 == 0 && channels >= 64 && channels <= 256;
+    const size_t slots = g->t_n_work ? static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float) : 0;
+    if (workspace_bytes < (walk ? full : slots)) return DGCN_E_WORKSPACE;
+  }
   if (g->t_n_work && g->t_n_slots > 0 && !workspace) return DGCN_E_NULL;
 
   const bool vec4 = (channels % 4 == 0) && (x_stride % 4 == 0) && aligned16(x) && aligned16(gcoef) &&
@@ -794,7 +803,14 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
     P.shift_bad = (flags & DGCN_FLAG_SHIFT_FLAG_IS_RANGE) ? 1 : 0;
   }
   P.ws = static_cast<float*>(workspace);
-
+  P.ticket = nullptr;
+  if (enc && vec4 && channels >= 64 && channels <= 256) {       // wave-uniform encoder walk: work-item counter
+    if (!workspace) return DGCN_E_NULL;
+    P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
+                                          dgcn_gen_aggr_bwd_workspace_bytes(g, channels) - kTicketBytes);
+    const hipError_t me = hipMemsetAsync(P.ticket, 0, kTicketBytes, static_cast<hipStream_t>(stream));
+    if (me != hipSuccess) return static_cast<int>(me);
+  }
   const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (mode) {
@@ -841,8 +857,9 @@ extern "C" int dgcn_power_bwd_prep_f32(const dgcn_graph* g, const float* grad_ou
 }
 
 extern "C" size_t dgcn_gen_aggr_bwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
-  if (!g || g->t_n_work == 0) return 0;
-  return static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float);
+  if (!g) return 0;
+  const size_t slots = g->t_n_work ? static_cast<size_t>(g->t_n_slots) * static_cast<size_t>(channels) * sizeof(float) : 0;
+  return (slots + 255u) / 256u * 256u + kTicketBytes;     // + the work-item counter of the encoder walk
 }
 
 

@@ -51,6 +51,7 @@ struct FwdParams {
   const float* enc_b;     // [C] or null
   int n_edges_hint;     // edges of the walk (layout choice only)
   float* ws;  // partial slots: [slot][4][C]
+  int32_t* ticket;      // wave-uniform encoder walk: work-item counter (zeroed by the entry point before the launch)
 };
 
 struct BwdParams {
@@ -85,7 +86,36 @@ struct BwdParams {
   const uint32_t* maxmask;
   int mask_words;
   float* ws;  // partial slots: [slot][C]
+  int32_t* ticket;      // wave-uniform encoder walk: work-item counter (zeroed by the entry point before the launch)
 };
+
+// Work items are claimed from a counter instead of being dealt out by wave index: the items of a power-law graph differ
+// by two orders of magnitude (1 .. 512 edges), a workgroup of four dealt waves lives as long as its longest item and the
+// chip was 35 % occupied (SQ counters, profiles/r04_enc_*): with tickets every wave slot stays busy until the list is
+// empty.  The next ticket is claimed while the current item is processed (its row bounds and first block are prefetched).
+// Eight counters, one per XCD (blockIdx % 8), each handing out its own interleaved eighth of the items (item = t * 8 +
+// xcd): same-address device atomics complete at ~10 ns each, and ONE counter serving the 27 k items of an ogbn-proteins
+// cluster serialised the whole launch at 0.27 ms; eight counters on separate cache lines run side by side (3.4 k atomics
+// each, spread over the launch), and an interleaved eighth of the items is as heavy as any other to a percent or two.
+constexpr int kQueues = kNumXCD;
+constexpr int kQueueStride = 32;          // ints between two counters (128 bytes)
+struct ItemQueue {
+  int32_t* cnt;
+  int q, nq;
+  __device__ __forceinline__ int claim() {
+    int t = 0;
+    if (lane_id() == 0) t = atomicAdd(cnt, 1);
+    return __builtin_amdgcn_readfirstlane(t) * nq + q;
+  }
+  __device__ __forceinline__ int first(int32_t* ticket) {
+    nq = min(kQueues, static_cast<int>(gridDim.x));      // (a tiny launch: every queue needs a workgroup)
+    q = blockIdx.x % nq;
+    cnt = ticket + q * kQueueStride;
+    return claim();
+  }
+  __device__ __forceinline__ int next(int32_t*) { return claim(); }
+};
+constexpr size_t kTicketBytes = kQueues * kQueueStride * sizeof(int32_t);
 
 struct Work {
   int row, beg, end, slot;

@@ -22,6 +22,8 @@
 #include "gen_aggr_common.h"
 #include "gen_aggr_state.h"
 
+extern "C" size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
+
 namespace dgcn {
 namespace {
 
@@ -349,8 +351,6 @@ __device__ __forceinline__ void enc_fwd_body(const FwdParams& P) {
   const bool act = c0ch < C;
   const uint32_t xs32 = static_cast<uint32_t>(P.x_stride);
   const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
-  const int total_waves = gridDim.x * kWavesPerWg;
-  const int wave0 = virtual_block() * kWavesPerWg + wv;
   const float t = P.t_dev ? *P.t_dev : P.t;
   const float p = P.p_dev ? *P.p_dev : P.p;
   const float eps = P.eps;
@@ -376,10 +376,13 @@ __device__ __forceinline__ void enc_fwd_body(const FwdParams& P) {
   };
 
   float* sf = sfeat[wv];
-  Work w = fetch_work<kWave>(P.g, wave0, n_items);
+  ItemQueue q;
+  int item = q.first(P.ticket);
+  Work w = fetch_work<kWave>(P.g, item, n_items);
   Stage sg = stage_load(w, w.beg);
-  for (int item = wave0; item < n_items; item += total_waves) {
-    const Work wn = fetch_work<kWave>(P.g, item + total_waves, n_items);
+  while (item < n_items) {
+    const int next = q.next(P.ticket);
+    const Work wn = fetch_work<kWave>(P.g, next, n_items);
     State<VEC> st;
     state_init<MODE, VEC>(st);
     for (int blk = w.beg; blk < w.end || blk == w.beg; blk += kEncBlk) {
@@ -444,6 +447,7 @@ __device__ __forceinline__ void enc_fwd_body(const FwdParams& P) {
     }
     if (act && w.row >= 0) enc_fwd_finish<MODE, VEC, WITH_D>(P, w, st, c0ch, eps_r, p, xs32);
     w = wn;
+    item = next;
   }
 }
 
@@ -494,16 +498,17 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
     State<1> st;
     state_init<MODE, 1>(st);
     constexpr int NQ = (MODE == DGCN_AGGR_MAX) ? 2 : 4;
-    for (int i = 0; i < npieces; i += 4) {
-      float v[4][4];
+    constexpr int PB = (MODE == DGCN_AGGR_MAX) ? 16 : 8;       // pieces in flight (32 loads)
+    for (int i = 0; i < npieces; i += PB) {
+      float v[PB][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < PB; ++k) {
         const float* ws = P.ws + (static_cast<int64_t>(slot0 + min(i + k, npieces - 1)) * 4) * C + c;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[k][q] = ws[static_cast<int64_t>(q) * C];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < PB; ++k) {
         if (i + k < npieces) {
           State<1> o;
           state_init<MODE, 1>(o);
@@ -582,7 +587,10 @@ inline bool enc_uniform_walk(const FwdParams& P, int vec) { return vec == 4 && P
 template <int MODE>
 void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t s) {
   if (enc_uniform_walk(P, vec)) {
-    if (P.C <= 128) launch_enc_fwd<MODE, 2>(P, grid, s); else launch_enc_fwd<MODE, 4>(P, grid, s);
+    // persistent grid: four waves per SIMD (the kernels' register budget), items claimed from the ticket counter
+    const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
+    const int pgrid = min((n_items + kWavesPerWg - 1) / kWavesPerWg, kNumCU * 4);
+    if (P.C <= 128) launch_enc_fwd<MODE, 2>(P, pgrid, s); else launch_enc_fwd<MODE, 4>(P, pgrid, s);
   } else if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
@@ -623,7 +631,14 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   if (!g->rowptr || (g->n_edges > 0 && !g->col)) return DGCN_E_NULL;
   if (g->n_work && (!g->work_row || !g->work_beg || !g->work_end || !g->work_slot)) return DGCN_E_NULL;
   if (g->n_work && g->n_split > 0 && !g->split_item) return DGCN_E_NULL;
-  if (workspace_bytes < dgcn_gen_aggr_fwd_workspace_bytes(g, channels)) return DGCN_E_WORKSPACE;
+  {
+    // split-row slots; the scheduling state behind them is needed by the encoder walk only (a caller of the plain
+    // entry point on a graph without split rows may pass no workspace at all)
+    const size_t full = dgcn_gen_aggr_fwd_workspace_bytes(g, channels);
+    const bool walk = enc && channels % 4 == 0 && channels >= 64 && channels <= 256;
+    const size_t slots = g->n_work ? static_cast<size_t>(g->n_slots) * 4u * static_cast<size_t>(channels) * sizeof(float) : 0;
+    if (workspace_bytes < (walk ? full : slots)) return DGCN_E_WORKSPACE;
+  }
   if (g->n_work && g->n_slots > 0 && !workspace) return DGCN_E_NULL;
 
   const bool vec4 = (channels % 4 == 0) && (x_stride % 4 == 0) && aligned16(x) && aligned16(out) &&
@@ -645,6 +660,14 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.enc_b = enc ? enc->b : nullptr;
   P.n_edges_hint = g->n_edges;
   if (enc && !vec4) return DGCN_E_ALIGN;
+  P.ticket = nullptr;
+  if (enc_uniform_walk(P, vec)) {
+    if (!workspace) return DGCN_E_NULL;
+    P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
+                                          dgcn_gen_aggr_fwd_workspace_bytes(g, channels) - kTicketBytes);
+    const hipError_t me = hipMemsetAsync(P.ticket, 0, kTicketBytes, static_cast<hipStream_t>(stream));
+    if (me != hipSuccess) return static_cast<int>(me);
+  }
 
   const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->n_work ? g->n_work : g->n_dst), g->n_edges) : 1;   // items walked side by side by one wave
   const int n_items = ((g->n_work ? g->n_work : g->n_dst) + per_wave - 1) / per_wave;
@@ -670,8 +693,10 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
 using namespace dgcn;
 
 extern "C" size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels) {
-  if (!g || g->n_work == 0) return 0;
-  return static_cast<size_t>(g->n_slots) * 4u * static_cast<size_t>(channels) * sizeof(float);
+  if (!g) return 0;
+  // partial-state slots of the split rows + the work-item counter of the encoder walk (last kTicketBytes)
+  const size_t slots = g->n_work ? static_cast<size_t>(g->n_slots) * 4u * static_cast<size_t>(channels) * sizeof(float) : 0;
+  return (slots + 255u) / 256u * 256u + kTicketBytes;
 }
 
 

@@ -25,7 +25,14 @@ import torch
 
 from . import _lib
 
-HUB_CHUNK = 256
+HUB_CHUNK = 256                  # rows longer than 2 * chunk are cut into chunk-edge work items (big graphs)
+HUB_CHUNK_SMALL = 64             # graphs of up to SMALL_GRAPH_EDGES edges: their few thousand rows have to fill the chip's
+SMALL_GRAPH_EDGES = 8 << 20      # 8192 wave slots AND balance them, which 64-edge items do (an ogbn-proteins cluster:
+                                 # 13 k rows, degrees 1 .. 3000) and 256-edge ones do not
+
+
+def default_hub_chunk(n_edges: int) -> int:
+    return HUB_CHUNK_SMALL if n_edges <= SMALL_GRAPH_EDGES else HUB_CHUNK
 
 
 def _work_list(rowptr: torch.Tensor, chunk: int):
@@ -55,8 +62,10 @@ class Graph:
     """CSR-by-destination + CSC-by-source of one edge list, plus the ctypes view of it."""
 
     def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_src: int, n_dst: int,
-                 need_transpose: bool = True, hub_chunk: int = HUB_CHUNK):
+                 need_transpose: bool = True, hub_chunk: int = None):
         dev = src.device  # structure building is index plumbing and also runs on CPU tensors (host-logic tests)
+        if hub_chunk is None:
+            hub_chunk = default_hub_chunk(src.numel())
         if src.dim() != 1 or src.shape != dst.shape:
             raise ValueError("src/dst must be 1-D tensors of equal length")
         E = src.numel()

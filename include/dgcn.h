@@ -126,7 +126,10 @@ int dgcn_selftest_axpy_f32(float a, const float* x, float* y, int64_t n, void* s
  *              POWER+LEARN_P: sum_e u_e^p ln u_e.  Otherwise unused.
  *   range_flag optional device int32, zeroed by the caller: SOFTMAX sets it to 1 when some |L_i| >= 80, i.e. when
  *              the single-gather backward with shift 0 would leave the fp32 range (decided on the device).
- *   workspace  >= dgcn_gen_aggr_fwd_workspace_bytes(g, C) bytes (0 unless rows are split).
+ *   workspace  >= dgcn_gen_aggr_fwd_workspace_bytes(g, C) bytes: the partial-state slots of split rows + 1 KiB of
+ *              scheduling state for the per-edge-encoder entry points (dgcn_gen_aggr_enc_*: a work-item counter the
+ *              entry point zeroes itself with a memset node on `stream`).  This plain entry point needs the slots only:
+ *              on a graph without split rows NULL / 0 is accepted.
  */
 size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t channels);
 
