@@ -394,6 +394,24 @@ def extras(dev, level="default"):
         v = _variant(dev, make, step_of, 3, 1)
         rev[name] = dict(ms_per_step=v["ms_per_step"], ms_per_layer=v["ms_per_step"] / layers,
                          edges_per_s=Ep * layers * 2 / (v["ms_per_step"] * 1e-3), peak_mem_gb=v["peak_mem_gb"])
+        if impl in ("product_composed", "product_modelfile_fused") or (full and impl == "product"):
+            # the same step captured as ONE hipGraph (deep_gcns_torch_amd.graphs.GraphedStep): ~850 launches per step make
+            # the eager step host-bound once the kernels are fast
+            from deep_gcns_torch_amd.graphs import GraphedStep
+
+            def make_g(layers=layers, impl=impl, aggr=aggr):
+                m, _ = make(layers, impl, aggr)
+                return m, torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+
+            def step_of_g(m, opt):
+                return GraphedStep(step_of(m, opt), warmup=2)
+            try:
+                vg = _variant(dev, make_g, step_of_g, 5, 1)
+                rev[name + "_hipgraph"] = dict(ms_per_step=vg["ms_per_step"], ms_per_layer=vg["ms_per_step"] / layers,
+                                               edges_per_s=Ep * layers * 2 / (vg["ms_per_step"] * 1e-3),
+                                               peak_mem_gb=vg["peak_mem_gb"])
+            except Exception as exc:   # noqa: BLE001 -- reported, the eager number stands
+                rev[name + "_hipgraph"] = {"error": repr(exc)[:200]}
     ops.FUSED_EDGE_GEMM = True
     gcn_revop.KEEP_AGGREGATION = keep_default
     rev["speedup_per_layer_vs_reference_algorithm_on_stock_gemm"] = (
@@ -401,6 +419,10 @@ def extras(dev, level="default"):
     rev["speedup_per_layer_composed_edge_encoders_vs_reference_algorithm"] = (
         rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"]
         / rev["revgcn8_product_composed_edge_encoders"]["ms_per_layer"])
+    gk = "revgcn8_product_composed_edge_encoders_hipgraph"
+    if "ms_per_layer" in rev.get(gk, {}):
+        rev["speedup_per_layer_composed_hipgraph_vs_reference_algorithm"] = (
+            rev["revgcn8_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev[gk]["ms_per_layer"])
     rev["speedup_per_layer_power_aggregation"] = (
         rev["revgcn8_power_reference_algorithm_stock_gemm"]["ms_per_layer"] / rev["revgcn8_power_product"]["ms_per_layer"])
     rev["workload"] = (f"RevGCN hidden=224 group=2 gcn_aggr=max (the README's commands; *_power_* rows: power) conv_encode_edge (ogb_eff/ogbn_proteins/model_rev.py) on a "
@@ -564,6 +586,12 @@ def main():
                     help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
     ap.add_argument("--node-groups", type=int, default=0, help="transposed scheme: node groups (0 = library default)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="CPU dress rehearsal of the N-rank job (no GPU, no timing claim): gloo instead of RCCL, CPU "
+                         "tensors, the oracle as the rank-local aggregation, the graph scaled down by --scale-div -- the "
+                         "SAME partition build, scheme autotuning, timed loop, phase breakdown and JSON line as the "
+                         "real run, so that an 8-rank launch is exercised before a multi-GPU node ever sees it")
+    ap.add_argument("--scale-div", type=int, default=16, help="--rehearsal: nodes and edges of the shape divided by this")
     ap.add_argument("--model", default="", choices=["", "deepergcn14"],
                     help="time a whole node-partitioned MODEL step instead of the aggregation op: deepergcn14 = BASELINE "
                          "config 4 (DeeperGCN-14, GENConv softmax_sg, BatchNorm, hidden 128) on the full products-shaped "
@@ -577,26 +605,41 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    rehearsal = args.rehearsal
+    if rehearsal:
+        if args.model:
+            raise SystemExit("--rehearsal covers the aggregation benchmark (the model job has its own gloo test)")
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(world, 1)))
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+
+    def dsync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     from deep_gcns_torch_amd import ops, synth
     from deep_gcns_torch_amd.graph import Graph
     from deep_gcns_torch_amd import _lib
-    _lib.load()
+    if not rehearsal:
+        _lib.load()
 
     dist = None
-    partitioned = world > 1 or args.force_partitioned
+    partitioned = world > 1 or args.force_partitioned or rehearsal
     if partitioned:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         import datetime
         # a rank that dies inside a collective must surface as an error within minutes, not as the default 10-minute hang
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                timeout=datetime.timedelta(seconds=240))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=240))
 
     if args.model:
         return model_bench(args, dev, rank, world, dist)
@@ -604,9 +647,21 @@ def main():
     s = synth.SHAPES[args.shape]
     C = args.channels or s["channels"]
     n = s["n"]
+    n_und = s["n_undirected"]
+    if rehearsal:
+        n, n_und = max(n // args.scale_div, 64), max(n_und // args.scale_div, 64)
     gen = {"uniform": synth.undirected_random_graph, "powerlaw": synth.powerlaw_graph, "local": synth.local_graph}[args.graph]
-    ei = gen(n, s["n_undirected"], seed=s["seed"], device=dev)
+    ei = gen(n, n_und, seed=s["seed"], device=dev)
     E = ei.size(1)
+    local_kernel = {}
+    if rehearsal:
+        from oracle import sparse_ref  # the rank-local kernel of the rehearsal only (never of a measured run)
+
+        def _oracle_local(x_full, graph, aggr="softmax", **kw):
+            deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+            dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+            return sparse_ref.gen_propagate(x_full, torch.stack([graph.col.long(), dst]), aggr=aggr, dim_size=graph.n_dst, **kw)
+        local_kernel = dict(local_aggregate=_oracle_local)
 
     gx = torch.Generator(device=dev).manual_seed(1234)
     x_full = torch.randn(n, C, device=dev, generator=gx)
@@ -640,6 +695,7 @@ def main():
         from deep_gcns_torch_amd import dist as ddist
         x = g_loc = None
         extra = dict(pipeline_chunks=args.pipeline_chunks) if args.pipeline_chunks else {}
+        extra.update(local_kernel)
 
         def make(scheme, node_groups):
             """(partition, x_local, g_local, fwd) for one exchange scheme; rows are re-sliced per scheme because the
@@ -650,13 +706,13 @@ def main():
             return part, xl, gl, (lambda: ddist.aggregate(xl, part, aggr=args.aggr, t=args.t, **extra))
 
         def timed(fwd_fn, xl, gl, reps):
-            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            dsync(); dist.barrier(); dsync()
             t0 = time.perf_counter()
             for _ in range(reps):
                 o = fwd_fn()
                 if not args.fwd_only:
                     torch.autograd.grad(o, xl, gl)
-            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            dsync(); dist.barrier(); dsync()
             tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()) / reps * 1e3
@@ -666,7 +722,7 @@ def main():
             # the exchange is bound by the xGMI links and RCCL's per-collective efficiency: try the applicable schemes
             # for a few untimed steps and keep the fastest (same choice on every rank: max-over-ranks timings)
             cands = [("allgather", 1), ("halo", 1)]
-            if world > 1 or args.force_partitioned:
+            if world > 1 or args.force_partitioned or rehearsal:
                 if ddist.transposed_supported(C, world, None, 1):
                     cands.append(("transposed", 1))
                 if wn_default > 1 and ddist.transposed_supported(C, world, None, wn_default):
@@ -698,7 +754,8 @@ def main():
                 if best is None or ms < best[0]:
                     best = (ms, sch, wn, cand)
                 cand = None
-            torch.cuda.empty_cache()
+            if dev.type == "cuda":
+                torch.cuda.empty_cache()
         if best is None:
             raise SystemExit(f"no exchange scheme ran: {tuned}")
         _, scheme, node_groups, (part, x, g_loc, fwd) = best
@@ -712,10 +769,10 @@ def main():
             return out
 
     def sync():
-        torch.cuda.synchronize(dev)
+        dsync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            dsync()
 
     for _ in range(args.warmup):
         step()
@@ -734,17 +791,28 @@ def main():
         elapsed = float(tt.item())
 
     # dominant kernel (forward aggregation) timed alone with events on the launch stream
-    stream = torch.cuda.current_stream(dev)
+    class _HostTimer:                 # --rehearsal: wall clock in place of HIP events (CPU tensors have no stream)
+        def __init__(self, enable_timing=True):
+            self.t = 0.0
+
+        def record(self, _stream=None):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+    Event = _HostTimer if rehearsal else torch.cuda.Event
+    stream = None if rehearsal else torch.cuda.current_stream(dev)
+    n_ev = 2 if rehearsal else max(5, min(args.steps, 20))
     evs = []
     # same launch as inside the timed steps (training-mode forward: it also writes the array the backward needs --
     # log-sum-exp / pre-clamp mean / arg-max ids -- counted below), so rocprofv3's per-kernel average agrees
-    for _ in range(max(5, min(args.steps, 20))):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(n_ev):
+        a, b = Event(enable_timing=True), Event(enable_timing=True)
         a.record(stream)
         fwd()
         b.record(stream)
         evs.append((a, b))
-    torch.cuda.synchronize(dev)
+    dsync()
     fwd_ms = sorted(a.elapsed_time(b) for a, b in evs)
     fwd_ms_avg = sum(fwd_ms) / len(fwd_ms)
     # the backward of the op alone (node-wise prologue + CSC edge walk), same way
@@ -752,21 +820,21 @@ def main():
     if not args.fwd_only:
         evs = []
         gl = g_full if not partitioned else g_loc
-        for _ in range(max(5, min(args.steps, 20))):
+        for _ in range(n_ev):
             o = fwd()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a, b = Event(enable_timing=True), Event(enable_timing=True)
             a.record(stream)
             torch.autograd.grad(o, x, gl)
             b.record(stream)
             evs.append((a, b))
-        torch.cuda.synchronize(dev)
+        dsync()
         bwd_ms_avg = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
 
     # multi-rank: where the step time goes (exchange vs local kernels), so a scaling run can be read
     phase_ms = None
     if partitioned and not args.fwd_only:
         try:
-            phase_ms = ddist.phase_times(x, g_loc, part, aggr=args.aggr, t=args.t, reps=5)
+            phase_ms = ddist.phase_times(x, g_loc, part, aggr=args.aggr, t=args.t, reps=1 if rehearsal else 5, **local_kernel)
         except Exception as exc:   # noqa: BLE001 -- reported, never hidden
             phase_ms = {"error": repr(exc)[:200]}
 
@@ -809,7 +877,10 @@ def main():
             "config": {
                 "workload": f"GENConv {args.aggr} aggregation (t={args.t}) fwd+bwd, ogbn-{args.shape}-shaped "
                             f"{args.graph} random graph N={n} E={E} C={C}"
-                            + (" [fwd only]" if args.fwd_only else ""),
+                            + (" [fwd only]" if args.fwd_only else "")
+                            + (f" [CPU REHEARSAL of the {world}-rank job: gloo, oracle as the local kernel, shape / "
+                               f"{args.scale_div}: exercises partition build, autotuning, the timed loop and this line -- "
+                               f"NOT a measurement]" if rehearsal else ""),
                 "parallelism": ("single GPU" if not partitioned else
                                 (f"node-partitioned rows x{world}, channel-transposed exchange (RCCL all-to-all in/out; "
                                  f"{part.node_groups} node group(s) x {part.channel_groups} channel group(s): each rank "
@@ -850,6 +921,11 @@ def main():
             res["config"]["autotuned_ms_per_step"] = tuned
         if phase_ms is not None:
             res["config"]["phase_ms"] = phase_ms
+        if rehearsal:
+            res["rehearsal"] = True
+            res["dtype"] = "f32 (CPU oracle)"
+            res["roofline"] = None          # host timings of the oracle: no statement about any kernel
+            res["bwd_hbm_frac"] = None
         if world > 1:
             res["config"]["note"] = "no multi-GPU curve had been measured when this was written (1-GPU gpurun boxes only)"
         if world == 1 and not partitioned and not args.no_cpu_baseline:

@@ -622,7 +622,7 @@ def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, ran
 
 
 def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = "softmax", reps: int = 5, group=None,
-                **kw) -> dict:
+                local_aggregate=None, **kw) -> dict:
     """Where one forward+backward of ``aggregate`` spends its time on this job (max over ranks, ms):
     ``step`` = exchange + kernels as they run together (pipelined / overlapped where the scheme does that);
     ``kernels`` = the rank-local aggregation kernels alone, on a feature tensor of the shape the exchange delivers;
@@ -653,8 +653,11 @@ def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = 
 
     xl = x_local.detach().clone().requires_grad_(True)
 
+    akw = dict(kw) if local_aggregate is None else dict(kw, local_aggregate=local_aggregate)
+    local = ops.gen_aggregate if local_aggregate is None else local_aggregate
+
     def step():
-        torch.autograd.grad(aggregate(xl, part, aggr=aggr, group=group, **kw), xl, g_local)
+        torch.autograd.grad(aggregate(xl, part, aggr=aggr, group=group, **akw), xl, g_local)
 
     C = x_local.size(1)
     c_loc = C // part.channel_groups if isinstance(part, TransposedGraph) else C
@@ -664,7 +667,7 @@ def phase_times(x_local: torch.Tensor, g_local: torch.Tensor, part, aggr: str = 
     kk = {k: v for k, v in kw.items() if k != "pipeline_chunks"}
 
     def kernels():
-        torch.autograd.grad(ops.gen_aggregate(xin, g, aggr=aggr, **kk), xin, gout)
+        torch.autograd.grad(local(xin, g, aggr=aggr, **kk), xin, gout)
 
     out = {"step": timed(step), "kernels": timed(kernels)}
     out["exchange_and_wait"] = out["step"] - out["kernels"]
