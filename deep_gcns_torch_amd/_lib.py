@@ -16,7 +16,7 @@ _LIB_PATH = Path(os.environ.get("DGCN_LIB_PATH") or (Path(__file__).resolve().pa
 # aggregation modes / flags (include/dgcn.h)
 AGGR_ADD, AGGR_MEAN, AGGR_MAX, AGGR_SOFTMAX, AGGR_POWER = 0, 1, 2, 3, 4
 MSG_IDENTITY, MSG_RELU_EPS = 0, 1
-FLAG_LEARN_T, FLAG_LEARN_P, FLAG_ADD_ROOT, FLAG_SHIFT_FLAG_IS_RANGE, FLAG_EA_IS_Z = 1, 2, 4, 8, 16
+FLAG_LEARN_T, FLAG_LEARN_P, FLAG_ADD_ROOT, FLAG_SHIFT_FLAG_IS_RANGE, FLAG_EA_IS_Z, FLAG_STATIC_ITEMS = 1, 2, 4, 8, 16, 32
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)

@@ -804,7 +804,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   }
   P.ws = static_cast<float*>(workspace);
   P.ticket = nullptr;
-  if (enc && vec4 && channels >= 64 && channels <= 256) {       // wave-uniform encoder walk: work-item counter
+  if (enc && vec4 && channels >= 64 && channels <= 256 && !(flags & DGCN_FLAG_STATIC_ITEMS)) {       // wave-uniform encoder walk: work-item counter
     if (!workspace) return DGCN_E_NULL;
     P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                           dgcn_gen_aggr_bwd_workspace_bytes(g, channels) - kTicketBytes);

@@ -101,13 +101,25 @@ constexpr int kQueues = kNumXCD;
 constexpr int kQueueStride = 32;          // ints between two counters (128 bytes)
 struct ItemQueue {
   int32_t* cnt;
-  int q, nq;
+  int q, nq, t_static;
   __device__ __forceinline__ int claim() {
+    if (cnt == nullptr) {                                // DGCN_FLAG_STATIC_ITEMS: wave w takes items w, w + W, ...
+      const int it = t_static;
+      t_static += nq;
+      return it;
+    }
     int t = 0;
     if (lane_id() == 0) t = atomicAdd(cnt, 1);
     return __builtin_amdgcn_readfirstlane(t) * nq + q;
   }
   __device__ __forceinline__ int first(int32_t* ticket) {
+    if (ticket == nullptr) {
+      cnt = nullptr;
+      nq = static_cast<int>(gridDim.x) * kWavesPerWg;
+      t_static = static_cast<int>(blockIdx.x) * kWavesPerWg + (threadIdx.x >> 6);
+      q = 0;
+      return claim();
+    }
     nq = min(kQueues, static_cast<int>(gridDim.x));      // (a tiny launch: every queue needs a workgroup)
     q = blockIdx.x % nq;
     cnt = ticket + q * kQueueStride;

@@ -661,7 +661,7 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   P.n_edges_hint = g->n_edges;
   if (enc && !vec4) return DGCN_E_ALIGN;
   P.ticket = nullptr;
-  if (enc_uniform_walk(P, vec)) {
+  if (enc_uniform_walk(P, vec) && !(flags & DGCN_FLAG_STATIC_ITEMS)) {
     if (!workspace) return DGCN_E_NULL;
     P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                           dgcn_gen_aggr_fwd_workspace_bytes(g, channels) - kTicketBytes);

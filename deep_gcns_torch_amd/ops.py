@@ -24,6 +24,9 @@ POW_LO, POW_HI = 1e-7, 1e1  # gcn_lib/sparse/torch_message.py:69
 ENC_FEATURES = 8                   # raw edge features of the per-edge encoder (kEncF in csrc/gen_aggr_common.h)
 SINGLE_GATHER_SOFTMAX_BWD = True   # halves the backward's gather traffic when the log-sum-exp range allows
 SHIFT_SAFE_ABS_L = 80.0            # the forward kernel flags |L_i| >= 80 (kShiftSafe in csrc/gen_aggr_common.h)
+ENC_STATIC_ITEMS = False           # per-edge encoder kernels: True = work items dealt by wave index (DGCN_FLAG_STATIC_ITEMS):
+                                   # bit-reproducible dW | db at 1.3 - 1.6x the launch time; default = items claimed from
+                                   # device-side counters (outputs and grad_x identical, dW | db equal to rounding)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
 MAX_MASK_MIN_TABLE_BYTES = 128 << 20   # max backward through per-edge arg-max bit masks (two launches) when the (n_dst, C)
@@ -283,7 +286,7 @@ class _GenAggregate(torch.autograd.Function):
             elif enc:
                 rc = lib.dgcn_gen_aggr_enc_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
-                    ENC_FEATURES, C, mode, msg, flags, t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                    ENC_FEATURES, C, mode, msg, flags | (_lib.FLAG_STATIC_ITEMS if ENC_STATIC_ITEMS else 0), t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
                     out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
             else:
@@ -377,7 +380,8 @@ class _GenAggregate(torch.autograd.Function):
                     gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
                     rc = lib.dgcn_gen_aggr_enc_bwd_f32(
                         graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
-                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags, ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
+                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags | (_lib.FLAG_STATIC_ITEMS if ENC_STATIC_ITEMS else 0),
+                        ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
                         _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))

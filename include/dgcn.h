@@ -51,6 +51,12 @@ extern "C" {
 #define DGCN_FLAG_LEARN_P 2 /* power exponent is differentiated  (torch_message.py:33-34) */
 #define DGCN_FLAG_SHIFT_FLAG_IS_RANGE 8 /* backward: shift_ok points at the forward's range_flag (0 = safe), not at an "ok" flag */
 #define DGCN_FLAG_ADD_ROOT 4 /* forward: out_i += x_i, the h = x + m of GENConv.forward (torch_vertex.py:74) fused in */
+#define DGCN_FLAG_STATIC_ITEMS 32 /* per-edge-encoder entry points: deal the work items to the waves by index instead of
+                                  * handing them out from the device-side counters.  The outputs and grad_x are the same
+                                  * bits either way (an item's result does not depend on who computes it); the dW | db
+                                  * partial sums are grouped per workgroup, so with the dynamic schedule (default) their
+                                  * LAST BITS vary from run to run -- set this flag for bit-reproducible weight
+                                  * gradients at 1.3 - 1.6x the launch time on power-law graphs. */
 #define DGCN_FLAG_EA_IS_Z 16 /* backward: the rows of edge_attr are the pre-activations z_e themselves (saved by
                                 dgcn_gen_aggr_egemm_fwd_f32), x is not gathered (may be NULL).  With DGCN_AGGR_MAX the
                                 rows are not read either (edge_attr may be NULL, no z_save needed): that forward marks

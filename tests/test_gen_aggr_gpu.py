@@ -557,3 +557,39 @@ def test_max_backward_bit_mask_path_equals_the_row_walk(C, sorted_input, monkeyp
     run("mask")
     for k in (False, True, "raw"):
         assert torch.equal(grads[("mask", k)], grads[("rows", k)]), k
+
+
+def test_encoder_walk_item_schedules():
+    """The per-edge encoder kernels hand their work items out from device-side counters (default) or deal them by wave
+    index (ops.ENC_STATIC_ITEMS / DGCN_FLAG_STATIC_ITEMS).  Outputs and grad_x: the same bits under both schedules and
+    from run to run (an item's result does not depend on who computes it).  dW | db: bit-reproducible under the static
+    schedule; under the dynamic one equal to rounding (per-workgroup partial sums are grouped by the schedule)."""
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    n, C = 6000, 112
+    ei = synth.powerlaw_graph(n, 120_000, seed=21, exponent=2.2).to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=g).to(dev)
+    feat = torch.rand(ei.size(1), 8, generator=g).to(dev)
+    W = (torch.randn(C, 8, generator=g) / 3).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    probe = torch.randn(n, C, generator=g).to(dev)
+
+    def run(static):
+        saved = ops.ENC_STATIC_ITEMS
+        ops.ENC_STATIC_ITEMS = static
+        try:
+            xa, Wa, ba = (t.clone().requires_grad_(True) for t in (x, W, b))
+            out = ops.gen_aggregate(xa, ei, feat, aggr="softmax", t=1.0, edge_encoder=(Wa, ba))
+            (out * probe).sum().backward()
+            return out.detach(), xa.grad, Wa.grad, ba.grad
+        finally:
+            ops.ENC_STATIC_ITEMS = saved
+    s1, s2, d1, d2 = run(True), run(True), run(False), run(False)
+    for a, b_ in zip(s1, s2):
+        assert torch.equal(a, b_)                                  # static: every result bit for bit
+    for k in (0, 1):
+        assert torch.equal(d1[k], d2[k]) and torch.equal(d1[k], s1[k])      # out, grad_x: schedule-independent bits
+    for k in (2, 3):
+        torch.testing.assert_close(d1[k], s1[k], rtol=1e-5, atol=1e-5 * float(s1[k].abs().max()))
+        torch.testing.assert_close(d1[k], d2[k], rtol=1e-5, atol=1e-5 * float(s1[k].abs().max()))
