@@ -223,3 +223,47 @@ def test_shared_leaf_argument_survives_eval_passes_and_aborted_backwards():
         torch.testing.assert_close(emb.grad, want + 0.5, rtol=1e-4, atol=1e-5)
     finally:
         torch_message.GenMessagePassing.propagate = saved
+
+
+@pytest.mark.gpu
+def test_kept_aggregation_memory_is_bounded_by_the_budget():
+    """keeping the aggregation results of every coupling function for the backward costs memory that grows
+    with DEPTH -- what the reversible scheme exists to avoid.  KEEP_AGGREGATION = "auto" (the default) keeps them while
+    the live reversible layers of the device hold less than the budget and launches the edge kernels again beyond it;
+    the ledger empties when the backward has run (or the graph is dropped)."""
+    _install()
+    import rev_restated
+    from deep_gcns_torch_amd import synth
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
+    dev = torch.device("cuda:0")
+    n = 3000
+    ei = synth.powerlaw_graph(n, 20_000, seed=9).to(dev)
+    g = torch.Generator().manual_seed(2)
+    table = torch.rand(n, 8, generator=g).to(dev)
+    x = torch.rand(n, 8, generator=g).to(dev)
+    ea = torch.rand(ei.size(1), 8, generator=g).to(dev)
+    nidx = torch.arange(n, device=dev)
+
+    def kept_after_forward(layers, mode, budget):
+        saved = (gcn_revop.KEEP_AGGREGATION, gcn_revop.KEEP_AGGREGATION_BUDGET_BYTES)
+        gcn_revop.KEEP_AGGREGATION, gcn_revop.KEEP_AGGREGATION_BUDGET_BYTES = mode, budget
+        try:
+            torch.manual_seed(1)
+            m = rev_restated.RevGCN(num_layers=layers, hidden=64, num_tasks=8, aggr="max", dropout=0.0, node_table=table,
+                                    impl="product").to(dev).train()
+            assert gcn_revop.kept_aggregation_bytes(dev) == 0
+            pred, _ = m(x, nidx, ei, ea)
+            held = gcn_revop.kept_aggregation_bytes(dev)
+            pred.sum().backward()
+            assert gcn_revop.kept_aggregation_bytes(dev) == 0          # released layer by layer in the backward
+            return held
+        finally:
+            gcn_revop.KEEP_AGGREGATION, gcn_revop.KEEP_AGGREGATION_BUDGET_BYTES = saved
+    per_layer = kept_after_forward(1, True, None)
+    assert per_layer > 0
+    assert kept_after_forward(12, True, None) == 12 * per_layer                   # True: linear in depth
+    assert kept_after_forward(12, False, None) == 0                              # False: the reference's footprint
+    budget = 3 * per_layer
+    held = kept_after_forward(12, "auto", budget)
+    assert budget <= held < budget + per_layer                                   # auto: stops at the budget
+    assert kept_after_forward(12, "auto", None) == 12 * per_layer                # default budget (1/8 of HBM): all kept
