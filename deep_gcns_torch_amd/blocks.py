@@ -141,7 +141,14 @@ class ComposedEdgeEmbedding:
             raise ValueError("edge_attr must be (E, encoder.in_features)")
         self.encoder = encoder
         # (the same tensor object for every group view / layer: per-tensor caches of the kernels' host side hit)
-        self.raw = edge_attr.detach() if edge_attr.requires_grad else edge_attr
+        # Raw features that require a gradient (learned / upstream-computed edge features): the per-edge kernels have no
+        # gradient w.r.t. them and the reversible wrapper routes gradients of tensor arguments only -- refuse instead of
+        # dropping that gradient silently (ops._GenAggregate raises for the same case)
+        if edge_attr.requires_grad:
+            raise ValueError("ComposedEdgeEmbedding: edge_attr requires grad; the composed per-edge encoder has no gradient "
+                             "w.r.t. the raw edge features -- pass edge_attr.detach() if that gradient is not needed, or "
+                             "keep the model's own edge_emb = edge_encoder(edge_attr)")
+        self.raw = edge_attr
         self.repeat = int(repeat)
         self._full = None
 

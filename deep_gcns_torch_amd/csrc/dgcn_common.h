@@ -12,7 +12,10 @@ namespace dgcn {
 constexpr int kWave = 64;
 constexpr int kWgThreads = 256;           // 4 waves, one per SIMD
 constexpr int kWavesPerWg = kWgThreads / kWave;
-constexpr int kNumCU = 256;               // MI355X
+constexpr int kNumCU = 256;               // MI355X (SPX mode).  Used for GRID CAPS and partial-buffer sizing only: every kernel
+                                          // strides over its work, so on a partitioned (CPX: 32 CUs) device the grids are merely
+                                          // larger than needed -- results are unaffected.  A compile-time constant on purpose: the
+                                          // *_num_partials sizing calls and the launches must agree whatever device is current.
 constexpr int kNumXCD = 8;
 
 #define DGCN_NEG_INF (-__builtin_inff())

@@ -64,6 +64,9 @@ class TallLinear(nn.Linear):
         from . import node_ops
         if ROWS_KERNEL and node_ops.rows_linear_supported(x, self.weight):
             return node_ops.rows_linear(x, self.weight, self.bias, residual, want_stats)
+        if ROWS_KERNEL and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            node_ops.warn_library_gemm("a node Linear", x.size(0), self.in_features, self.out_features,
+                                       "it takes 16 <= in-features <= 256 and out-features <= 256, multiples of 4")
         if x.is_cuda and x.dim() == 2 and x.size(0) >= _MIN_ROWS and torch.is_grad_enabled() \
                 and x.dtype == self.weight.dtype and not torch.is_autocast_enabled():
             y = _TallLinearFn.apply(x, self.weight, self.bias)

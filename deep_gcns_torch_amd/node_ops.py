@@ -402,6 +402,21 @@ def pre_activation(norm: nn.Module, x: torch.Tensor, p: float = 0.0, training: b
 # ---- Linear over node rows ------------------------------------------------------------------------------------------
 ROWS_LINEAR_MIN_ROWS = 2048     # below this the library GEMM is as good (launch-bound either way)
 
+_WARNED = set()
+
+
+def warn_library_gemm(kind: str, rows: int, a: int, b: int, why: str) -> None:
+    """Say ONCE per shape that a node-row product left the row kernels for the library GEMM (same results, slower):
+    a user must not lose the kernel without notice.  Small inputs (< ROWS_LINEAR_MIN_ROWS rows) are silent:
+    there the library call is the intended path."""
+    key = (kind, a, b)
+    if key in _WARNED or rows < ROWS_LINEAR_MIN_ROWS:
+        return
+    _WARNED.add(key)
+    import warnings
+    warnings.warn(f"deep_gcns_torch_amd: {kind} of {rows} rows x ({a}, {b}) runs on the library GEMM, not on the row "
+                  f"kernel ({why}); results are the same", RuntimeWarning, stacklevel=3)
+
 
 def rows_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
@@ -516,6 +531,9 @@ def rows_tn(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
             and x.stride(1) == 1 and max(g.stride(0), x.stride(0)) < (1 << 22)
             and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
             and _lib.load().dgcn_rows_tn_supported(C, K)):
+        if ROWS_TN_KERNEL and g.is_cuda and g.dim() == 2 and g.dtype == torch.float32:
+            warn_library_gemm("the weight gradient g^T x", g.size(0), C, K,
+                              "it takes min(C, K) <= 128, max(C, K) <= 256, both multiples of 4, 16-byte aligned fp32 rows")
         return splitk_xt_g(g.contiguous(), x.contiguous())
     lib = _lib.load()
     dev = g.device
