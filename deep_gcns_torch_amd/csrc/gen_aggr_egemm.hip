@@ -748,12 +748,15 @@ template <int NT, int KC, int MODE, int WPS>
 __device__ __forceinline__ void egemm_bf16_body(const EgParams& P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DBW = WPS == 3 ? 1 : kEgAheadB;
+  // the next batch's x rows wait in the idle fragment buffer during the fold -- except where the fold itself needs
+  // those registers (wide tiles with the four-float softmax / power state)
+  constexpr bool PARK = WPS == 2 && !(NT >= 5 && MODE == DGCN_AGGR_SOFTMAX);
   constexpr int DB = DBW < KC ? DBW : KC;
   constexpr int SU = 4 * KC + 2;            // row stride of a weight plane in 16-byte units: % 4 == 2, conflict-free
   constexpr int PLANE = NT * 16 * SU;       // units per plane
   const int C = P.C, K = P.K;
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
+  const int wave = uni(static_cast<int>(threadIdx.x >> 6));   // scalar: the batch coordinates below stay in SGPRs
   const int nwaves = blockDim.x >> 6;
   i4v* Wp = reinterpret_cast<i4v*>(smem);   // [3][NT*16][SU] units of 8 bf16
   {
@@ -850,7 +853,7 @@ __device__ __forceinline__ void egemm_bf16_body(const EgParams& P) {
                                               // batch's x rows between two chains); WPS == 3: one, used as two halves
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bx[0][ct] = wb[ct * 16 * SU];       // plane 1 of block 0
-  if constexpr (WPS == 2) gather_x(bx[1], mc.src);
+  if constexpr (PARK) gather_x(bx[1], mc.src);
 
   EgWalk wk;
   State<NT> st;
@@ -859,9 +862,10 @@ __device__ __forceinline__ void egemm_bf16_body(const EgParams& P) {
 
   while (true) {
     const EgCoord nn = next_coord(nxt, vnn);
-    const EgMeta mnn = eg_load_meta(P, nn, lane);
+    EgMeta mnn;
+    if constexpr (WPS != 3) mnn = eg_load_meta(P, nn, lane);
     const float* arow_n = P.feat + static_cast<int64_t>(mn.eid) * P.feat_stride;
-    if constexpr (WPS == 2) {
+    if constexpr (PARK) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
@@ -983,7 +987,8 @@ __device__ __forceinline__ void egemm_bf16_body(const EgParams& P) {
       }
     }
 
-    if constexpr (WPS == 2) gather_x(bx[1], mn.src);   // next batch's x rows; bx[1] is idle until the next chain
+    if constexpr (PARK) gather_x(bx[1], mn.src);       // next batch's x rows; bx[1] is idle until the next chain
+    if constexpr (WPS == 3) mnn = eg_load_meta(P, nn, lane);   // (register-lean: requested here, the fold covers it)
 
     // ---- fold the tile (it stays in the accumulators) ----
     const int nb = (P.dbg & 1) ? 0 : min(kEgM, cur.ie - cur.b);
