@@ -361,6 +361,7 @@ def extras(dev, level="default"):
             ("revgcn8_reference_algorithm_stock_gemm", 8, "restated", False, "max"),
             # BASELINE.json words config 5 with power-mean aggregation (the reference's commands use max): both
             ("revgcn8_power_product", 8, "product", True, "power"),
+            ("revgcn8_power_model_file_install_fuse_models", 8, "product_modelfile_fused", True, "power"),
             ("revgcn8_power_reference_algorithm_stock_gemm", 8, "restated", False, "power")]
     if full:
         rows += [("revgcn112_product", 112, "product", True, "max"),

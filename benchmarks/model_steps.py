@@ -2,7 +2,7 @@
 """Training steps of one BASELINE model only, for rocprofv3 (run twice with different step counts and difference the
 kernel statistics: profiles/diff_stats.py):
 
-    python benchmarks/model_steps.py {deepergcn28|deepergcn14|resgcn28|revgcn8|revgcn8_graph|revgcn112} STEPS
+    python benchmarks/model_steps.py {deepergcn28|deepergcn14|resgcn28|revgcn8|revgcn112}[_graph] STEPS
 
 deepergcn28 / deepergcn14: the restated model file's class fused from outside (fuse.fuse_model, full recompute) on the
 arxiv shape / one products cluster; resgcn28: sem_seg_dense at B = 8 x 4096; revgcn8 / revgcn112: the model file's forward
@@ -29,7 +29,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 graphed = which.endswith("_graph")
 if which.startswith("deepergcn"):
-    if which == "deepergcn28":
+    if which.startswith("deepergcn28"):
         sh = synth.SHAPES["arxiv"]
         n, L, cin, ncls = sh["n"], 28, 128, 40
         ei = synth.undirected_random_graph(n, sh["n_undirected"], sh["seed"], device=dev)
@@ -45,11 +45,11 @@ if which.startswith("deepergcn"):
         opt.zero_grad(set_to_none=True)
         torch.nn.functional.nll_loss(m(x, ei), y).backward()
         opt.step()
-elif which == "resgcn28":
+elif which.startswith("resgcn28"):
     m = arch_restated.DenseDeepGCN(n_blocks=28, channels=64, k=16, in_channels=9, n_classes=13).to(dev).train()
     x = torch.cat([torch.rand(8, 3, 4096, 1), torch.rand(8, 6, 4096, 1)], 1).to(dev)
     y = torch.randint(0, 13, (8, 4096), device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -72,11 +72,14 @@ else:
         opt.zero_grad(set_to_none=True)
         torch.nn.functional.binary_cross_entropy_with_logits(m(xin, nidx, ei, ea), y).backward()
         opt.step()
-if graphed:
-    g = GraphedStep(step, warmup=2)
-    for _ in range(steps):
-        g()
-else:
-    for _ in range(steps):
-        step()
+import time  # noqa: E402
+
+run = GraphedStep(step, warmup=2) if graphed else step
+if not graphed:
+    step()
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    run()
+torch.cuda.synchronize()
+print(f"{which}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step over {steps} steps (wall)")

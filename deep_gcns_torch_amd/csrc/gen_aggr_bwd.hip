@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
 }
 template <int MODE, int VEC, int LPR, int SW>
 void launch_bwd_ea(const BwdParams& P, int grid, hipStream_t s) {
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 4 && LPR <= 16 && SW == kWave) {   // per-edge encoder at C < 64 (wider rows: gen_aggr_enc_bwd_kernel)
     if (P.enc_feat) {
       hipLaunchKernelGGL((gen_aggr_bwd_kernel<MODE, VEC, LPR, SW, 2>), dim3(grid), dim3(kWgThreads), 0, s, P);
       return;
@@ -631,7 +631,8 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the
     // chip that way, else one row per wave (more, shorter waves)
     const int sw_sel = subgroup_width(lpr, P.g.n_work ? P.g.n_work : P.g.n_rows, P.n_edges_hint);
-    const bool one = sw_sel == kWave;
+    // (per-edge encoder at C < 64: the side-by-side layouts need > 256 registers there, one row per wave only)
+    const bool one = sw_sel == kWave || P.enc_feat != nullptr;
     switch (lpr) {
       case 4: one ? launch_bwd_ea<MODE, 4, 4, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 4, kSubWidth(4)>(P, grid, s); break;
       case 8: one ? launch_bwd_ea<MODE, 4, 8, 64>(P, grid, s) : launch_bwd_ea<MODE, 4, 8, kSubWidth(8)>(P, grid, s); break;
@@ -652,7 +653,8 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
 
 int bwd_grid(const dgcn_graph* g, int channels, bool vec4, bool enc) {
   const int lpr = vec4 ? lanes_per_row(channels, 4) : 64;
-  const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src), g->n_edges) : 1;
+  int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->t_n_work ? g->t_n_work : g->n_src), g->n_edges) : 1;
+  if (enc && channels < 64) per_wave = 1;          // launch_bwd_mode: one row per wave for the narrow encoder shapes
   const int n_items = ((g->t_n_work ? g->t_n_work : g->n_src) + per_wave - 1) / per_wave;
   int grid = round_up8(grid_for_waves(n_items));
   if (enc && grid > kEncMaxParts) grid = kEncMaxParts;

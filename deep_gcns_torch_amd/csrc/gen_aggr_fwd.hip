@@ -568,7 +568,7 @@ void launch_fwd_d(const FwdParams& P, int grid, hipStream_t s) {
 
 template <int MODE, int VEC, int LPR, int SW>
 void launch_fwd_ea(const FwdParams& P, int grid, hipStream_t s) {
-  if constexpr (VEC == 4) {
+  if constexpr (VEC == 4 && LPR <= 16) {   // C < 64 (wider rows take gen_aggr_enc_fwd_kernel, enc_uniform_walk)
     if (P.enc_feat) {   // fused edge encoder: float4 layouts only (the host entry point checks)
       launch_fwd_d<MODE, VEC, LPR, SW, 2>(P, grid, s);
       return;

@@ -1283,14 +1283,15 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       const uint32_t incl = static_cast<uint32_t>(wave_scan_incl(static_cast<int>(tot)));
       const uint32_t rank = static_cast<uint32_t>(P.sample_rank);
       const bool mine = incl - tot < rank && rank <= incl;          // exactly one lane (rank <= the valid samples)
-      uint32_t run = incl - tot, bq = 8u * lane + 7u;
+      uint32_t run = incl - tot, qsel = 7u;
 #pragma unroll
       for (int q = 7; q >= 0; --q) {                                // first bucket whose inclusive prefix reaches the rank
         uint32_t upto = run;
 #pragma unroll
         for (int u = 0; u <= q; ++u) upto += hc[u];
-        if (rank <= upto) bq = 8u * lane + q;
+        if (rank <= upto) qsel = static_cast<uint32_t>(q);
       }
+      uint32_t bq = 8u * lane + qsel;     // (formed once: eight per-lane 8 lane + q constants would stay live, and spill)
       const unsigned long long mm = __ballot(mine);
       const int src = mm ? static_cast<int>(__builtin_ctzll(mm)) : 63;
       bq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bq), src));
