@@ -6,8 +6,9 @@ kernel statistics: profiles/diff_stats.py):
 
 deepergcn28 / deepergcn14: the restated model file's class fused from outside (fuse.fuse_model, full recompute) on the
 arxiv shape / one products cluster; resgcn28: sem_seg_dense at B = 8 x 4096; revgcn8 / revgcn112: the model file's forward
-fused from outside (composed per-edge encoders), max aggregation, ogbn-proteins cluster shape; revgcn8_graph: the same
-step replayed as one hipGraph."""
+fused from outside (composed per-edge encoders), max aggregation, ogbn-proteins cluster shape; revgcn8_product /
+revgcn8_power_product: the same model file WITHOUT fuse (install() alone: fused edge-GEMM kernels, max / power);
+*_graph: the same step replayed as one hipGraph."""
 import os
 import sys
 
@@ -64,8 +65,11 @@ else:
     xin, nidx = torch.rand(N, 8, device=dev), torch.arange(N, device=dev)
     ea = torch.rand(E, 8, device=dev)
     y = (torch.rand(N, 112, device=dev) > 0.5).float()
-    m = fuse.fuse_model(rev_restated.RevGCNModelFile(num_layers=layers, hidden=224, aggr="max", dropout=0.2, node_table=table,
-                                                     impl="product").to(dev).train())
+    aggr = "power" if "power" in which else "max"
+    m = rev_restated.RevGCNModelFile(num_layers=layers, hidden=224, aggr=aggr, dropout=0.2, node_table=table,
+                                     impl="product").to(dev).train()
+    if "product" not in which:        # *_product: install() alone, the fused edge-GEMM path of eff_gcn_modules.rev
+        m = fuse.fuse_model(m)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed)
 
     def step():

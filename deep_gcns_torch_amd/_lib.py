@@ -74,6 +74,10 @@ _SIGNATURES = {
         C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_egemm_max_bwd_num_partials": (C.c_int32, [C.c_int32]),
+    "dgcn_egemm_max_bwd_f32": (C.c_int, [
+        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dgcn_power_bwd_prep_f32": (C.c_int, [C.POINTER(DgcnGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                           C.c_int32, C.c_void_p]),
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -28,6 +28,8 @@ ENC_STATIC_ITEMS = False           # per-edge encoder kernels: True = work items
                                    # bit-reproducible dW | db at 1.3 - 1.6x the launch time; default = items claimed from
                                    # device-side counters (outputs and grad_x identical, dW | db equal to rounding)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
+EGEMM_MAX_WINNER_BWD = True        # its backward under max: walk the (row, channel) winners (csrc/egemm_max_bwd.hip) instead of
+                                   # writing dz (E, C) and running dz @ W, dz^T F over it; False = that dense route (A/B)
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
 MAX_MASK_MIN_TABLE_BYTES = 128 << 20   # max backward through per-edge arg-max bit masks (two launches) when the (n_dst, C)
                                    # arg-max table is at least this big, i.e. falls out of the 256 MiB Infinity Cache
@@ -349,8 +351,14 @@ class _GenAggregate(torch.autograd.Function):
         grad_x = grad_ea = grad_w = grad_b = grad_feat = None
         egemm = ctx.egemm
         need_dz = egemm and any(ctx.needs_input_grad[14:17])
+        # max over the fused edge GEMM: dz has one non-zero per (row, channel); the winners kernel needs no (E, C) array
+        winners = (egemm and mode == _lib.AGGR_MAX and EGEMM_MAX_WINNER_BWD and need_dz and C <= 128
+                   and ctx.enc[0].size(1) <= 256)
+        if winners:
+            need_dz = False
         enc = None if egemm else ctx.enc                  # narrow per-edge encoder: dW | db partials, no (E, C) array
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
+                (winners and ctx.enc[2] is not None and ctx.needs_input_grad[16]) or \
                 (enc is not None and any(ctx.needs_input_grad[15:17])):
             gcoef = gcoef.contiguous()
             grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
@@ -409,7 +417,11 @@ class _GenAggregate(torch.autograd.Function):
                     grad_w = gsum[:, :ENC_FEATURES].contiguous()
                 if b_enc is not None and ctx.needs_input_grad[16]:
                     grad_b = gsum[:, ENC_FEATURES].contiguous()
-            if egemm:
+            if winners:
+                feat, w_enc, b_enc = ctx.enc
+                if b_enc is not None and ctx.needs_input_grad[16]:
+                    grad_b = grad_x.sum(0) - g.sum(0) if ctx.add_root else grad_x.sum(0)
+            elif egemm:
                 # dz = dL/dz_e (E, C), original edge order = the gradient of the never-materialised edge embedding
                 feat, w_enc, b_enc = ctx.enc
                 dz, grad_ea = grad_ea, None
@@ -430,6 +442,25 @@ class _GenAggregate(torch.autograd.Function):
                         grad_b = grad_x.sum(0) - g.sum(0) if ctx.add_root else grad_x.sum(0)
             if not ctx.needs_input_grad[0]:
                 grad_x = None
+        if winners and (ctx.needs_input_grad[14] or ctx.needs_input_grad[15]):
+            feat, w_enc, b_enc = ctx.enc
+            n_feat = feat.size(1)
+            gf = None
+            if ctx.needs_input_grad[14]:
+                gf = ctx.grad_sink                         # running sum owned by the caller (edge_grad_sink), or a fresh one
+                if gf is None:
+                    gf = grad_feat = torch.zeros(graph.n_edges, n_feat, device=dev, dtype=torch.float32)
+            wpart = None
+            if ctx.needs_input_grad[15]:
+                wpart = torch.empty(lib.dgcn_egemm_max_bwd_num_partials(graph.n_dst), C, n_feat, device=dev,
+                                    dtype=torch.float32)
+            with _lib.device_ctx(dev):
+                _lib.check(lib.dgcn_egemm_max_bwd_f32(
+                    gcoef.contiguous().data_ptr(), aux1.data_ptr(), graph.n_dst, graph.n_edges, feat.data_ptr(),
+                    feat.stride(0), w_enc.data_ptr(), n_feat, C, _lib.ptr(gf), gf.stride(0) if gf is not None else 0,
+                    _lib.ptr(wpart), _lib.current_stream_handle(dev)), "dgcn_egemm_max_bwd_f32")
+            if wpart is not None:
+                grad_w = wpart.sum(0)
         return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10 + (grad_feat, grad_w, grad_b)
 
 

@@ -258,6 +258,31 @@ int dgcn_gen_aggr_egemm_fwd_f32(const dgcn_graph* g, const int32_t* erow, const 
                                 float* out, void* aux1, float* aux2, int32_t* range_flag, float* z_save,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Backward of the fused edge encoder under DGCN_AGGR_MAX without the (E, channels) gradient dz (what autograd builds
+ * for edge_emb = edge_encoder(edge_feat) in GENConv.forward, gcn_lib/sparse/torch_vertex.py:62-66, aggregated by
+ * scatter(reduce='max'), gcn_lib/sparse/torch_message.py:46-47; called per layer from the reversible backward,
+ * eff_gcn_modules/rev/gcn_revop.py:121-133).  dz has one non-zero per (destination row, channel) -- g[r][c] at the
+ * arg-max edge -- so the kernel walks the winners instead of the edges:
+ *   grad_feat[e][:]       += sum over the channels c that edge e wins:  gcoef[r][c] * enc_weight[c][:]
+ *   d enc_weight[c][:]     = sum over rows r:                           gcoef[r][c] * edge_feat[argmax[r][c]][:]
+ *   gcoef   [n_dst, channels] gradient of the aggregated rows (for MAX: grad_out itself)
+ *   argmax  [n_dst, channels] int32 = aux1 of dgcn_gen_aggr_egemm_fwd_f32(DGCN_AGGR_MAX): ORIGINAL edge id of the
+ *           winner, -1 where no neighbour passed the relu (those channels pass no gradient)
+ *   edge_feat / feat_stride, enc_weight: as in the forward (edge_feat may be NULL when grad_w_partials is NULL)
+ *   grad_feat [n_edges, n_feat] row stride grad_feat_stride, ACCUMULATED in place (rows of edges that win nothing are
+ *           not touched: pass a zeroed or running buffer), or NULL
+ *   grad_w_partials [dgcn_egemm_max_bwd_num_partials(n_dst)][channels][n_feat], every block fully written, their sum
+ *           over the first axis is d enc_weight; or NULL.  No atomics anywhere: both results are bit-reproducible.
+ * grad_x and d enc_bias come from dgcn_gen_aggr_bwd_f32(edge_attr = NULL, grad_edge_attr = NULL, DGCN_FLAG_EA_IS_Z) as
+ * before.  channels <= 128, n_feat % 4 == 0, n_feat <= 256, 16-byte aligned rows.
+ */
+int32_t dgcn_egemm_max_bwd_num_partials(int32_t n_dst);
+int dgcn_egemm_max_bwd_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst, int32_t n_edges,
+                           const float* edge_feat, int64_t feat_stride, const float* enc_weight, int32_t n_feat,
+                           int32_t channels, float* grad_feat, int64_t grad_feat_stride, float* grad_w_partials,
+                           void* stream);
+
 /* Per-destination coefficient of the POWER / MEAN backward in one pass (the `gcoef` of dgcn_gen_aggr_bwd_f32):
  *   out[i,c] = grad_out[i,c] * r^(1/p - 1) * [1e-7 <= q <= 10] / max(deg_i, 1),  r = clamp(q, 1e-7, 10)
  * q = aux1 of the POWER forward (torch_message.py:68-74); q == NULL gives the MEAN form grad_out / max(deg_i, 1).

@@ -191,6 +191,57 @@ def test_bit_reproducible_and_matches_unfused_path():
         torch.testing.assert_close(a, u, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("C,K", [(112, 224), (32, 64), (128, 256), (20, 48)])
+def test_max_winner_backward_equals_the_dense_route(C, K):
+    """csrc/egemm_max_bwd.hip (walk the (row, channel) winners; no (E, C) gradient) against the dense route (dz written,
+    dz @ W and dz^T F on the matrix pipe) from the same forward: every gradient agrees to fp32 rounding; into a running
+    sink (ops.edge_grad_sink, what the reversible backward uses) the winners' rows receive the same sums and the rows of
+    edges that win nothing keep their bits."""
+    from deep_gcns_torch_amd import ops
+    dev = _dev()
+    n = 3000
+    ei = synth.powerlaw_graph(n, 40_000, seed=11).to(dev)
+    E = ei.size(1)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g).to(dev)
+    full = torch.randn(E, 2 * K, generator=g).to(dev)
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(C, generator=g)
+    b[:3] = -1e3                                   # three channels at the relu floor everywhere: arg-max id -1
+    b = b.to(dev)
+    probe = torch.randn(n, C, generator=g).to(dev)
+    saved = ops.EGEMM_MAX_WINNER_BWD
+
+    def run(winner, sink=None):
+        ops.EGEMM_MAX_WINNER_BWD = winner
+        try:
+            xs, fs = x.clone().requires_grad_(True), full.clone().requires_grad_(True)
+            Ws, bs = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            feat = fs[:, K:]
+            if sink is None:
+                out = ops.gen_aggregate(xs, ei, feat, aggr="max", edge_encoder=(Ws, bs), dim_size=n, add_root=True)
+                (out * probe).sum().backward()
+                return out.detach(), xs.grad, fs.grad[:, K:], Ws.grad, bs.grad
+            with ops.edge_grad_sink(feat, sink):
+                out = ops.gen_aggregate(xs, ei, feat, aggr="max", edge_encoder=(Ws, bs), dim_size=n, add_root=True)
+                torch.autograd.grad((out * probe).sum(), [xs, Ws, bs, feat], allow_unused=True)
+            return sink
+        finally:
+            ops.EGEMM_MAX_WINNER_BWD = saved
+
+    dense = run(False)
+    win = run(True)
+    assert torch.equal(win[0], dense[0]) and torch.equal(win[1], dense[1]) and torch.equal(win[4], dense[4])
+    for a, r, what in ((win[2], dense[2], "grad_feat"), (win[3], dense[3], "grad_W")):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=2e-6 * float(r.abs().max()), msg=lambda m, what=what: f"{what}: {m}")
+    assert torch.equal(fs_zero := (win[2] == 0).all(1), (dense[2] == 0).all(1)) and 0 < int(fs_zero.sum()) < E
+    # the running sum of the reversible backward
+    before = torch.randn(E, K, generator=g).to(dev)
+    after = run(True, before.clone())
+    torch.testing.assert_close(after - before, win[2], rtol=1e-4, atol=1e-5 * float(win[2].abs().max()))
+    assert torch.equal(after[fs_zero], before[fs_zero])
+
+
 @pytest.mark.parametrize("aggr,kw", [("max", {}), ("softmax", dict(t=0.7)), ("power", dict(p=2.0))])
 def test_channels_at_the_relu_floor(aggr, kw):
     """Channels whose pre-activation is negative on EVERY edge (m = eps everywhere): no gradient flows through them.
