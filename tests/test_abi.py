@@ -45,6 +45,18 @@ def test_argument_errors_do_not_launch():
     assert lib.dgcn_gen_aggr_fwd_f32(C.byref(g), ptr, 2, None, 4, 3, 1, 0, 1.0, 1.0, 1e-7, None, None, ptr,
                                      None, None, None, None, 0, None) == -2
     assert lib.dgcn_selftest_axpy_f32(1.0, None, None, 4, None) == -1
+    # the max-winner backward of the fused edge GEMM: null inputs, channel / feature limits, row strides, nothing to do
+    big = (C.c_float * 4096)()
+    bp = (C.addressof(big) + 15) & ~15
+    assert lib.dgcn_egemm_max_bwd_num_partials(0) == 0 and lib.dgcn_egemm_max_bwd_num_partials(13253) == 255
+    assert lib.dgcn_egemm_max_bwd_f32(None, bp, 4, 8, bp, 16, bp, 16, 8, bp, 16, bp, None) == -1
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, bp, 16, bp, 16, 132, bp, 16, bp, None) == -2      # channels > 128
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, bp, 16, bp, 18, 8, bp, 16, bp, None) == -2       # n_feat % 4
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, bp, 16, bp, 16, 8, bp, 12, bp, None) == -2       # gradient stride < n_feat
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, bp + 4, 16, bp, 16, 8, bp, 16, bp, None) == -3    # misaligned feature rows
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, None, 16, bp, 16, 8, bp, 16, bp, None) == -1      # dW needs the features
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 0, 8, bp, 16, bp, 16, 8, bp, 16, bp, None) == 0         # no rows: no launch
+    assert lib.dgcn_egemm_max_bwd_f32(bp, bp, 4, 8, bp, 16, bp, 16, 8, None, 0, None, None) == 0      # nothing requested
 
 
 def test_hot_path_refuses_cpu_tensors():
