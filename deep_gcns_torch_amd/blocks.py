@@ -171,12 +171,11 @@ class ComposedEdgeEmbedding:
         if self.repeat != 1:
             raise ValueError("compose a group view, not the repeated embedding")
         w = layer_encoder.weight @ self.encoder.weight                               # (C, 8)
-        b = None
-        if self.encoder.bias is not None:
-            b = layer_encoder.weight @ self.encoder.bias
-        if layer_encoder.bias is not None:
-            b = layer_encoder.bias if b is None else b + layer_encoder.bias
-        return w, b
+        if self.encoder.bias is None:
+            return w, layer_encoder.bias
+        if layer_encoder.bias is None:
+            return w, layer_encoder.weight @ self.encoder.bias
+        return w, torch.addmv(layer_encoder.bias, layer_encoder.weight, self.encoder.bias)    # one op: b_l + W_l b_e
 
     def materialize(self) -> torch.Tensor:
         e = self.encoder(self.raw)
