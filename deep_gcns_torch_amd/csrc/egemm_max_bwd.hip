@@ -114,14 +114,21 @@ __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_feat_kernel(co
 }
 
 // dW[c][:] = sum_r g[r][c] F[arg[r][c]][:], owner-computes: wave w of the workgroup owns the channels w, w + 16, ...
-// (at most kMbChan of them: C <= 128) and keeps their K-float sums in registers (lane l: features 4l .. 4l+3); it walks
-// the workgroup's destination rows 64 at a time (lane = row for the id / gradient loads, then wave-uniform row by
-// row), kMbEdges feature rows in flight.  A feature row that wins several channels is fetched by several waves of the
-// same workgroup at about the same time: HBM sees it once, the rest are cache hits.  No LDS, no atomics; every
-// workgroup writes its whole [C][K] block: fixed summation order, bit-reproducible.
+// (at most kMbChan of them: C <= 128) and keeps their K-float sums in registers (lane l: features 4l .. 4l+3).  The
+// workgroup's 16 waves walk its destination rows TOGETHER, one row at a time: a winning edge wins ~3 channels of its
+// row, i.e. its feature row is wanted by ~3 waves -- with the whole workgroup inside the same row those requests fall
+// into one L2 residency.  Measured fetch per launch at the cluster shape (FETCH_SIZE x 2): 0.47 GB = the distinct
+// winning rows; every wave sweeping 64 rows per channel: 1.21 GB (0.200 ms); two rows per step: 0.86 GB; this form
+// 0.147 ms, bound by the latency of the kMbChan rows a wave has in flight (a rolling reload of the registers pair by
+// pair would keep them in flight across rows; the compiler's waitcnt placement drained it, not pursued).
+// Per row a wave has kMbChan (row, channel) pairs: lane p loads id / gradient of pair p (the next row's are requested
+// before this row's feature rows).  No LDS, no atomics; every workgroup writes its whole [C][K] block: fixed summation
+// order, bit-reproducible.
 constexpr int kMbChan = 8;
+constexpr int kMbChunk = 1;
 
 __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_weight_kernel(const MaxBwdParams P) {
+  constexpr int NP = kMbChan * kMbChunk;          // pairs per chunk: pair p = ci * kMbChunk + j  (channel slot ci, row j)
   const int C = P.C, K = P.K;
   const int lane = lane_id();
   const int wave = uni(static_cast<int>(threadIdx.x >> 6));
@@ -132,36 +139,34 @@ __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_weight_kernel(
   f4v acc[kMbChan];
 #pragma unroll
   for (int ci = 0; ci < kMbChan; ++ci) acc[ci] = f4v{0.f, 0.f, 0.f, 0.f};
-  for (int rc = r_beg; rc < r_end; rc += kWave) {
-    const int r = rc + lane;
-    const bool rok = r < r_end;
+  const int pc = wave + kMbWaves * (lane / kMbChunk);      // this lane's pair: channel ...
+  const int pj = lane % kMbChunk;                          // ... and row within the chunk
+  auto load_pair = [&](int rc, int& id, float& gv) {
+    const int r = rc + pj;
+    const bool ok = lane < NP && pc < C && r < r_end;
+    id = ok ? P.arg[static_cast<int64_t>(r) * C + pc] : -1;
+    gv = ok ? P.g[static_cast<int64_t>(r) * C + pc] : 0.f;
+  };
+  int id, idn;
+  float gv, gvn;
+  load_pair(r_beg, id, gv);
+  for (int rc = r_beg; rc < r_end; rc += kMbChunk) {
+    load_pair(rc + kMbChunk, idn, gvn);                    // (past the end: all lanes off)
+    f4v row[NP];
+    float gg[NP];
 #pragma unroll
-    for (int ci = 0; ci < kMbChan; ++ci) {
-      const int c = wave + kMbWaves * ci;            // wave-uniform
-      if (c < C) {
-        const int id = rok ? P.arg[static_cast<int64_t>(r) * C + c] : -1;
-        const float gv = rok ? P.g[static_cast<int64_t>(r) * C + c] : 0.f;
-        uint64_t live = __ballot(id >= 0);
-        while (live) {
-          f4v row[kMbEdges];
-          float gg[kMbEdges];
-#pragma unroll
-          for (int u = 0; u < kMbEdges; ++u) {
-            row[u] = f4v{0.f, 0.f, 0.f, 0.f};
-            gg[u] = 0.f;
-            if (live) {
-              const int l = first_bit(live);
-              live &= live - 1;
-              const int e = __builtin_amdgcn_readlane(id, l);
-              gg[u] = lane_value(gv, l);
-              if (kact) row[u] = *reinterpret_cast<const f4v*>(P.feat + static_cast<int64_t>(e) * P.feat_stride + k0);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < kMbEdges; ++u) acc[ci] += gg[u] * row[u];
-        }
+    for (int p = 0; p < NP; ++p) {
+      const int e = __builtin_amdgcn_readlane(id, p);
+      gg[p] = lane_value(gv, p);
+      row[p] = f4v{0.f, 0.f, 0.f, 0.f};
+      if (e >= 0 && kact) {                                // e wave-uniform
+        row[p] = *reinterpret_cast<const f4v*>(P.feat + static_cast<int64_t>(e) * P.feat_stride + k0);
       }
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p / kMbChunk] += gg[p] * row[p];
+    id = idn;
+    gv = gvn;
   }
   float* out = P.wpart + static_cast<int64_t>(blockIdx.x) * C * K;
 #pragma unroll
