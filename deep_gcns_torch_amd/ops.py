@@ -454,9 +454,10 @@ class _GenAggregate(torch.autograd.Function):
             if ctx.needs_input_grad[15]:
                 wpart = torch.empty(lib.dgcn_egemm_max_bwd_num_partials(graph.n_dst), C, n_feat, device=dev,
                                     dtype=torch.float32)
+            gc_rows = gcoef.contiguous()
             with _lib.device_ctx(dev):
                 _lib.check(lib.dgcn_egemm_max_bwd_f32(
-                    gcoef.contiguous().data_ptr(), aux1.data_ptr(), graph.n_dst, graph.n_edges, feat.data_ptr(),
+                    gc_rows.data_ptr(), aux1.data_ptr(), graph.n_dst, graph.n_edges, feat.data_ptr(),
                     feat.stride(0), w_enc.data_ptr(), n_feat, C, _lib.ptr(gf), gf.stride(0) if gf is not None else 0,
                     _lib.ptr(wpart), _lib.current_stream_handle(dev)), "dgcn_egemm_max_bwd_f32")
             if wpart is not None:
