@@ -825,6 +825,59 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
   return launch_status();
 }
 
+
+// dW' | db' of the per-edge encoder under MAX from the arg-max winners: dz has one non-zero per (destination row,
+// channel) -- g[r][c] at the edge the forward stored (original id; -1 = relu floor or empty row, see max_id_for_bwd in
+// gen_aggr_fwd.hip) -- so  dW'[c][f] = sum_r g[r][c] feat[arg[r][c]][f],  db'[c] = sum_{r: arg >= 0} g[r][c]:
+// n_dst * C gathers of 32 bytes instead of a per-edge pass.  Thread = channel, kEwRows destination rows per workgroup,
+// four gathers in flight per thread; partials [grid][C][kEncF + 1], every block fully written, fixed order.
+constexpr int kEwRows = 16;
+
+__global__ __launch_bounds__(kWgThreads) void enc_max_bwd_weight_kernel(const float* __restrict__ g,
+                                                                        const int32_t* __restrict__ arg, int n_rows, int C,
+                                                                        const float* __restrict__ feat,
+                                                                        float* __restrict__ part) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.x * kEwRows, r1 = min(r0 + kEwRows, n_rows);
+  float acc[kEncF + 1];
+#pragma unroll
+  for (int f = 0; f <= kEncF; ++f) acc[f] = 0.f;
+  for (int r = r0; r < r1; r += 4) {
+    int id[4];
+    float gv[4];
+    float4 fa[4], fb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = r + u < r1;
+      id[u] = ok ? arg[static_cast<int64_t>(r + u) * C + c] : -1;
+      gv[u] = ok ? g[static_cast<int64_t>(r + u) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      fb[u] = fa[u];
+      if (id[u] >= 0) {
+        const float4* fp = reinterpret_cast<const float4*>(feat + static_cast<int64_t>(id[u]) * kEncF);
+        fa[u] = fp[0];
+        fb[u] = fp[1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (id[u] >= 0) {
+        const float fe[kEncF] = {fa[u].x, fa[u].y, fa[u].z, fa[u].w, fb[u].x, fb[u].y, fb[u].z, fb[u].w};
+#pragma unroll
+        for (int f = 0; f < kEncF; ++f) acc[f] = fmaf(gv[u], fe[f], acc[f]);
+        acc[kEncF] += gv[u];
+      }
+    }
+  }
+  float* o = part + (static_cast<int64_t>(blockIdx.x) * C + c) * (kEncF + 1);
+#pragma unroll
+  for (int f = 0; f <= kEncF; ++f) o[f] = acc[f];
+}
+
 }  // namespace
 }  // namespace dgcn
 
@@ -927,3 +980,18 @@ extern "C" int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, in
                            workspace, workspace_bytes, stream);
 }
 
+extern "C" int32_t dgcn_enc_max_bwd_num_partials(int32_t n_dst) {
+  return n_dst > 0 ? (n_dst + kEwRows - 1) / kEwRows : 0;
+}
+
+extern "C" int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst,
+                                           const float* enc_feat, int32_t n_feat, int32_t channels,
+                                           float* enc_grad_partials, void* stream) {
+  if (!gcoef || !argmax || !enc_feat || !enc_grad_partials) return DGCN_E_NULL;
+  if (n_feat != kEncF || n_dst < 0 || channels <= 0 || channels > kWgThreads) return DGCN_E_SHAPE;
+  if (!aligned16(enc_feat)) return DGCN_E_ALIGN;
+  if (n_dst == 0) return DGCN_OK;
+  hipLaunchKernelGGL(enc_max_bwd_weight_kernel, dim3(dgcn_enc_max_bwd_num_partials(n_dst)), dim3(kWgThreads), 0,
+                     static_cast<hipStream_t>(stream), gcoef, argmax, n_dst, channels, enc_feat, enc_grad_partials);
+  return launch_status();
+}

@@ -27,6 +27,14 @@ extern "C" size_t dgcn_gen_aggr_fwd_workspace_bytes(const dgcn_graph* g, int32_t
 namespace dgcn {
 namespace {
 
+// Arg-max id as stored for the backward: with the relu message, m = relu(z) + eps equals eps exactly where no neighbour
+// has z > 0 -- no edge receives a gradient there, and saying so in the id (-1) lets a backward run from the ids alone,
+// without the pre-activations (dgcn_enc_max_bwd_weight_f32; the fused edge GEMM's forward marks the same way)
+__device__ __forceinline__ int max_id_for_bwd(float a, int idx, int msg, float eps) {
+  return (msg == DGCN_MSG_RELU_EPS && !(a > eps)) ? -1 : idx;
+}
+
+
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gen_aggr_fwd_body(const FwdParams& P) {
               x2[j] = st.d[j];
             } else if constexpr (MODE == DGCN_AGGR_MAX) {
               res[j] = st.idx[j] >= 0 ? st.a[j] : 0.f;
-              xi[j] = st.idx[j];
+              xi[j] = max_id_for_bwd(st.a[j], st.idx[j], P.msg, P.eps);
             } else if constexpr (MODE == DGCN_AGGR_MEAN) {
               res[j] = st.b[j] / fmaxf(deg, 1.f);
             } else {
@@ -318,7 +326,7 @@ __device__ __forceinline__ void enc_fwd_finish(const FwdParams& P, const Work& w
       x2[j] = st.d[j];
     } else if constexpr (MODE == DGCN_AGGR_MAX) {
       res[j] = st.idx[j] >= 0 ? st.a[j] : 0.f;
-      xi[j] = st.idx[j];
+      xi[j] = max_id_for_bwd(st.a[j], st.idx[j], P.msg, P.eps);
     } else if constexpr (MODE == DGCN_AGGR_MEAN) {
       res[j] = st.b[j] / fmaxf(deg, 1.f);
     } else {
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
     }
     P.out[o] = P.add_root ? res + P.x[static_cast<int64_t>(row) * P.x_stride + c] : res;
     if constexpr (MODE == DGCN_AGGR_MAX) {
-      if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = st.idx[0];
+      if (P.aux1) static_cast<int32_t*>(P.aux1)[o] = max_id_for_bwd(st.a[0], st.idx[0], P.msg, P.eps);
     } else if constexpr (MODE == DGCN_AGGR_SOFTMAX || MODE == DGCN_AGGR_POWER) {
       if (P.aux1) static_cast<float*>(P.aux1)[o] = x1;
       if (P.aux2) P.aux2[o] = x2;

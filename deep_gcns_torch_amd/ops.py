@@ -28,6 +28,8 @@ ENC_STATIC_ITEMS = False           # per-edge encoder kernels: True = work items
                                    # bit-reproducible dW | db at 1.3 - 1.6x the launch time; default = items claimed from
                                    # device-side counters (outputs and grad_x identical, dW | db equal to rounding)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
+ENC_MAX_WINNER_BWD = True          # per-edge encoder under max: dW' | db' from the (row, channel) arg-max winners (n_dst * C gathers
+                                   # of 32 bytes) + the plain CSC walk for grad_x, instead of the per-edge encoder walk; False = that walk
 EGEMM_MAX_WINNER_BWD = True        # its backward under max: walk the (row, channel) winners (csrc/egemm_max_bwd.hip) instead of
                                    # writing dz (E, C) and running dz @ W, dz^T F over it; False = that dense route (A/B)
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
@@ -357,6 +359,11 @@ class _GenAggregate(torch.autograd.Function):
         if winners:
             need_dz = False
         enc = None if egemm else ctx.enc                  # narrow per-edge encoder: dW | db partials, no (E, C) array
+        # ... under max the forward's arg-max ids (-1 = relu floor) are all the backward needs: grad_x from the plain
+        # walk (no encoder recomputation per edge), dW' | db' from the winners
+        enc_winners = enc is not None and mode == _lib.AGGR_MAX and ENC_MAX_WINNER_BWD and ctx.msg == _lib.MSG_RELU_EPS
+        if enc_winners:
+            enc_w_args, enc = enc, None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
                 (winners and ctx.enc[2] is not None and ctx.needs_input_grad[16]) or \
                 (enc is not None and any(ctx.needs_input_grad[15:17])):
@@ -367,7 +374,7 @@ class _GenAggregate(torch.autograd.Function):
             ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
             gshift = kshift = shift_ok = None
-            bwd_flags = ctx.flags | (_lib.FLAG_EA_IS_Z if egemm else 0)
+            bwd_flags = ctx.flags | (_lib.FLAG_EA_IS_Z if (egemm or enc_winners) else 0)
             if mode == _lib.AGGR_SOFTMAX and not ctx.learn_t and C % 4 == 0 and ctx.range_flag is not None:
                 # g_i exp(t m - L_i) = [g_i exp(K_c - L_i)] exp(t m - K_c): one gathered row per edge.  K_c = 0
                 # is safe whenever every |L_i| < 80, which the FORWARD kernel checked on the fly (range_flag);
@@ -393,7 +400,7 @@ class _GenAggregate(torch.autograd.Function):
                         _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
-                elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and C <= 256 and \
+                elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and not enc_winners and C <= 256 and \
                         graph.n_dst * C * 4 >= MAX_MASK_MIN_TABLE_BYTES and graph.n_edges > 0:
                     # arg-max bit masks per edge instead of gathered arg-max rows (big graphs: the table misses the caches)
                     mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
@@ -442,6 +449,20 @@ class _GenAggregate(torch.autograd.Function):
                         grad_b = grad_x.sum(0) - g.sum(0) if ctx.add_root else grad_x.sum(0)
             if not ctx.needs_input_grad[0]:
                 grad_x = None
+        if enc_winners and any(ctx.needs_input_grad[15:17]):
+            feat, w_enc, b_enc = enc_w_args
+            gpart = torch.empty(lib.dgcn_enc_max_bwd_num_partials(graph.n_dst), C, ENC_FEATURES + 1, device=dev,
+                                dtype=torch.float32)
+            gc_rows = gcoef.contiguous()
+            with _lib.device_ctx(dev):
+                _lib.check(lib.dgcn_enc_max_bwd_weight_f32(gc_rows.data_ptr(), aux1.data_ptr(), graph.n_dst, feat.data_ptr(),
+                                                           ENC_FEATURES, C, gpart.data_ptr(),
+                                                           _lib.current_stream_handle(dev)), "dgcn_enc_max_bwd_weight_f32")
+            gsum = gpart.sum(0)
+            if ctx.needs_input_grad[15]:
+                grad_w = gsum[:, :ENC_FEATURES].contiguous()
+            if b_enc is not None and ctx.needs_input_grad[16]:
+                grad_b = gsum[:, ENC_FEATURES].contiguous()
         if winners and (ctx.needs_input_grad[14] or ctx.needs_input_grad[15]):
             feat, w_enc, b_enc = ctx.enc
             n_feat = feat.size(1)

@@ -229,6 +229,21 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
                               float* enc_grad_partials, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Weight gradient of the per-edge encoder (dgcn_gen_aggr_enc_fwd_f32) under DGCN_AGGR_MAX from the arg-max winners:
+ * the forward's aux1 holds the ORIGINAL edge id of the winner of every (destination row, channel), -1 where no
+ * neighbour passed the relu of GENConv.message (gcn_lib/sparse/torch_vertex.py:78-85) or the row is empty, so
+ *   d enc_weight[c][f] = sum_r gcoef[r][c] * enc_feat[argmax[r][c]][f],   d enc_bias[c] = sum_{r: argmax >= 0} gcoef[r][c]
+ * (what autograd builds for edge_emb = edge_encoder(edge_attr), torch_vertex.py:62-66, under scatter(reduce='max'),
+ * gcn_lib/sparse/torch_message.py:46-47) costs n_dst * channels gathers of 32 bytes instead of a pass over the edges.
+ * grad_x then comes from dgcn_gen_aggr_bwd_f32(edge_attr = NULL, flags | DGCN_FLAG_EA_IS_Z) (the ids carry the relu mask).
+ *   enc_grad_partials [dgcn_enc_max_bwd_num_partials(n_dst)][channels][n_feat + 1], every block fully written; the sum
+ *   over the first axis is (d enc_weight | d enc_bias), fixed summation order.  n_feat == 8, channels <= 256.
+ */
+int32_t dgcn_enc_max_bwd_num_partials(int32_t n_dst);
+int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst, const float* enc_feat,
+                                int32_t n_feat, int32_t channels, float* enc_grad_partials, void* stream);
+
+/*
  * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE
  * (E, hidden) edge embedding and every GENConv owns edge_encoder = Linear(edge_feat_dim = hidden -> C)
  * (gcn_lib/sparse/torch_vertex.py:56-66; examples/ogb_eff/ogbn_proteins/model_rev.py:45-55,98-107;

@@ -559,6 +559,54 @@ def test_max_backward_bit_mask_path_equals_the_row_walk(C, sorted_input, monkeyp
         assert torch.equal(grads[("mask", k)], grads[("rows", k)]), k
 
 
+@pytest.mark.parametrize("C", [112, 40, 256])
+def test_per_edge_encoder_max_backward_from_the_winners(C):
+    """Max aggregation with the per-edge encoder: the backward that takes grad_x from the plain walk over the forward's
+    arg-max ids (-1 marks the relu floor) and dW' | db' from the (row, channel) winners (dgcn_enc_max_bwd_weight_f32)
+    against the per-edge encoder walk that recomputes z for every edge -- same forward, channels at the relu floor on
+    every edge, rows without edges, the fused root term."""
+    from deep_gcns_torch_amd import ops, synth
+    dev = _dev()
+    n = 3000
+    ei = synth.powerlaw_graph(n, 25_000, seed=3, exponent=2.1)
+    ei = ei[:, ei[1] < n - 40].to(dev)                    # the last 40 destination rows have no edges
+    E = ei.size(1)
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g).to(dev)
+    feat = torch.randn(E, 8, generator=g).to(dev)
+    W = (torch.randn(C, 8, generator=g) * 0.5).to(dev)
+    b = torch.randn(C, generator=g) * 0.5
+    b[:5] = -1e3                                           # z < 0 on every edge: m = eps, no gradient
+    b = b.to(dev)
+    probe = torch.randn(n, C, generator=g).to(dev)
+    saved = ops.ENC_MAX_WINNER_BWD
+
+    def run(flag):
+        ops.ENC_MAX_WINNER_BWD = flag
+        try:
+            xa, Wa, ba = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            out = ops.gen_aggregate(xa, ei, feat, aggr="max", edge_encoder=(Wa, ba), dim_size=n, add_root=True)
+            (out * probe).sum().backward()
+            return out.detach(), xa.grad, Wa.grad, ba.grad
+        finally:
+            ops.ENC_MAX_WINNER_BWD = saved
+
+    walk, win = run(False), run(True)
+    assert torch.equal(win[0], walk[0])
+    for a, r, what in zip(win[1:], walk[1:], ("grad_x", "grad_W", "grad_b")):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=2e-6 * float(r.abs().max()), msg=lambda m, what=what: f"{what}: {m}")
+    assert float(win[2][:5].abs().max()) == 0.0 and float(win[3][:5].abs().max()) == 0.0     # the dead channels
+    # only the weights need a gradient: no walk at all
+    ops.ENC_MAX_WINNER_BWD = True
+    try:
+        Wa, ba = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = ops.gen_aggregate(x, ei, feat, aggr="max", edge_encoder=(Wa, ba), dim_size=n, add_root=True)
+        gW, gb = torch.autograd.grad((out * probe).sum(), [Wa, ba])
+    finally:
+        ops.ENC_MAX_WINNER_BWD = saved
+    assert torch.equal(gW, win[2]) and torch.equal(gb, win[3])
+
+
 def test_encoder_walk_item_schedules():
     """The per-edge encoder kernels hand their work items out from device-side counters (default) or deal them by wave
     index (ops.ENC_STATIC_ITEMS / DGCN_FLAG_STATIC_ITEMS).  Outputs and grad_x: the same bits under both schedules and
