@@ -127,7 +127,8 @@ int dgcn_selftest_axpy_f32(float a, const float* x, float* y, int64_t n, void* s
  *   out        [n_dst, C] contiguous
  *   aux1       [n_dst, C] or NULL.  SOFTMAX: logsumexp L_i = M_i + log D_i of t*m_e.
  *              POWER: the pre-clamp mean q_i.  MAX: int32 original edge id of the arg-max
- *              (-1 for an empty row).  ADD/MEAN: unused.
+ *              (-1 for an empty row, and with DGCN_MSG_RELU_EPS for a channel whose best message is the relu
+ *              floor m = eps: no neighbour has z > 0, no edge receives a gradient).  ADD/MEAN: unused.
  *   aux2       [n_dst, C] or NULL.  SOFTMAX+LEARN_T: sum_e w_e m_e^2.
  *              POWER+LEARN_P: sum_e u_e^p ln u_e.  Otherwise unused.
  *   range_flag optional device int32, zeroed by the caller: SOFTMAX sets it to 1 when some |L_i| >= 80, i.e. when
