@@ -28,8 +28,10 @@ ENC_STATIC_ITEMS = False           # per-edge encoder kernels: True = work items
                                    # bit-reproducible dW | db at 1.3 - 1.6x the launch time; default = items claimed from
                                    # device-side counters (outputs and grad_x identical, dW | db equal to rounding)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
-ENC_MAX_WINNER_BWD = True          # per-edge encoder under max: dW' | db' from the (row, channel) arg-max winners (n_dst * C gathers
-                                   # of 32 bytes) + the plain CSC walk for grad_x, instead of the per-edge encoder walk; False = that walk
+ENC_MAX_WINNER_BWD = False         # per-edge encoder under max: dW' | db' from the (row, channel) arg-max winners (n_dst * C gathers
+                                   # of 32 bytes) + the plain CSC walk for grad_x, instead of the per-edge encoder walk.  OFF by
+                                   # default: 0.296 -> 0.254 ms per layer and 11.06 -> 10.57 ms per RevGCN-8 hipGraph step, but a
+                                   # graph captured after eager steps of the same process faulted in replay
 EGEMM_MAX_WINNER_BWD = True        # its backward under max: walk the (row, channel) winners (csrc/egemm_max_bwd.hip) instead of
                                    # writing dz (E, C) and running dz @ W, dz^T F over it; False = that dense route (A/B)
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
