@@ -58,3 +58,53 @@ def test_graphed_training_step_equals_eager_steps():
     for (k, a), (_, b) in zip(graphed_model.named_parameters(), eager.named_parameters()):
         # deterministic kernels, the same arithmetic in the same order: equal to the last bit or two
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_graphed_forward_backward_with_the_dynamic_item_schedule():
+    """The default (dynamic, device-side counters) item schedule of the per-edge encoder kernels inside a replayed graph:
+    the counters are re-armed by a memset node of every launch, so a replay must do the same work as an eager pass.
+    Forward outputs are schedule-independent (bit-equal); the weight gradients' partial sums are grouped by the schedule
+    (rounding-level differences).  No optimizer here: Adam would turn those last bits into O(lr) differences."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import ops
+    from deep_gcns_torch_amd.graphs import GraphedStep
+    assert not ops.ENC_STATIC_ITEMS
+    dev = torch.device("cuda:0")
+    n = 2500
+    ei = synth.powerlaw_graph(n, 20_000, seed=5).to(dev)
+    g = torch.Generator().manual_seed(7)
+    table = torch.rand(n, 8, generator=g).to(dev)
+    x = torch.rand(n, 8, generator=g).to(dev)
+    ea = torch.rand(ei.size(1), 8, generator=g).to(dev)
+    nidx = torch.arange(n, device=dev)
+    y = (torch.rand(n, 16, generator=g) > 0.5).float().to(dev)
+    torch.manual_seed(1)
+    model = rev_restated.RevGCN(num_layers=3, hidden=224, num_tasks=16, aggr="max", dropout=0.0, node_table=table,
+                                impl="product", composed_edges=True).to(dev).train()
+    held = {}
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        pred, _ = model(x, nidx, ei, ea)
+        torch.nn.functional.binary_cross_entropy_with_logits(pred, y).backward()
+        held["pred"] = pred.detach()
+
+    fwd_bwd()
+    torch.cuda.synchronize()
+    ref_pred = held["pred"].clone()
+    ref_grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    graphed = GraphedStep(fwd_bwd, warmup=2)
+    captured_pred = held["pred"]                      # the tensor the captured step writes on every replay
+    for _ in range(3):
+        captured_pred.fill_(float("nan"))             # a replay that skipped work would leave this behind
+        graphed()
+    torch.cuda.synchronize()
+    assert torch.equal(captured_pred, ref_pred)
+    assert ref_grads
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            r = ref_grads[k]
+            torch.testing.assert_close(p.grad, r, rtol=1e-4, atol=1e-6 * max(float(r.abs().max()), 1e-3),
+                                       msg=lambda m, k=k: f"{k}: {m}")
