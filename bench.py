@@ -13,6 +13,8 @@ N>1 (launched by torch.distributed.run, one rank per GPU): the SAME graph is par
 destination range across ranks (strong scaling); every step all-gathers the feature shards
 over RCCL and each rank aggregates its own destination rows (deep_gcns_torch_amd/dist.py).
 Rank 0 prints ONE JSON line.
+
+DGCN_BENCH_TRACE=1 in the environment prints the name of every `extra` row to stderr before it runs.
 """
 from __future__ import annotations
 
