@@ -26,6 +26,9 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL peer access)
+# the four 1x1 Conv2d layers around the ResGCN-28 stack go through MIOpen; on a fresh box its default find mode compiles
+# and times candidates for 15 - 25 s (the `dense` section read 4 - 29 s box to box): take its immediate-mode choice
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
