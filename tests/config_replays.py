@@ -79,3 +79,51 @@ def deepergcn_oracle_forward(model, x, ei, hidden_rows=None):
 
 def fixture_path(size):
     return os.path.join(GOLDEN, f"config_deepergcn28_{size}.pt")
+
+
+# ---- config 5 at the depth BASELINE names: RevGCN-112 (hidden 224, group 2) on the ogbn-proteins cluster shape -----------
+REVGCN112_KW = dict(num_layers=112, hidden=224)
+REVGCN_OUT_ROWS = 1024
+
+
+def formula_init(model, seed):
+    """Parameters as a function of (name, shape, seed) only: the generator builds the REFERENCE's classes, the GPU tests the
+    restated / product classes, whose constructors consume torch's RNG in a different order.  Scales follow nn.Linear /
+    LayerNorm defaults (U(-1/sqrt(fan_in), 1/sqrt(fan_in)); norm weights 1 +- 0.1, norm biases +- 0.1) so that the depth
+    behaves like a freshly initialised model."""
+    import zlib
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+            if p.dim() == 2:
+                bound = 1.0 / (p.size(1) ** 0.5)
+                v = (torch.rand(p.shape, generator=g, dtype=torch.float64) * 2 - 1) * bound
+            elif "norm" in name and name.endswith("weight"):
+                v = 1.0 + 0.1 * (torch.rand(p.shape, generator=g, dtype=torch.float64) * 2 - 1)
+            elif p.numel() == 1:
+                continue                                  # t / p of the aggregation keep their configured values
+            else:
+                v = 0.1 * (torch.rand(p.shape, generator=g, dtype=torch.float64) * 2 - 1)
+            p.copy_(v.to(p.dtype))
+    return model
+
+
+def revgcn_inputs(scale=1.0):
+    """Seeded inputs at the ogbn-proteins cluster shape: graph, node features, node index, raw edge
+    features, node table, probe for L = sum(last_norm_out * probe)."""
+    from deep_gcns_torch_amd import synth
+    s = synth.SHAPES["proteins_cluster"]
+    n = max(64, int(s["n"] * scale))
+    ei = synth.powerlaw_graph(n, max(64, int(s["n_undirected"] * scale)), s["seed"])
+    g = torch.Generator().manual_seed(55)
+    x = torch.rand(n, 8, generator=g)
+    node_index = torch.randperm(n, generator=g)
+    edge_attr = torch.rand(ei.size(1), 8, generator=g)
+    table = torch.rand(n, 8, generator=g)
+    probe = torch.randn(n, REVGCN112_KW["hidden"], generator=g)
+    return dict(n=n, edge_index=ei, x=x, node_index=node_index, edge_attr=edge_attr, table=table, probe=probe)
+
+
+def revgcn_fixture_path(aggr, layers=112, scale=1.0):
+    tag = "" if scale == 1.0 else f"_s{scale:g}"
+    return os.path.join(GOLDEN, f"config_revgcn{layers}_{aggr}{tag}.pt")

@@ -13,6 +13,43 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+GUARD_LIB = os.path.join(ROOT, "tests", "guard_alloc", "libguard_alloc.so")
+_guard_installed = False
+
+
+def install_guard_allocator():
+    """DGCN_GUARD_ALLOC=1: every device allocation of this process gets its own mapping with unmapped guard pages on
+    both sides (tests/guard_alloc/guard_alloc.cpp), so that an out-of-bounds access of any kernel -- torch's or
+    libdgcn's -- faults instead of touching a neighbouring buffer.  Must run before the first device allocation.
+    tests/test_memory_guard_gpu.py runs parts of this suite in such a process."""
+    global _guard_installed
+    if _guard_installed or os.environ.get("DGCN_GUARD_ALLOC") != "1":
+        return False
+    import torch
+    if not torch.cuda.is_available():
+        return False
+    if not os.path.exists(GUARD_LIB):
+        raise RuntimeError(f"{GUARD_LIB} not built (python -c 'import __graft_entry__ as g; g.build()')")
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(GUARD_LIB, "dgcn_guard_malloc", "dgcn_guard_free")
+    torch.cuda.memory.change_current_allocator(alloc)
+    # a free must not synchronise the device while a hipGraph is being captured, and what a capture allocates or frees
+    # has to stay mapped for the replays: the allocator is told when torch.cuda.graph is active
+    import ctypes
+    lib = ctypes.CDLL(GUARD_LIB)
+    enter, exit_ = torch.cuda.graph.__enter__, torch.cuda.graph.__exit__
+
+    def _enter(self):
+        lib.dgcn_guard_set_capturing(1)
+        return enter(self)
+
+    def _exit(self, *exc):
+        try:
+            return exit_(self, *exc)
+        finally:
+            lib.dgcn_guard_set_capturing(0)
+    torch.cuda.graph.__enter__, torch.cuda.graph.__exit__ = _enter, _exit
+    _guard_installed = True
+    return True
 
 
 def pytest_configure(config):
@@ -22,6 +59,7 @@ def pytest_configure(config):
     # (bench.py's thread sweeps: kNN 507 ms at 32 threads against 2010 ms at 256; arxiv aggregation 0.40 vs 0.11 M
     # edges/s).  DGCN_TEST_THREADS overrides.
     import torch
+    install_guard_allocator()
     want = int(os.environ.get("DGCN_TEST_THREADS", "32"))
     torch.set_num_threads(max(1, min(want, os.cpu_count() or 1)))
 
