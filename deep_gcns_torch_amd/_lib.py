@@ -69,8 +69,8 @@ _SIGNATURES = {
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_enc_max_bwd_num_partials": (C.c_int32, [C.c_int32]),
-    "dgcn_enc_max_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
-                                              C.c_void_p, C.c_void_p]),
+    "dgcn_enc_max_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_gen_aggr_egemm_supported": (C.c_int32, [C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_f32": (C.c_int, [

