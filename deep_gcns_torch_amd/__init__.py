@@ -24,7 +24,7 @@ _SUBMODULES = (
 )
 
 
-def install(reference_root=None, fuse_models=False):
+def install(reference_root=None, fuse_models=True):
     """Register this package's `gcn_lib` and `utils` under their top-level names so the reference's
     example scripts (`from gcn_lib.sparse.torch_vertex import GENConv`, `from utils.pyg_util import
     scatter_`, ...) import them unchanged.  With ``reference_root`` the reference's own `utils/`
@@ -32,7 +32,7 @@ def install(reference_root=None, fuse_models=False):
     ... (pure-torch helpers outside the hot path) keep resolving to the reference's files, and
     `eff_gcn_modules` / `examples` become importable from there.
 
-    ``fuse_models=True``: the layer loops the reference writes in its MODEL files (examples/ogb/ogbn_arxiv/model.py:88-106,
+    ``fuse_models=True`` (default since round 5; ``False`` opts out and removes the hook): the layer loops the reference writes in its MODEL files (examples/ogb/ogbn_arxiv/model.py:88-106,
     ogbn_products/model.py, ogb_eff/ogbn_proteins/model_rev.py:98-99) are routed through ``blocks.res_plus_layer`` /
     ``blocks.ComposedEdgeEmbedding`` when those files are imported -- unchanged files, same ``state_dict``, same values
     (deep_gcns_torch_amd/fuse.py; ``fuse.fuse_model(instance)`` does it for one object)."""
@@ -46,7 +46,9 @@ def install(reference_root=None, fuse_models=False):
             utils_mod.__path__.append(ref_utils)
         if reference_root not in sys.path:
             sys.path.append(reference_root)
+    from . import fuse
     if fuse_models:
-        from . import fuse
         fuse.enable_import_hook()
+    else:
+        fuse.disable_import_hook()
     return sys.modules["gcn_lib"]

@@ -79,9 +79,10 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
         # device's autograd thread, possibly after the ``with`` block was left -- and must exchange rows / statistics
         # exactly like the first pass: the context object travels with the closure
         part_ctx = _active_partition()
+        opt_ctx = ops.captured_options()                   # the caller's ``ops.options`` block, for the same reason
 
         def run(h2_, h_, ea_):
-            with _reentered(part_ctx):
+            with _reentered(part_ctx), opt_ctx:
                 return run_(h2_, h_, ea_)
 
         def run_(h2_, h_, ea_):

@@ -35,6 +35,33 @@ def _newest_header_mtime() -> float:
     return max(h.stat().st_mtime for h in hdrs)
 
 
+def build_debug_ids() -> Path:
+    """libdgcn_dbg.so: the library with -DDGCN_DEBUG_IDS (investigation builds: out-of-range arg-max ids are counted
+    and recorded, dgcn_debug_bad_ids).  Loaded through DGCN_LIB_PATH; never the shipped library."""
+    out = CSRC / "libdgcn_dbg.so"
+    srcs = sorted(CSRC.glob("*.hip"))
+    objs = []
+    dbg = CSRC / "_obj_dbg"
+    dbg.mkdir(exist_ok=True)
+    for src in srcs:
+        obj = dbg / (src.stem + ".o")
+        reuse = OBJ / (src.stem + ".o")
+        if src.name != "gen_aggr_bwd.hip" and reuse.exists():
+            objs.append(reuse)
+            continue
+        cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-DDGCN_DEBUG_IDS", f"-I{INCLUDE}",
+               f"-I{CSRC}", "-c", str(src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+        objs.append(obj)
+    r = subprocess.run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out)] + [str(o) for o in objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def _compile_one(src: Path, force: bool, verbose: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
     if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
@@ -73,6 +100,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+if __name__ == "__main__" and "--debug-ids" in sys.argv:
+    build()
+    print(build_debug_ids())
+    sys.exit(0)
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)

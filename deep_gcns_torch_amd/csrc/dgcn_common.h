@@ -87,6 +87,27 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
+// Zero-fill of counters the next kernel of the same call claims work from / accumulates into -- as a KERNEL, never
+// hipMemsetAsync.  Round 5 finding: in a replayed hipGraph (ROCm 7.2, MI355X) a memset NODE is not held back until the
+// kernel node in front of it has drained; the next call's reset of the work-item counters (same address: torch hands
+// the same workspace block to consecutive layers) landed while the last waves of the previous launch were still making
+// their final claims, the counters started the next launch at 1 instead of 0 and the first item of a few queues --
+// rows 0 .. 2 of the ogbn-proteins cluster -- was never processed: stale arg-max ids, wrong outputs in ~10 % of the
+// replayed launches (and an illegal address once the ids were used as addresses: DESIGN.md 4.13).  A kernel node is
+// ordered after the kernel in front of it like any other launch.
+static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, size_t n_words) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+}
+
+static inline void zero_async(void* p, size_t bytes, hipStream_t s) {       // bytes % 4 == 0, p 4-byte aligned
+  const size_t n = bytes / 4;
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, static_cast<uint32_t*>(p), n);
+}
+
 // Grid size for a wave-per-item kernel: enough workgroups to keep every CU's 32 wave
 // slots busy, capped so very large inputs grid-stride instead of launching millions
 // of tiny workgroups.

@@ -810,8 +810,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
     if (!workspace) return DGCN_E_NULL;
     P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                           dgcn_gen_aggr_bwd_workspace_bytes(g, channels) - kTicketBytes);
-    const hipError_t me = hipMemsetAsync(P.ticket, 0, kTicketBytes, static_cast<hipStream_t>(stream));
-    if (me != hipSuccess) return static_cast<int>(me);
+    zero_async(P.ticket, kTicketBytes, static_cast<hipStream_t>(stream));     // a kernel, not a memset node: dgcn_common.h
   }
   const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -833,6 +832,12 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
 // four gathers in flight per thread; partials [grid][C][kEncF + 1], every block fully written, fixed order.
 constexpr int kEwRows = 16;
 
+#ifdef DGCN_DEBUG_IDS
+// investigation build only (python -m deep_gcns_torch_amd.build --debug-ids -> libdgcn_dbg.so): ids that are neither -1
+// nor an edge of the graph are counted and the first 64 recorded as (row, channel, id)
+__device__ int dgcn_dbg_bad[1 + 3 * 64 + 8 + 16];   // [201..216] = bad ids per row 0..15;   // [193..] = bad ids in row 0 / rows 1-15 / rows 16-1023 / rows >= 1024
+#endif
+
 __global__ __launch_bounds__(kWgThreads) void enc_max_bwd_weight_kernel(const float* __restrict__ g,
                                                                         const int32_t* __restrict__ arg, int n_rows, int C,
                                                                         int n_edges, const float* __restrict__ feat,
@@ -851,6 +856,15 @@ __global__ __launch_bounds__(kWgThreads) void enc_max_bwd_weight_kernel(const fl
     for (int u = 0; u < 4; ++u) {
       const bool ok = r + u < r1;
       id[u] = ok ? arg[static_cast<int64_t>(r + u) * C + c] : -1;
+#ifdef DGCN_DEBUG_IDS
+      if (id[u] != -1 && static_cast<uint32_t>(id[u]) >= static_cast<uint32_t>(n_edges)) {
+        const int k = atomicAdd(&dgcn_dbg_bad[0], 1);
+        if (k < 64) { dgcn_dbg_bad[1 + 3 * k] = r + u; dgcn_dbg_bad[2 + 3 * k] = c; dgcn_dbg_bad[3 + 3 * k] = id[u]; }
+        const int rr = r + u;
+        atomicAdd(&dgcn_dbg_bad[193 + (rr == 0 ? 0 : (rr < 16 ? 1 : (rr < 1024 ? 2 : 3)))], 1);
+        if (rr < 16) atomicAdd(&dgcn_dbg_bad[201 + rr], 1);
+      }
+#endif
       if (static_cast<uint32_t>(id[u]) >= static_cast<uint32_t>(n_edges)) id[u] = -1;   // never an address outside feat
       gv[u] = ok ? g[static_cast<int64_t>(r + u) * C + c] : 0.f;
     }
@@ -980,6 +994,13 @@ extern "C" int dgcn_gen_aggr_enc_bwd_f32(const dgcn_graph* g, const float* x, in
                            t_dev, p_dev, gcoef, aux1, out, gshift, kshift, shift_ok, groot, grad_x, nullptr,
                            workspace, workspace_bytes, stream);
 }
+
+#ifdef DGCN_DEBUG_IDS
+extern "C" int dgcn_debug_bad_ids(int32_t* host, int32_t n_ints) {
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(dgcn_dbg_bad), sizeof(int32_t) * n_ints, 0,
+                                              hipMemcpyDeviceToHost));
+}
+#endif
 
 extern "C" int32_t dgcn_enc_max_bwd_num_partials(int32_t n_dst) {
   return n_dst > 0 ? (n_dst + kEwRows - 1) / kEwRows : 0;

@@ -579,6 +579,11 @@ constexpr int kFTM = 16;
 constexpr int kFSamples = 256;
 constexpr int kFThreads = 1024;   // 16 waves: one per query row in the select phase, 4 per SIMD to hide latency
 constexpr int kFWaves = kFThreads / kWave;
+#ifndef DGCN_KNN_FB_WAVES
+#define DGCN_KNN_FB_WAVES 8
+#endif
+constexpr int kFbWaves = DGCN_KNN_FB_WAVES;   // waves per workgroup of the bf16 filter kernel: 8 = two workgroups per CU whose phases
+                                               // (matrix pass / per-row select) overlap; 16 = round 4's single resident workgroup
 
 constexpr int kPrepThreads = kFSamples;   // one thread per sampled candidate
 
@@ -1131,8 +1136,8 @@ __global__ __launch_bounds__(256) void knn_planes_kernel(const float* __restrict
 // Distances: D = (|x_i|^2 + (-2 ip)) + |x_j|^2 with ip from the six-product sum instead of the channel-ordered fma chain:
 // the same value up to fp32 rounding (not bit for bit); a row is ranked entirely by ONE of the two evaluations (this
 // kernel's, or the exact kernel's chain when the row is redone), never by a mixture.
-template <int kFCap, int KC>
-__global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const KnnParams P) {
+template <int kFCap, int KC, int NW>
+__global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const KnnParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kFTM;
   const int N = P.N, K = P.K;
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
   auto frag = [&](int ctile, int kb, int p) -> i4v {
     return pb[p * plane + static_cast<int64_t>(ctile) * UNITS * 16 + (4 * kb + lk) * 16 + li];
   };
-  constexpr int kColStride = kFWaves * 64;
+  constexpr int kColStride = NW * 64;
   // one step = the three plane fragments of TWO 16-candidate tiles for one 32-channel block: 6 loads, 12 MFMAs that
   // alternate between the two accumulators (no back-to-back dependent MFMAs); the next step's loads are in flight
   // while this step's MFMAs run.  Four steps (2 tile pairs x KC) per 64-candidate block when KC = 2.
@@ -1202,44 +1207,55 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
     uint32_t* skeys = ckey;                       // [16][512], aliasing the (still empty) candidate lists
     const int NT = Np >> 4;
     const int rot = (tile * 7) % max(NT / 32, 1);
-    int sct[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) sct[t] = static_cast<int>((static_cast<int64_t>(2 * wave + t) * NT / 32 + rot) % NT);
-    i4v sf[KC][2][3];
+    constexpr int NPASS = 16 / NW;                // sample tiles: 32 per workgroup, two per wave and pass
 #pragma unroll
     for (int kb = 0; kb < KC; ++kb) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        a[kb][p] = frag(tile, kb, p);
-        sf[kb][0][p] = frag(sct[0], kb, p);
-        sf[kb][1][p] = frag(sct[1], kb, p);
-      }
+      for (int p = 0; p < 3; ++p) a[kb][p] = frag(tile, kb, p);
     }
     load_step(wave * 64, 0, 0, fA);
-    float sjv[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) sjv[t] = (sct[t] * 16 + li) < N ? sqn[sct[t] * 16 + li] : 0.f;
-    __syncthreads();                              // sq[], cnt[] visible
-    f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int pass = 0; pass < NPASS; ++pass) {
+      int sct[2];
 #pragma unroll
-    for (int kb = 0; kb < KC; ++kb) {
-#pragma unroll
-      for (int s6 = 0; s6 < 6; ++s6) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) sacc[t] = eg_mfma_bf16(a[kb][pa[s6]], sf[kb][t][pbb[s6]], sacc[t]);
+      for (int t = 0; t < 2; ++t) {
+        sct[t] = static_cast<int>((static_cast<int64_t>(2 * (wave + pass * NW) + t) * NT / 32 + rot) % NT);
       }
-    }
+      i4v sf[KC][2][3];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bool inn = (sct[t] * 16 + li) < N;
+      for (int kb = 0; kb < KC; ++kb) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = lk * 4 + reg;
-        skeys[r * 512 + (2 * wave + t) * 16 + li] = inn ? key_of((sq[r] + (-2.f * sacc[t][reg])) + sjv[t]) : 0xFFFFFFFFu;
+        for (int p = 0; p < 3; ++p) {
+          sf[kb][0][p] = frag(sct[0], kb, p);
+          sf[kb][1][p] = frag(sct[1], kb, p);
+        }
+      }
+      float sjv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) sjv[t] = (sct[t] * 16 + li) < N ? sqn[sct[t] * 16 + li] : 0.f;
+      if (pass == 0) __syncthreads();             // sq[], cnt[] visible
+      f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) sacc[t] = eg_mfma_bf16(a[kb][pa[s6]], sf[kb][t][pbb[s6]], sacc[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool inn = (sct[t] * 16 + li) < N;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = lk * 4 + reg;
+          skeys[r * 512 + (2 * (wave + pass * NW) + t) * 16 + li] =
+              inn ? key_of((sq[r] + (-2.f * sacc[t][reg])) + sjv[t]) : 0xFFFFFFFFu;
+        }
       }
     }
     __syncthreads();
-    {
+    for (int trow = wave; trow < TM; trow += NW) {
       // tau_r = an upper bound of the sample_rank-th smallest of the 512 sample keys, one bucket of a 256-bucket
       // histogram wide (a threshold may overshoot by a couple of samples; the 20-step bisection that used to find it
       // exactly cost 1,240 vector instructions per wave, 40 % of the K = 16 kernel): key range, histogram in LDS,
@@ -1250,7 +1266,7 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        ks[q] = skeys[wave * 512 + q * kWave + lane];
+        ks[q] = skeys[trow * 512 + q * kWave + lane];
         mn = min(mn, ks[q]);
         mx = max(mx, ks[q] == 0xFFFFFFFFu ? 0u : ks[q]);            // (padding of a last, partly filled tile)
       }
@@ -1263,7 +1279,7 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       if (lo > mx) lo = mn;                                         // every sample has the same key
       const uint32_t span = mx - lo;
       const int shift = max(0, 24 - static_cast<int>(__builtin_clz(span | 1u)));   // (span >> shift) < 256
-      uint32_t* hist = cidx + wave * 512;                           // [512] in the (still unused) id lists
+      uint32_t* hist = cidx + trow * 512;                           // [512] in the (still unused) id lists
       *reinterpret_cast<uint4*>(hist + lane * 8) = make_uint4(0u, 0u, 0u, 0u);
       *reinterpret_cast<uint4*>(hist + lane * 8 + 4) = make_uint4(0u, 0u, 0u, 0u);
       wave_lds_sync();
@@ -1299,7 +1315,7 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       const unsigned long long edge = static_cast<unsigned long long>(lo) + (static_cast<unsigned long long>(bq) << shift) - 1ull;
       const uint32_t tv = mm ? static_cast<uint32_t>(min(edge, 0xFFFFFFFEull)) : 0xFFFFFFFEu;
       // the float with that key (key_of is monotone: distance <= tauf  <=>  key <= tv)
-      if (lane == 0) tauf[wave] = __uint_as_float((tv & 0x80000000u) ? (tv & 0x7FFFFFFFu) : ~tv);
+      if (lane == 0) tauf[trow] = __uint_as_float((tv & 0x80000000u) ? (tv & 0x7FFFFFFFu) : ~tv);
     }
     __syncthreads();
   }
@@ -1331,34 +1347,58 @@ __global__ __launch_bounds__(kFThreads, 4) void knn_filter_bf16_kernel(const Knn
       sj[t] = in[t] ? sqn[c] : 0.f;
     }
     // Append the candidates below the row's threshold.  The compare runs on the distance itself (tauf = the float
-    // whose key is tau: float order == key order) and a hit takes its list position from ONE LDS atomic of its own:
-    // no ballot / prefix arithmetic per (row, tile) -- the lists are unordered sets, the select ranks by (key, id).
-    // (25 -> ~9 vector instructions per row-tile pair; at K = 16 two percent of the pairs are hits and whole
-    // hit-blocks are skipped.)
+    // whose key is tau: float order == key order).  Round 5: ONE LDS atomic per (row, 64-candidate block) instead of one
+    // per hit -- the 16-lane group of a row counts its hits of the four tiles from four ballots, its first lane reserves
+    // the positions with a single ds_add_rtn (four different counters per instruction: no same-address serialisation,
+    // which cost 36 M bank-conflict cycles per launch at K = 432 where a quarter of the candidates are hits), the hits
+    // take base + their rank among the group's hits.  A block without a hit in any of the four rows of this register
+    // (K = 16: 98 % of the candidates miss) is skipped with one wave-uniform branch.  The lists are unordered sets, the
+    // select ranks by (key, id): the emitted ids do not depend on the order of the appends.
+    const int seg = lane & ~15;                                       // first lane of this lane's 16-lane group
+    const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
       const float tf = tauf[r];
       const float sr = sq[r];
       const int self = P.exclude_self ? i0 + r : -1;
+      float dist[4];
+      bool hit[4];
+      unsigned long long bal[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float dist = (sr + (-2.f * acc[t][reg])) + sj[t];
-        const int c = col0 + 16 * t + li;
-        if (in[t] && dist <= tf && c != self) {
-          const int pos = atomicAdd(&cnt[r], 1);
+        dist[t] = (sr + (-2.f * acc[t][reg])) + sj[t];
+        hit[t] = in[t] && dist[t] <= tf && (col0 + 16 * t + li) != self;
+        bal[t] = __ballot(hit[t]);
+      }
+      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;     // wave-uniform
+      int nseg[4], total = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        nseg[t] = __popcll((bal[t] >> seg) & 0xFFFFull);
+        total += nseg[t];
+      }
+      int base = 0;
+      if (li == 0 && total > 0) base = atomicAdd(&cnt[r], total);
+      base = __shfl(base, seg);
+      int before = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (hit[t]) {
+          const int pos = base + before + __popcll(bal[t] & segbelow);
           if (pos < kFCap) {
-            ckey[r * kFCap + pos] = key_of(dist);
-            cidx[r * kFCap + pos] = static_cast<uint32_t>(c);
+            ckey[r * kFCap + pos] = key_of(dist[t]);
+            cidx[r * kFCap + pos] = static_cast<uint32_t>(col0 + 16 * t + li);
           }
         }
+        before += nseg[t];
       }
     }
   }
   __syncthreads();
 
   // ---- per-row select on the candidate lists (as in knn_filter_kernel) ----
-  for (int rr = wave; rr < TM; rr += kFWaves) {
+  for (int rr = wave; rr < TM; rr += NW) {
     const int i = i0 + rr;
     if (i >= N) continue;  // wave-uniform
     const int c = cnt[rr];
@@ -1511,17 +1551,19 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
                            F.redo);
         F.planes = planes;
         const size_t blds = knn_filter_bf16_lds_bytes(bcap);
-#define DGCN_KNNB_LAUNCH(CAP, KCV)                                                                           \
+#define DGCN_KNNB_LAUNCH(CAP, KCV, NWV)                                                                      \
   do {                                                                                                        \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_bf16_kernel<CAP, KCV>),                  \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_bf16_kernel<CAP, KCV, NWV>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(blds));              \
     if (e != hipSuccess) return static_cast<int>(e);                                                          \
-    hipLaunchKernelGGL((knn_filter_bf16_kernel<CAP, KCV>), fgrid, dim3(kFThreads), blds, s, F);               \
+    hipLaunchKernelGGL((knn_filter_bf16_kernel<CAP, KCV, NWV>), fgrid, dim3(NWV * kWave), blds, s, F);        \
   } while (0)
+        // 512-entry lists (64 KB of LDS): 8-wave workgroups, two per CU, so that one's per-row select overlaps the
+        // other's matrix pass; 1024-entry lists (128 KB) leave room for one workgroup per CU anyway: 16 waves
         if (bcap == 512) {
-          if (kc == 1) DGCN_KNNB_LAUNCH(512, 1); else DGCN_KNNB_LAUNCH(512, 2);
+          if (kc == 1) DGCN_KNNB_LAUNCH(512, 1, kFbWaves); else DGCN_KNNB_LAUNCH(512, 2, kFbWaves);
         } else {
-          if (kc == 1) DGCN_KNNB_LAUNCH(1024, 1); else DGCN_KNNB_LAUNCH(1024, 2);
+          if (kc == 1) DGCN_KNNB_LAUNCH(1024, 1, 16); else DGCN_KNNB_LAUNCH(1024, 2, 16);
         }
 #undef DGCN_KNNB_LAUNCH
       } else {

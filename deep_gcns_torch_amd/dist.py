@@ -703,8 +703,11 @@ import threading
 # lookup is: this thread's innermost context, else the innermost context entered (and not yet left) by any thread of
 # the process.  Code that may run after the ``with`` block was left (loss.backward() outside it) captures the context
 # object and re-enters it: blocks.res_plus_layer does (``reentered``).
-_ACTIVE = threading.local()
-_ACTIVE_PROCESS = []            # contexts entered by any thread, innermost last
+# ONE partition per process at a time: a thread that enters a DIFFERENT context object while another thread holds one
+# is refused (a thread without a context of its own would otherwise inherit whichever was entered last); the same
+# object may be entered from several threads (``reentered`` on the autograd thread) and nested on one thread.
+_ACTIVE = threading.local()     # .ctx = this thread's innermost context, .stack = the ones it shadows
+_ACTIVE_PROCESS = []            # (context, entering thread id) of every live entry, innermost last
 _ACTIVE_LOCK = threading.Lock()
 
 
@@ -736,19 +739,25 @@ class partitioned:
         self.sync = BatchSync(part.bounds[-1], group)
 
     def __enter__(self):
-        if not hasattr(self, "_prevs"):
-            self._prevs = []
-        self._prevs.append(getattr(_ACTIVE, "ctx", None))
-        _ACTIVE.ctx = self
+        me = threading.get_ident()
         with _ACTIVE_LOCK:
-            _ACTIVE_PROCESS.append(self)
+            for other, tid in _ACTIVE_PROCESS:
+                if other is not self and tid != me:
+                    raise RuntimeError("dist.partitioned: another thread of this process is inside a different partition "
+                                       "context (one process drives one GPU and one partition at a time)")
+            _ACTIVE_PROCESS.append((self, me))
+        if not hasattr(_ACTIVE, "stack"):
+            _ACTIVE.stack = []                              # per THREAD (the context object may be shared by threads)
+        _ACTIVE.stack.append(getattr(_ACTIVE, "ctx", None))
+        _ACTIVE.ctx = self
         return self
 
     def __exit__(self, *exc):
-        _ACTIVE.ctx = self._prevs.pop()
+        me = threading.get_ident()
+        _ACTIVE.ctx = _ACTIVE.stack.pop()
         with _ACTIVE_LOCK:
-            for k in range(len(_ACTIVE_PROCESS) - 1, -1, -1):       # the innermost entry of THIS context
-                if _ACTIVE_PROCESS[k] is self:
+            for k in range(len(_ACTIVE_PROCESS) - 1, -1, -1):       # the innermost entry of THIS context by THIS thread
+                if _ACTIVE_PROCESS[k][0] is self and _ACTIVE_PROCESS[k][1] == me:
                     del _ACTIVE_PROCESS[k]
                     break
         return False
@@ -777,7 +786,7 @@ def active_partition():
     ctx = getattr(_ACTIVE, "ctx", None)
     if ctx is None and _ACTIVE_PROCESS:
         with _ACTIVE_LOCK:
-            ctx = _ACTIVE_PROCESS[-1] if _ACTIVE_PROCESS else None
+            ctx = _ACTIVE_PROCESS[-1][0] if _ACTIVE_PROCESS else None
     return ctx
 
 

@@ -194,6 +194,7 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
             if ctx.had_cuda_in_fwd:
                 ctx.fwd_gpu_devices, ctx.fwd_gpu_states = get_device_states(*inputs)
         ctx.input_requires_grad = [isinstance(t, torch.Tensor) and t.requires_grad for t in inputs]
+        ctx.options = ops.captured_options()       # the caller's ``ops.options`` block: the backward re-evaluates inside it
         # tensors every layer receives (edge embedding): count the layers whose backward will contribute
         module = getattr(fn, "__self__", None)
         ctx.fused = (hasattr(module, "fused_backward") and getattr(fn, "__name__", "") == "forward"
@@ -235,6 +236,11 @@ class InvertibleCheckpointFunction(torch.autograd.Function):
                                "times! Try raising `num_bwd_passes` by one.".format(ctx.num_bwd_passes))
         inputs = ctx.inputs.pop()
         outputs = ctx.outputs.pop()
+        with ctx.options:
+            return InvertibleCheckpointFunction._backward(ctx, inputs, outputs, grad_outputs)
+
+    @staticmethod
+    def _backward(ctx, inputs, outputs, grad_outputs):
         if ctx.fused:
             return (None,) * 6 + InvertibleCheckpointFunction._backward_fused(ctx, inputs, outputs, grad_outputs)
 

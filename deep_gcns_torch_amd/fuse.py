@@ -14,7 +14,9 @@ reference's classes from outside: ``fuse_model_class(cls)`` swaps ``cls.forward`
 route when the instance qualifies (device tensors, this package's GENConv / norm layers, the 'res+' block, ...) and calls
 the original ``forward`` otherwise.  ``install(fuse_models=True)`` applies it to every class named ``DeeperGCN`` /
 ``RevGCN`` of a module named ``model`` / ``model_rev`` as the example scripts import it (a ``sys.meta_path`` hook that
-post-processes the freshly executed module); ``fuse_model(instance)`` does it for one object.
+post-processes the freshly executed module; the hook is process-wide: ANY top-level module of that name that defines
+such a class is post-processed, ``install(fuse_models=False)`` removes it); ``fuse_model(instance)`` does it for one
+object.
 
 Checkpointing: the reference wraps the convolutions of deep softmax / power stacks in ``torch.utils.checkpoint``
 (ogbn_arxiv/model.py:38-40,98-100).  ``CHECKPOINT = "full"`` (default) keeps that memory behaviour to the letter -- the
@@ -145,7 +147,9 @@ def fuse_model_class(cls) -> bool:
     replacement exists for this class's ``forward`` signature."""
     if not (isinstance(cls, type) and issubclass(cls, torch.nn.Module)):
         raise TypeError("fuse_model_class expects an nn.Module subclass")
-    if _ORIG in cls.__dict__:
+    if _ORIG in cls.__dict__ or cls.forward in (_deepergcn_forward, _revgcn_forward):
+        # already fused -- itself, or through a fused base class whose replacement it inherits (wrapping that again would
+        # record the replacement as the "original" and the non-qualifying fall-back would call itself for ever)
         return True
     repl = _replacement_for(cls)
     if repl is None:
@@ -164,7 +168,7 @@ def unfuse_model_class(cls) -> None:
 def fuse_model(model: torch.nn.Module) -> torch.nn.Module:
     """Fuse ONE instance (its class is left alone): ``model = fuse_model(DeeperGCN(args))``."""
     cls = type(model)
-    if _ORIG in cls.__dict__:
+    if _ORIG in cls.__dict__ or cls.forward in (_deepergcn_forward, _revgcn_forward):
         return model
     repl = _replacement_for(cls)
     if repl is None:

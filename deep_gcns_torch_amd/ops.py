@@ -41,6 +41,56 @@ MAX_MASK_MIN_TABLE_BYTES = 128 << 20   # max backward through per-edge arg-max b
                                    # walk over gathered arg-max rows (arxiv shape with locality: 0.44 vs 0.53 ms)
 
 
+_OPTION_NAMES = ("SINGLE_GATHER_SOFTMAX_BWD", "ENC_STATIC_ITEMS", "FUSED_EDGE_GEMM", "ENC_MAX_WINNER_BWD",
+                 "EGEMM_MAX_WINNER_BWD", "MAX_MASK_MIN_TABLE_BYTES")
+
+
+class options:
+    """``with ops.options(enc_max_winner_bwd=True, ...):`` -- the switches above for the aggregation calls of THIS thread.
+
+    The module-level names are the process defaults (set them before the model runs).  A call reads its switches ONCE,
+    in its forward, on the calling thread -- the defaults overlaid by the innermost ``options`` block of that thread --
+    and its backward (which autograd runs on another thread, possibly while another replica's host thread is inside its
+    own block: nn.DataParallel) uses that snapshot, never the globals."""
+
+    def __init__(self, **kw):
+        self._kw = {}
+        for k, v in kw.items():
+            name = k.upper()
+            if name not in _OPTION_NAMES:
+                raise TypeError(f"unknown option {k!r} (known: {', '.join(n.lower() for n in _OPTION_NAMES)})")
+            self._kw[name] = v
+
+    def __enter__(self):
+        self._prev = getattr(_TLS, "options", None)
+        merged = dict(self._prev or {})
+        merged.update(self._kw)
+        _TLS.options = merged
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.options = self._prev
+        return False
+
+
+def captured_options() -> "options":
+    """The calling thread's overrides as a context object that can be re-entered later / on another thread (the
+    recomputation of a checkpointed or reversible layer runs inside the backward pass, on autograd's thread)."""
+    o = options()
+    o._kw = dict(getattr(_TLS, "options", None) or {})
+    return o
+
+
+def current_options() -> dict:
+    """Snapshot of the switches for a call made now on this thread."""
+    g = globals()
+    snap = {n: g[n] for n in _OPTION_NAMES}
+    over = getattr(_TLS, "options", None)
+    if over:
+        snap.update(over)
+    return snap
+
+
 def _scalar_arg(v):
     """(host float, device pointer or None) for a python float or a 1-element device tensor."""
     if isinstance(v, torch.Tensor):
@@ -162,6 +212,7 @@ class edge_grad_sink:
 
 
 _ZEROS = {}
+_DEBUG_AUX = None       # investigation only (tests/guard_alloc/bench_guarded.py): device counters of out-of-range arg-max ids
 
 
 def _zeros_cached(dev, n):
@@ -219,6 +270,8 @@ class _GenAggregate(torch.autograd.Function):
                 enc_feat = _feat_rows(enc_feat)
             else:
                 raise ValueError(f"fused edge encoder: unsupported shape F={n_feat}, C={C} (see encoder_fusable)")
+        opts = current_options()
+        ctx.opts = opts
         need_grad = track and (any(ctx.needs_input_grad[:4]) or any(ctx.needs_input_grad[14:17]))
         # (no_grad / inverse passes skip the saved aux)
         stash = _active_stash()
@@ -272,7 +325,7 @@ class _GenAggregate(torch.autograd.Function):
                 raise ValueError("add_root needs a square graph and non-learnable t / p")
             flags |= _lib.FLAG_ADD_ROOT
         range_flag = None
-        if want_aux and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and SINGLE_GATHER_SOFTMAX_BWD:
+        if want_aux and mode == _lib.AGGR_SOFTMAX and not learn_t and C % 4 == 0 and opts["SINGLE_GATHER_SOFTMAX_BWD"]:
             range_flag = torch.zeros(1, device=dev, dtype=torch.int32)   # set by the kernel if some |L| >= 80
         ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
@@ -292,7 +345,7 @@ class _GenAggregate(torch.autograd.Function):
             elif enc:
                 rc = lib.dgcn_gen_aggr_enc_fwd_f32(
                     graph.c_struct, x.data_ptr(), x.stride(0), enc_feat.data_ptr(), enc_w.data_ptr(), _lib.ptr(enc_b),
-                    ENC_FEATURES, C, mode, msg, flags | (_lib.FLAG_STATIC_ITEMS if ENC_STATIC_ITEMS else 0), t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
+                    ENC_FEATURES, C, mode, msg, flags | (_lib.FLAG_STATIC_ITEMS if opts["ENC_STATIC_ITEMS"] else 0), t_val, p_val, eps, _lib.ptr(t_param), _lib.ptr(p_param),
                     out.data_ptr(), _lib.ptr(aux1), _lib.ptr(aux2), _lib.ptr(range_flag), _lib.ptr(ws), ws_bytes,
                     _lib.current_stream_handle(dev))
             else:
@@ -303,6 +356,9 @@ class _GenAggregate(torch.autograd.Function):
                     _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
                    ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
+        if _DEBUG_AUX is not None and enc and mode == _lib.AGGR_MAX and aux1 is not None:
+            _DEBUG_AUX["fwd"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).sum()
+            _DEBUG_AUX["fwd_rows"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).any(1).sum()
         if record:
             stash.items.append((slot_key, (out, aux1, aux2, range_flag, z_save)))
         if need_grad:
@@ -322,6 +378,7 @@ class _GenAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
+        opts = ctx.opts                                   # the forward's snapshot (see ``options``)
         x, edge_attr, t_param, p_param, aux1, aux2, out = ctx.saved_tensors
         graph, mode = ctx.graph, ctx.mode
         dev = x.device
@@ -356,14 +413,14 @@ class _GenAggregate(torch.autograd.Function):
         egemm = ctx.egemm
         need_dz = egemm and any(ctx.needs_input_grad[14:17])
         # max over the fused edge GEMM: dz has one non-zero per (row, channel); the winners kernel needs no (E, C) array
-        winners = (egemm and mode == _lib.AGGR_MAX and EGEMM_MAX_WINNER_BWD and need_dz and C <= 128
+        winners = (egemm and mode == _lib.AGGR_MAX and opts["EGEMM_MAX_WINNER_BWD"] and need_dz and C <= 128
                    and ctx.enc[0].size(1) <= 256)
         if winners:
             need_dz = False
         enc = None if egemm else ctx.enc                  # narrow per-edge encoder: dW | db partials, no (E, C) array
         # ... under max the forward's arg-max ids (-1 = relu floor) are all the backward needs: grad_x from the plain
         # walk (no encoder recomputation per edge), dW' | db' from the winners
-        enc_winners = enc is not None and mode == _lib.AGGR_MAX and ENC_MAX_WINNER_BWD and ctx.msg == _lib.MSG_RELU_EPS
+        enc_winners = enc is not None and mode == _lib.AGGR_MAX and opts["ENC_MAX_WINNER_BWD"] and ctx.msg == _lib.MSG_RELU_EPS
         if enc_winners:
             enc_w_args, enc = enc, None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or need_dz or \
@@ -397,13 +454,13 @@ class _GenAggregate(torch.autograd.Function):
                     gpart = torch.empty(nparts, C, ENC_FEATURES + 1, device=dev, dtype=torch.float32)
                     rc = lib.dgcn_gen_aggr_enc_bwd_f32(
                         graph.c_struct, x.data_ptr(), x.stride(0), feat.data_ptr(), w_enc.data_ptr(), _lib.ptr(b_enc),
-                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags | (_lib.FLAG_STATIC_ITEMS if ENC_STATIC_ITEMS else 0),
+                        ENC_FEATURES, C, mode, ctx.msg, bwd_flags | (_lib.FLAG_STATIC_ITEMS if opts["ENC_STATIC_ITEMS"] else 0),
                         ctx.t_val, ctx.p_val, ctx.eps, _lib.ptr(t_param),
                         _lib.ptr(p_param), gcoef.data_ptr(), _lib.ptr(aux1), _lib.ptr(out), _lib.ptr(gshift),
                         _lib.ptr(kshift), _lib.ptr(shift_ok), g.data_ptr() if ctx.add_root else None,
                         grad_x.data_ptr(), gpart.data_ptr(), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
                 elif mode == _lib.AGGR_MAX and edge_attr is None and not egemm and not enc_winners and C <= 256 and \
-                        graph.n_dst * C * 4 >= MAX_MASK_MIN_TABLE_BYTES and graph.n_edges > 0:
+                        graph.n_dst * C * 4 >= opts["MAX_MASK_MIN_TABLE_BYTES"] and graph.n_edges > 0:
                     # arg-max bit masks per edge instead of gathered arg-max rows (big graphs: the table misses the caches)
                     mbytes = lib.dgcn_gen_aggr_max_mask_bytes(graph.n_edges, C)
                     mask = torch.empty(mbytes, device=dev, dtype=torch.uint8)
@@ -452,6 +509,8 @@ class _GenAggregate(torch.autograd.Function):
             if not ctx.needs_input_grad[0]:
                 grad_x = None
         if enc_winners and any(ctx.needs_input_grad[15:17]):
+            if _DEBUG_AUX is not None:
+                _DEBUG_AUX["bwd"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).sum()
             feat, w_enc, b_enc = enc_w_args
             gpart = torch.empty(lib.dgcn_enc_max_bwd_num_partials(graph.n_dst), C, ENC_FEATURES + 1, device=dev,
                                 dtype=torch.float32)
@@ -545,7 +604,7 @@ def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: Optional[t
     if narrow:
         return (F == ENC_FEATURES and C % 4 == 0 and C <= 256 and not edge_feat.requires_grad
                 and (weight is None or tuple(weight.shape) == (C, F)))
-    if weight is None or tuple(weight.shape) != (C, F) or not FUSED_EDGE_GEMM:
+    if weight is None or tuple(weight.shape) != (C, F) or not current_options()["FUSED_EDGE_GEMM"]:
         return False
     return bool(_lib.load().dgcn_gen_aggr_egemm_supported(F, C))
 

@@ -371,3 +371,45 @@ class ReluDecisions:
 
     def n_decisions(self):
         return sum(int(m.numel()) for m in self.masks)
+
+
+def float64_backward_along(decisions, ref_model, loss_of, oracle_propagate):
+    """Backward of ``loss_of(ref_model)`` on the host in float64 ALONG the recorded ReLU decisions of a device pass:
+    ``ref_model`` is a CPU float64 copy of the model (its plain layer loop), every ``F.relu`` / ``torch.relu`` site takes
+    the device's mask, the aggregation is ``oracle_propagate`` (whose own message ReLU is not a recorded site: on the
+    device it lives inside the kernel).  Gradients are left on ``ref_model``'s parameters; returns the loss."""
+    from gcn_lib.sparse import torch_message
+    saved = torch_message.GenMessagePassing.propagate
+
+    def propagate(self, *a, **k):
+        with decisions.suspended():
+            return oracle_propagate(self, *a, **k)
+    torch_message.GenMessagePassing.propagate = propagate
+    try:
+        with decisions.replaying():
+            loss = loss_of(ref_model)
+            loss.backward()
+    finally:
+        torch_message.GenMessagePassing.propagate = saved
+    return loss.detach()
+
+
+def gradient_errors(model, ref_model, zero_scale=1e-9):
+    """{parameter name: max |device gradient - float64 gradient| / max |float64 gradient|}; a parameter whose float64
+    gradient is zero to ``zero_scale`` (a bias in front of a training-mode BatchNorm) reports the device gradient's
+    magnitude relative to the model-wide gradient scale instead."""
+    ref = dict(ref_model.named_parameters())
+    wide = max(float(r.grad.abs().max()) for r in ref.values() if r.grad is not None)
+    out = {}
+    for k, a in model.named_parameters():
+        r = ref[k].grad
+        if r is None:
+            assert a.grad is None, k
+            continue
+        assert a.grad is not None, k
+        scale = float(r.abs().max())
+        if scale < zero_scale * max(wide, 1.0):
+            out[k] = float(a.grad.abs().max()) / max(wide, 1e-30)
+        else:
+            out[k] = float((a.grad.detach().cpu().double() - r).abs().max()) / scale
+    return out

@@ -107,7 +107,8 @@ def test_install_fuse_models_patches_the_real_model_files_on_import(dropin, tmp_
     import types
     import deep_gcns_torch_amd
     from deep_gcns_torch_amd import fuse
-    deep_gcns_torch_amd.install(reference_root=ref_models.REF, fuse_models=True)
+    deep_gcns_torch_amd.install(reference_root=ref_models.REF)          # fuse_models defaults to True (round 5)
+    assert fuse._FINDER in sys.meta_path
     if "torch_geometric" not in sys.modules:               # rev_layer.py's import block starts with torch_geometric
         tgnn = types.ModuleType("torch_geometric.nn")
         for n in ("GCNConv", "SAGEConv", "GATConv"):
@@ -131,6 +132,11 @@ def test_install_fuse_models_patches_the_real_model_files_on_import(dropin, tmp_
             cls = getattr(mod, clsname)
             assert mod.__file__.startswith(d)
             assert cls.forward is repl and callable(cls.__dict__[fuse._ORIG])
+            # a subclass without a forward of its own inherits the replacement; fusing it again must not record the
+            # replacement as its "original" (the fall-back would recurse for ever: ADVICE r4)
+            sub = type("Sub" + clsname, (cls,), {})
+            assert fuse.fuse_model_class(sub) and fuse._ORIG not in sub.__dict__
+            assert getattr(sub, fuse._ORIG) is cls.__dict__[fuse._ORIG]
             for name in (modname, "__init__"):
                 sys.modules.pop(name, None)
         # other model files (ogbn_proteins/model.py: forward(x, node_index, edge_index, edge_attr) of a DeeperGCN with
@@ -146,7 +152,8 @@ def test_install_fuse_models_patches_the_real_model_files_on_import(dropin, tmp_
                 sys.modules.pop(name, None)
         assert fuse._ORIG not in mod.DeeperGCN.__dict__
     finally:
-        fuse.disable_import_hook()
+        deep_gcns_torch_amd.install(reference_root=ref_models.REF, fuse_models=False)      # the opt-out removes the hook
+        assert fuse._FINDER not in sys.meta_path
     # the classes loaded by path (not through the hook) are fused explicitly; state_dict and CPU fallback
     with redirect_stdout(io.StringIO()):
         m = ref_models.arxiv_deepergcn(3)

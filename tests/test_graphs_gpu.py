@@ -108,3 +108,56 @@ def test_graphed_forward_backward_with_the_dynamic_item_schedule():
             r = ref_grads[k]
             torch.testing.assert_close(p.grad, r, rtol=1e-4, atol=1e-6 * max(float(r.abs().max()), 1e-3),
                                        msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_replayed_back_to_back_encoder_aggregations_lose_no_work_item():
+    """Round-5 regression.  Consecutive per-edge-encoder aggregations of one captured step get the SAME workspace block
+    from torch's allocator, i.e. the same work-item counters.  While the library re-armed them with hipMemsetAsync, a
+    replayed graph ran that memset node before the last waves of the previous launch had made their final claim: the
+    counters then started at 1, the first item of a few queues -- rows 0 .. 2 of the ogbn-proteins cluster graph -- was
+    never processed and its output / arg-max ids were whatever the block held before (bench.py: ~10 % of the replayed
+    launches; an illegal address once the ids were used as addresses by the max backward).  Here: 24
+    back-to-back launches (max: output and gradients both depend on the ids) in one graph, 30 replays, every output and
+    every input gradient bit-equal to the eager pass; the buffers are poisoned between replays."""
+    from deep_gcns_torch_amd import ops
+    assert not ops.ENC_STATIC_ITEMS
+    dev = torch.device("cuda:0")
+    s = synth.SHAPES["proteins_cluster"]
+    ei = synth.powerlaw_graph(s["n"], s["n_undirected"], s["seed"], device=dev)
+    n, E, C, L = s["n"], ei.size(1), 112, 24
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, C, device=dev, generator=gen).requires_grad_(True)
+    feat = torch.rand(E, 8, device=dev, generator=gen)
+    W = (torch.randn(L, C, 8, device=dev, generator=gen) / 3).requires_grad_(True)
+    b = torch.randn(L, C, device=dev, generator=gen).requires_grad_(True)
+    probe = torch.randn(n, C, device=dev, generator=gen)
+    outs = torch.empty(L, n, C, device=dev)
+    gxs = torch.empty(L, n, C, device=dev)
+
+    def run():
+        for i in range(L):
+            out = ops.gen_aggregate(x, ei, feat, aggr="max", edge_encoder=(W[i], b[i]))
+            gx, = torch.autograd.grad(out, x, probe)
+            outs[i].copy_(out.detach())
+            gxs[i].copy_(gx)
+
+    with ops.options(enc_max_winner_bwd=True):
+        run()
+        torch.cuda.synchronize()
+        ref_o, ref_g = outs.clone(), gxs.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+    for rep in range(30):
+        outs.fill_(float("nan"))
+        gxs.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outs, ref_o), f"replay {rep}: outputs differ from the eager pass"
+        assert torch.equal(gxs, ref_g), f"replay {rep}: input gradients differ from the eager pass"
