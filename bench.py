@@ -102,6 +102,119 @@ def cpu_baseline(shape_name: str, channels: int, t: float, budget_s: float = 30.
                 thread_sweep_edges_per_s={str(k): v for k, v in sweep.items()})
 
 
+def cpu_baseline_range(graph, x_dev, channels, t, aggr, shape_name, frac=64, counts=(8, 32)):
+    """The oracle on the HEADLINE workload itself, restricted to a contiguous range of destination rows (SURVEY.md 8(d):
+    "chunk by destination range"; aggregation rows are independent, so a range of the products graph is the same per-edge
+    work as the whole graph -- gathers from all 2.4 M source rows included): rows [n/3, n/3 + n/frac) of the graph the GPU
+    just timed, forward + backward, one repetition per thread count after a warm-up, the best reported."""
+    from oracle import sparse_ref  # baseline leg only
+    ncores = os.cpu_count() or 1
+    n = graph.n_dst
+    lo = n // 3
+    hi = lo + max(n // frac, 1)
+    rp = graph.rowptr[lo:hi + 1].long().cpu()
+    e0, e1 = int(rp[0]), int(rp[-1])
+    src = graph.col[e0:e1].long().cpu()
+    dst = torch.repeat_interleave(torch.arange(hi - lo), rp[1:] - rp[:-1])
+    ei_r = torch.stack([src, dst])
+    x = x_dev.detach().cpu().requires_grad_(True)
+    go = torch.randn(hi - lo, channels, generator=torch.Generator().manual_seed(0))
+    E_r = e1 - e0
+
+    def step():
+        out = sparse_ref.gen_propagate(x, ei_r, aggr=aggr, t=t, dim_size=hi - lo)
+        torch.autograd.grad(out, x, go)
+    sweep = {}
+    for th in sorted({min(c or ncores, ncores) for c in counts}):
+        torch.set_num_threads(th)
+        step()                                   # warm-up at this thread count
+        t0 = time.perf_counter()
+        step()
+        sweep[th] = E_r / (time.perf_counter() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(ncores)
+    return dict(value=sweep[best], unit="edges/s", cores=best, kind="port",
+                sample=f"the headline workload itself ('{shape_name}' graph, C={channels}, {aggr} t={t}, fwd+bwd) restricted to "
+                       f"destination rows [{lo}, {hi}) = 1/{frac} of the rows: {E_r} edges whose sources are anywhere in the "
+                       f"{n} rows (oracle/sparse_ref.py on torch CPU ops; rows are independent, SURVEY.md 8(d) 'chunk by "
+                       f"destination range'); 1 rep per thread count after a warm-up, thread sweep "
+                       f"{ {k: round(v) for k, v in sweep.items()} } edges/s on a {ncores}-thread host",
+                thread_sweep_edges_per_s={str(k): v for k, v in sweep.items()})
+
+
+def emulate_ranks(args, dev, ei, n, C, worlds, t1_ms):
+    """Multi-GPU evidence that needs ONE GPU: for W in ``worlds`` the W-rank partition of the headline
+    graph is built exactly as ``bench.py --gpus W`` builds it and every rank's LOCAL forward + backward is run here, one
+    rank after the other, with HIP events -- the compute half of the scaling curve and the partition's load balance are
+    measured, the exchange half is priced from the bytes each rank receives at 40 / 60 / 77 GB/s per xGMI link.  No
+    collective runs; nothing here is a scaling measurement."""
+    from deep_gcns_torch_amd import dist as ddist, ops
+    out = {"t1_ms_per_step": t1_ms, "workload": f"GENConv {args.aggr} t={args.t} fwd+bwd, {args.shape} {args.graph} graph, "
+                                                  f"N={n} E={ei.size(1)} C={C}", "worlds": {}}
+
+    def time_local(graph, x_in, g_out, reps=3):
+        def step():
+            o = ops.gen_aggregate(x_in, graph, aggr=args.aggr, t=args.t)
+            torch.autograd.grad(o, x_in, g_out)
+        step()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            step()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps
+
+    gen = torch.Generator(device=dev).manual_seed(7)
+    for W in worlds:
+        entry = {}
+        for scheme in ("allgather", "transposed"):
+            wn = 1
+            if scheme == "transposed":
+                wn = ddist.default_node_groups(C, W)
+                if not ddist.transposed_supported(C, W, None, wn):
+                    continue
+            wc = W // wn
+            ms, edges, rows = [], [], []
+            recv = None
+            for r in range(W):
+                if scheme == "allgather":
+                    part = ddist.PartitionedGraph.from_edge_index(ei, n, r, W)
+                    x_in = torch.randn(part.graph.n_src, C, device=dev, generator=gen).requires_grad_(True)
+                    g_out = torch.randn(part.graph.n_dst, C, device=dev, generator=gen)
+                    edges.append(part.n_local_edges)
+                    # all-gather forward / reduce-scatter backward: (W - 1) / W of the padded (N, C) rows per direction
+                    recv = (W - 1) * part.max_rows * C * 4
+                else:
+                    part = ddist.TransposedGraph.from_edge_index(ei, n, r, W, node_groups=wn)
+                    cw = C // wc
+                    x_in = torch.randn(part.graph.n_src, cw, device=dev, generator=gen).requires_grad_(True)
+                    g_out = torch.randn(part.graph.n_dst, cw, device=dev, generator=gen)
+                    edges.append(part.n_edges)
+                    # rows -> channel block (input replicated to the node groups) + group-local exchange of the output
+                    recv = (W - 1) * part.max_rows * cw * 4 + (wc - 1) * part.max_rows * cw * 4
+                rows.append(part.n_local)
+                ms.append(time_local(part.graph, x_in, g_out))
+                del part, x_in, g_out
+                torch.cuda.empty_cache()
+            links = min(W - 1, 7)
+            proj = {}
+            for bw in (40, 60, 77):
+                t_x = 2 * recv / (links * bw * 1e9) * 1e3          # both directions of one step, ms
+                proj[f"{bw}GBs_per_link"] = dict(exchange_ms=t_x, speedup_no_overlap=t1_ms / (max(ms) + t_x),
+                                                 speedup_full_overlap=t1_ms / max(max(ms), t_x))
+            entry[f"{scheme}/node_groups={wn}"] = dict(
+                local_fwd_bwd_ms_per_rank=ms, local_ms_max=max(ms), local_ms_mean=sum(ms) / len(ms),
+                imbalance_max_over_mean=max(ms) / (sum(ms) / len(ms)), edges_per_rank=edges, rows_per_rank=rows,
+                bytes_received_per_rank_per_direction=recv, links_used=links, compute_only_speedup=t1_ms / max(ms),
+                projection=proj)
+        out["worlds"][str(W)] = entry
+    out["note"] = ("every rank's local kernels run one after the other on ONE GPU; exchange times are bytes / (links x "
+                   "assumed per-link rate), not measurements; no multi-GPU run has been made on this pool")
+    return out
+
+
 def gpu_timed(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -611,10 +724,14 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="profiling aid: skip the backward")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the RCCL multi-rank path even with one rank (sanity check)")
-    ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather", "halo"],
+    ap.add_argument("--scheme", default="auto", choices=["auto", "transposed", "allgather", "halo", "split"],
                     help="multi-rank exchange: channel-transposed all-to-all or destination-partitioned all-gather")
     ap.add_argument("--pipeline-chunks", type=int, default=0, help="0 = library default")
     ap.add_argument("--node-groups", type=int, default=0, help="transposed scheme: node groups (0 = library default)")
+    ap.add_argument("--emulate-ranks", default="", help="comma list of world sizes, e.g. 2,4,8: after the single-GPU "
+                    "timing, build every rank's partition of the same graph and time its LOCAL fwd+bwd on this one GPU "
+                    "(emulate_ranks: compute half of the scaling curve + load balance + priced exchange); prints its own "
+                    "JSON object instead of the driver line")
     ap.add_argument("--rehearsal", action="store_true",
                     help="CPU dress rehearsal of the N-rank job (no GPU, no timing claim): gloo instead of RCCL, CPU "
                          "tensors, the oracle as the rank-local aggregation, the graph scaled down by --scale-div -- the "
@@ -709,7 +826,8 @@ def main():
         graph = Graph.from_edge_index(ei, n)       # again: what every further graph of the process costs
         torch.cuda.synchronize(dev)
         graph_build_ms = (time.perf_counter() - tb) * 1e3
-        del ei
+        if not args.emulate_ranks:
+            del ei
         x = x_full.requires_grad_(True)
 
         def fwd():
@@ -751,6 +869,8 @@ def main():
             # the exchange is bound by the xGMI links and RCCL's per-collective efficiency: try the applicable schemes
             # for a few untimed steps and keep the fastest (same choice on every rank: max-over-ranks timings)
             cands = [("allgather", 1), ("halo", 1)]
+            if not rehearsal and args.aggr in ("softmax", "softmax_sg"):
+                cands.append(("split", 1))        # local-source edges aggregated while the all-gather is in flight
             if world > 1 or args.force_partitioned or rehearsal:
                 if ddist.transposed_supported(C, world, None, 1):
                     cands.append(("transposed", 1))
@@ -867,6 +987,14 @@ def main():
         except Exception as exc:   # noqa: BLE001 -- reported, never hidden
             phase_ms = {"error": repr(exc)[:200]}
 
+    if args.emulate_ranks and not partitioned:
+        ms_per_step = elapsed / args.steps * 1e3
+        del graph, x, x_full
+        gc.collect()
+        torch.cuda.empty_cache()
+        res = emulate_ranks(args, dev, ei, n, C, [int(w) for w in args.emulate_ranks.split(",")], ms_per_step)
+        print(json.dumps(res), flush=True)
+        return
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         saved = 1 if args.aggr.split("_")[0] in ("softmax", "power", "max") else 0
@@ -916,7 +1044,9 @@ def main():
                                  f"aggregates {part.n_edges} edges for {C // part.channel_groups} channels)" if transposed else
                                  (f"destination-partitioned x{world}, halo rows only (RCCL all-to-all, {part.n_halo} halo rows "
                                   f"on rank 0)" if isinstance(part, ddist.HaloGraph) else
-                                  f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd"))),
+                                  (f"destination-partitioned x{world}, local-first: local-source edges aggregated while the "
+                                   f"RCCL all-gather is in flight, softmax states merged" if isinstance(part, ddist.SplitGraph)
+                                   else f"destination-partitioned x{world}, RCCL all-gather fwd / reduce-scatter bwd")))),
             },
             "roofline": {
                 "kernel": "gen_aggr_fwd_kernel<SOFTMAX> (dgcn_gen_aggr_fwd_f32)"
@@ -958,8 +1088,12 @@ def main():
         if world > 1:
             res["config"]["note"] = "no multi-GPU curve had been measured when this was written (1-GPU gpurun boxes only)"
         if world == 1 and not partitioned and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.shape, C, args.t,
-                                               counts=(8, 32, 64, 0) if args.extras == "full" else (8, 32))
+            # the headline workload itself on the host cores, restricted to a destination range (round 5; rounds 2 - 4
+            # timed the arxiv-shaped graph instead: kept under --extras full as cpu_baseline_arxiv_shape)
+            res["cpu_baseline"] = cpu_baseline_range(graph, x_full, C, args.t, args.aggr, args.shape,
+                                                     counts=(8, 32, 64, 0) if args.extras == "full" else (8, 32))
+            if args.extras == "full":
+                res["cpu_baseline_arxiv_shape"] = cpu_baseline(args.shape, C, args.t, counts=(8, 32, 64, 0))
         if world == 1 and not partitioned and not args.no_extras and args.extras != "none" and args.shape == "products":
             del x, x_full, g_full, graph
             gc.collect()

@@ -88,13 +88,12 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // Zero-fill of counters the next kernel of the same call claims work from / accumulates into -- as a KERNEL, never
-// hipMemsetAsync.  Round 5 finding: in a replayed hipGraph (ROCm 7.2, MI355X) a memset NODE is not held back until the
-// kernel node in front of it has drained; the next call's reset of the work-item counters (same address: torch hands
-// the same workspace block to consecutive layers) landed while the last waves of the previous launch were still making
-// their final claims, the counters started the next launch at 1 instead of 0 and the first item of a few queues --
-// rows 0 .. 2 of the ogbn-proteins cluster -- was never processed: stale arg-max ids, wrong outputs in ~10 % of the
-// replayed launches (and an illegal address once the ids were used as addresses: DESIGN.md 4.13).  A kernel node is
-// ordered after the kernel in front of it like any other launch.
+// hipMemsetAsync.  Round 5 finding: with hipMemsetAsync (a memset NODE in a captured graph) ~10 % of the
+// REPLAYED launches of the per-edge encoder kernels found the work-item counters of a few queues non-zero at their first
+// claims (ROCm 7.2, MI355X; consecutive layers get the same workspace block, i.e. the same counters): item 0 of those
+// queues -- rows 0 .. 2 of the ogbn-proteins cluster -- was never processed, its arg-max ids were whatever the block held
+// before, and the max backward that uses the ids as addresses faulted.  8,026 stale ids per bench run with the memset
+// node, 0 with this kernel; eager launches were never affected.
 static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, size_t n_words) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_words; i += stride) p[i] = 0u;

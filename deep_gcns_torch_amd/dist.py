@@ -590,8 +590,138 @@ def halo_gen_aggregate(x_local: torch.Tensor, hg: HaloGraph, aggr: str = "softma
     return local_aggregate(x_ext, hg.graph, aggr=aggr, **kw)
 
 
+# ------------------------------------------------------------------------------------------------
+# local-first scheme ("split the local CSR into {sources owned locally} U {halo sources}; launch the local
+# part while the all-gather is in flight")
+# ------------------------------------------------------------------------------------------------
+class SplitGraph:
+    """Destination partition whose edges are cut by the OWNER OF THE SOURCE: ``local`` (sources among this rank's own
+    rows: n_src = n_local) and ``remote`` (sources on other ranks, ids in the padded all-gather layout).  The softmax
+    aggregation of a row over the union merges exactly from the two partial results and their log-sum-exps, so the
+    local kernel runs while the remote rows travel, and in the backward the remote gradient's reduce-scatter is in
+    flight while the local gradient kernel runs."""
+
+    def __init__(self, local: Graph, remote: Graph, bounds, rank, world, max_rows, n_local_edges):
+        self.local, self.remote = local, remote
+        self.graph = remote               # (phase_times / bench read .graph)
+        self.bounds = bounds
+        self.rank, self.world = rank, world
+        self.lo, self.hi = bounds[rank], bounds[rank + 1]
+        self.max_rows = max_rows
+        self.n_local_edges = n_local_edges
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+    @classmethod
+    def from_edge_index(cls, edge_index, num_nodes, rank, world, bounds=None, need_transpose=True) -> "SplitGraph":
+        src, dst = edge_index[0], edge_index[1]
+        if bounds is None:
+            bounds = balanced_bounds(torch.bincount(dst, minlength=num_nodes), world)
+        assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == num_nodes
+        max_rows = max(bounds[r + 1] - bounds[r] for r in range(world))
+        max_rows = (max_rows + 3) // 4 * 4
+        lo, hi = bounds[rank], bounds[rank + 1]
+        mine = (dst >= lo) & (dst < hi)
+        lsrc, ldst = src[mine], dst[mine] - lo
+        own = (lsrc >= lo) & (lsrc < hi)
+        g_loc = Graph(lsrc[own] - lo, ldst[own], n_src=hi - lo, n_dst=hi - lo, need_transpose=need_transpose)
+        b = torch.tensor(bounds, device=src.device, dtype=src.dtype)
+        rs = lsrc[~own]
+        owner = torch.bucketize(rs, b[1:], right=True)
+        g_rem = Graph(owner * max_rows + (rs - b[owner]), ldst[~own], n_src=world * max_rows, n_dst=hi - lo,
+                      need_transpose=need_transpose)
+        return cls(g_loc, g_rem, list(bounds), rank, world, max_rows, int(mine.sum()))
+
+
+def _hip_state_fns():
+    from . import ops
+    return ops.softmax_state_forward, ops.softmax_state_backward
+
+
+def merge_softmax_states(oa, la, has_a, ob, lb, has_b):
+    """(out, L) of the union of two disjoint edge sets from their partial (out, L); ``has_*``: (n, 1) bool, the row has
+    edges in that set (L is 0, not -inf, for a row without edges)."""
+    both = has_a & has_b
+    wa = torch.where(both, torch.sigmoid(la - lb), has_a.to(oa.dtype).expand_as(oa))
+    wb = torch.where(both, 1.0 - wa, has_b.to(oa.dtype).expand_as(oa))
+    out = wa * oa + wb * ob
+    L = torch.where(both, torch.logaddexp(la, lb), torch.where(has_a, la, lb))
+    return out, L
+
+
+class _SplitSoftmaxAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, sg, group, t, state_fwd, state_bwd):
+        world = dist.get_world_size(group)
+        n_local, C = x_local.shape
+        mr = sg.max_rows
+        send = x_local.new_zeros(mr, C)
+        send[:n_local] = x_local.detach()
+        full = x_local.new_empty(world * mr, C)
+        tensor_coll = _supports_tensor_collectives(group)
+        if tensor_coll:
+            work = dist.all_gather_into_tensor(full, send, group=group, async_op=True)
+        else:
+            work = dist.all_gather(list(full.view(world, mr, C).unbind(0)), send, group=group, async_op=True)
+        xl = x_local.detach().contiguous()
+        oa, la = state_fwd(xl, sg.local, t)              # runs while the remote rows are in flight
+        work.wait()
+        ob, lb = state_fwd(full, sg.remote, t)
+        has_a = (sg.local.deg > 0).unsqueeze(1)
+        has_b = (sg.remote.deg > 0).unsqueeze(1)
+        out, L = merge_softmax_states(oa, la, has_a, ob, lb, has_b)
+        ctx.sg, ctx.group, ctx.t, ctx.state_bwd, ctx.tensor_coll = sg, group, t, state_bwd, tensor_coll
+        ctx.save_for_backward(xl, full, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, full, L = ctx.saved_tensors
+        sg, group = ctx.sg, ctx.group
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        mr, C = sg.max_rows, xl.size(1)
+        g = g.contiguous()
+        g_full = ctx.state_bwd(full, sg.remote, g, L, ctx.t).contiguous()      # gradient of the remote rows first ...
+        if ctx.tensor_coll:
+            back = g_full.new_empty(mr, C)
+            work = dist.reduce_scatter_tensor(back, g_full, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            tmp = g_full.clone()
+            work = dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            back = None
+        g_loc = ctx.state_bwd(xl, sg.local, g, L, ctx.t)                        # ... its reduce-scatter flies during this
+        work.wait()
+        if back is None:
+            back = tmp.view(world, mr, C)[rank]
+        return g_loc + back[:xl.size(0)], None, None, None, None, None
+
+
+def split_supported(aggr: str, kw: dict) -> bool:
+    return (aggr in ("softmax", "softmax_sg") and not kw.get("learn_t") and kw.get("edge_attr") is None
+            and kw.get("edge_encoder") is None and not isinstance(kw.get("t", 1.0), torch.Tensor))
+
+
+def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "softmax", group=None, state_fns=None,
+                        **kw) -> torch.Tensor:
+    """Local-first aggregation of this rank's destination rows (``SplitGraph``).  softmax / softmax_sg with a fixed
+    temperature (BASELINE config 4); ``state_fns = (forward, backward)`` defaults to the HIP entry points
+    (``ops.softmax_state_forward`` / ``_backward``), the gloo tests inject torch restatements."""
+    if not split_supported(aggr, kw):
+        raise NotImplementedError("the local-first scheme covers softmax / softmax_sg with a fixed temperature; use the "
+                                  "allgather scheme for the other aggregators")
+    fwd, bwd = state_fns or _hip_state_fns()
+    return _SplitSoftmaxAggregate.apply(x_local, sg, group, float(kw.get("t", 1.0)), fwd, bwd)
+
+
 def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **kw) -> torch.Tensor:
     """Scheme-agnostic entry: ``part`` is a PartitionedGraph (all-gather scheme) or a TransposedGraph."""
+    if isinstance(part, SplitGraph):
+        kw.pop("pipeline_chunks", None)
+        kw.pop("local_aggregate", None)
+        return split_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
     if isinstance(part, TransposedGraph):
         return transposed_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
     if isinstance(part, HaloGraph):
@@ -618,6 +748,8 @@ def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, ran
         return PartitionedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
     if scheme == "halo":
         return HaloGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
+    if scheme == "split":
+        return SplitGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose)
     raise ValueError(f"unknown scheme {scheme!r}")
 
 

@@ -28,10 +28,12 @@ ENC_STATIC_ITEMS = False           # per-edge encoder kernels: True = work items
                                    # bit-reproducible dW | db at 1.3 - 1.6x the launch time; default = items claimed from
                                    # device-side counters (outputs and grad_x identical, dW | db equal to rounding)
 FUSED_EDGE_GEMM = True             # wide edge features (Linear(hidden -> C) per layer): GEMM + aggregation in one kernel
-ENC_MAX_WINNER_BWD = False         # per-edge encoder under max: dW' | db' from the (row, channel) arg-max winners (n_dst * C gathers
-                                   # of 32 bytes) + the plain CSC walk for grad_x, instead of the per-edge encoder walk.  OFF by
-                                   # default: 0.296 -> 0.254 ms per layer and 11.06 -> 10.57 ms per RevGCN-8 hipGraph step, but a
-                                   # graph captured after eager steps of the same process faulted in replay
+ENC_MAX_WINNER_BWD = True          # per-edge encoder under max: dW' | db' from the (row, channel) arg-max winners (n_dst * C gathers
+                                   # of 32 bytes) + the plain CSC walk for grad_x, instead of the per-edge encoder walk: 0.296 ->
+                                   # 0.254 ms per layer.  Round 4 shipped it OFF: a replayed hipGraph faulted with it.  Root cause
+                                   # (round 5): the work-item counters were re-armed by a memset NODE that a replay
+                                   # ran before the previous launch had drained -- items 0 .. 2 were lost, their arg-max ids stale,
+                                   # and this route used them as addresses.  Counters are now zeroed by a kernel, ids range-checked
 EGEMM_MAX_WINNER_BWD = True        # its backward under max: walk the (row, channel) winners (csrc/egemm_max_bwd.hip) instead of
                                    # writing dz (E, C) and running dz @ W, dz^T F over it; False = that dense route (A/B)
                                    # (csrc/gen_aggr_egemm.hip); False = stock GEMM + (E, C) embedding (A/B benchmarks)
@@ -585,6 +587,54 @@ def gen_aggregate(x: torch.Tensor, edge_index: Union[torch.Tensor, Graph],
                                    learn_p, torch.is_grad_enabled(), bool(add_root), edge_attr, w_enc, b_enc)
     return _GenAggregate.apply(x, edge_attr, t_param, p_param, graph, mode, msg, float(eps),
                                t_val, p_val, learn_t, learn_p, torch.is_grad_enabled(), bool(add_root))
+
+
+def softmax_state_forward(x: torch.Tensor, graph: Graph, t: float = 1.0, relu_eps: bool = True, eps: float = 1e-7):
+    """``(out, L)`` of the softmax aggregation over ``graph`` (no autograd): ``L[i, c]`` = log sum_e exp(t m_e) over the
+    row's edges (0 for a row without edges, whose ``out`` is 0).  Two partial aggregations over disjoint edge sets of the
+    same destination rows merge exactly from these two arrays (``dist.SplitGraph``: the local-source edges are aggregated
+    while the remote rows are still in flight)."""
+    lib = _lib.load()
+    dev = _lib.require_device(x)
+    x = _rows_f32(x)
+    C = x.size(1)
+    if x.size(0) != graph.n_src:
+        raise ValueError(f"x has {x.size(0)} rows, graph expects {graph.n_src}")
+    out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+    L = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+    ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+    msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_gen_aggr_fwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_SOFTMAX, msg, 0,
+                                       float(t), 1.0, float(eps), None, None, out.data_ptr(), L.data_ptr(), None, None,
+                                       _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_gen_aggr_fwd_f32")
+    return out, L
+
+
+def softmax_state_backward(x: torch.Tensor, graph: Graph, g: torch.Tensor, L: torch.Tensor, t: float = 1.0,
+                           relu_eps: bool = True, eps: float = 1e-7) -> torch.Tensor:
+    """grad_x (graph.n_src, C) of  sum_i g_i . sum_e w_e m_e  with the weights w_e = exp(t m_e - L_i) held constant
+    (softmax_sg / softmax without learnable t, gcn_lib/sparse/torch_message.py:54-58) for a GIVEN log-sum-exp array --
+    the merged one of a split aggregation."""
+    lib = _lib.load()
+    dev = _lib.require_device(x, g, L)
+    x = _rows_f32(x)
+    C = x.size(1)
+    g = g.float().contiguous()
+    L = L.float().contiguous()
+    grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
+    ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+    msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_gen_aggr_bwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_SOFTMAX, msg, 0,
+                                       float(t), 1.0, float(eps), None, None, g.data_ptr(), L.data_ptr(), None, None,
+                                       None, None, None, grad_x.data_ptr(), None, _lib.ptr(ws), ws_bytes,
+                                       _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
+    return grad_x
 
 
 def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: Optional[torch.Tensor], narrow: bool = False) -> bool:

@@ -394,10 +394,11 @@ def float64_backward_along(decisions, ref_model, loss_of, oracle_propagate):
     return loss.detach()
 
 
-def gradient_errors(model, ref_model, zero_scale=1e-9):
-    """{parameter name: max |device gradient - float64 gradient| / max |float64 gradient|}; a parameter whose float64
-    gradient is zero to ``zero_scale`` (a bias in front of a training-mode BatchNorm) reports the device gradient's
-    magnitude relative to the model-wide gradient scale instead."""
+def gradient_errors(model, ref_model, small=1e-2):
+    """{parameter name: max |device gradient - float64 gradient| / scale}, scale = max |float64 gradient| of that
+    parameter, but not less than ``small`` x the largest gradient entry of the whole model: a parameter whose true
+    gradient is (nearly) zero -- a bias in front of a training-mode BatchNorm, a norm bias whose per-row terms cancel --
+    receives fp32 rounding noise of the size of the OTHER gradients' resolution, and is measured against that."""
     ref = dict(ref_model.named_parameters())
     wide = max(float(r.grad.abs().max()) for r in ref.values() if r.grad is not None)
     out = {}
@@ -407,9 +408,6 @@ def gradient_errors(model, ref_model, zero_scale=1e-9):
             assert a.grad is None, k
             continue
         assert a.grad is not None, k
-        scale = float(r.abs().max())
-        if scale < zero_scale * max(wide, 1.0):
-            out[k] = float(a.grad.abs().max()) / max(wide, 1e-30)
-        else:
-            out[k] = float((a.grad.detach().cpu().double() - r).abs().max()) / scale
+        scale = max(float(r.abs().max()), small * wide, 1e-300)
+        out[k] = float((a.grad.detach().cpu().double() - r).abs().max()) / scale
     return out

@@ -173,9 +173,10 @@ def test_resgcn28_full_depth_forward():
     err = _rel_l2(out.cpu(), ref)
     # 28 stacked blocks, each re-normalised by a train-mode BatchNorm over 8192 x 16 edge activations: fp32 rounding
     # differences between the two conv formulations accumulate to a few 1e-4 of the logits' norm (measured 2.3e-4)
-    assert err < 5e-4, f"ResGCN-28 logits, relative L2 error {err:.3e}"
+    from conftest import gate
+    gate("resgcn28 full depth: logits vs the oracle's, relative L2", err, 5e-4)
     bad = ((out.cpu() - ref).abs() > 1e-3 * ref.abs() + 1e-3 * float(ref.abs().max())).float().mean().item()
-    assert bad < 1e-3, f"{bad:.2e} of the logits off by more than 1e-3"
+    gate("resgcn28 full depth: fraction of logits further than 1e-3 (|ref| + max |ref|) from the oracle's", bad, 1e-3)
 
     # --- (i) the HIP kNN of a block is exact on the block's own (GPU) input ---------------------------------------
     # Block features are arbitrary fp32 numbers, so two candidates closer than fp32 rounding may be ranked either

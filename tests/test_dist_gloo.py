@@ -386,3 +386,92 @@ def test_halo_exchange_matches_single_process(world, aggr, kw):
     # the halo is a fraction of the remote rows, and what is sent equals what is received overall
     assert all(r[4] < 0.6 * (n - r[5]) for r in res)
     assert sum(r[4] for r in res) == sum(r[6] for r in res)
+
+
+# ---- the local-first scheme (dist.SplitGraph) ---------------------------------------------------------
+def _state_fwd_torch(x, graph, t):
+    """(out, L) of the softmax aggregation over ``graph`` in plain torch (what ops.softmax_state_forward returns)."""
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+    src = graph.col.long()
+    C = x.size(1)
+    m = torch.relu(x[src]) + 1e-7
+    s = t * m
+    mx = torch.full((graph.n_dst, C), float("-inf"), dtype=x.dtype).scatter_reduce(0, dst.unsqueeze(1).expand_as(s), s,
+                                                                                    "amax", include_self=True)
+    mx0 = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    e = torch.exp(s - mx0[dst])
+    den = torch.zeros(graph.n_dst, C, dtype=x.dtype).index_add_(0, dst, e)
+    num = torch.zeros(graph.n_dst, C, dtype=x.dtype).index_add_(0, dst, e * m)
+    has = (deg > 0).unsqueeze(1)
+    out = torch.where(has, num / den.clamp_min(1e-300), torch.zeros_like(num))
+    L = torch.where(has, mx0 + torch.log(den.clamp_min(1e-300)), torch.zeros_like(num))
+    return out, L
+
+
+def _state_bwd_torch(x, graph, g, L, t):
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+    src = graph.col.long()
+    z = x[src]
+    m = torch.relu(z) + 1e-7
+    w = torch.exp(t * m - L[dst])
+    dz = w * g[dst] * (z > 0).to(x.dtype)
+    return torch.zeros(graph.n_src, x.size(1), dtype=x.dtype).index_add_(0, src, dz)
+
+
+def _split_worker(rank, world, port, t, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_gcns_torch_amd.dist import SplitGraph, build_partition, aggregate
+        torch.set_num_threads(2)
+        n, C = 257, 16
+        ei = synth.tricky_graph()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(n, C, generator=g, dtype=torch.float64)
+        probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+        part = build_partition(ei, n, C, rank, world, scheme="split")
+        assert isinstance(part, SplitGraph) and part.local.n_edges + part.remote.n_edges == part.n_local_edges
+        xl = x[part.lo:part.hi].clone().requires_grad_(True)
+        out = aggregate(xl, part, aggr="softmax_sg", t=t, state_fns=(_state_fwd_torch, _state_bwd_torch))
+        (out * probe[part.lo:part.hi]).sum().backward()
+        q.put(_pack((rank, part.bounds, out.detach(), xl.grad.detach(), part.local.n_edges)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,t", [(2, 0.7), (3, 0.1)])
+@_retry_rendezvous()
+def test_local_first_split_scheme_matches_single_process(world, t):
+    """dist.SplitGraph: the edges of a destination partition cut by the owner of the source, the local part aggregated
+    while the all-gather is in flight, the two partial softmax states merged; backward: the remote gradient's
+    reduce-scatter in flight during the local gradient kernel.  Same outputs and gradients as the oracle on the whole
+    graph (the tricky graph: a hub row whose in-edges come from every rank, rows without local or without remote edges,
+    isolated rows)."""
+    from oracle import sparse_ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, t, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    ref = sparse_ref.gen_propagate(x, ei, aggr="softmax_sg", t=t)
+    (ref * probe).sum().backward()
+    bounds = res[0][1]
+    assert sum(r[4] for r in res) > 0                                     # some edges are local-source
+    for rank, b, out, gx, _ in res:
+        lo, hi = bounds[rank], bounds[rank + 1]
+        torch.testing.assert_close(out, ref[lo:hi].detach(), rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(gx, x.grad[lo:hi], rtol=1e-10, atol=1e-12)

@@ -103,6 +103,41 @@ def test_rank_local_rectangular_graphs_of_a_multi_rank_job(world, rank, node_gro
             torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-6 * gs)
 
 
+@pytest.mark.parametrize("world,rank", [(2, 1), (4, 2), (8, 5)])
+def test_local_first_split_states_on_the_hip_kernels(world, rank):
+    """dist.SplitGraph on the device without a collective: the rank's local-source and remote-source aggregations
+    (ops.softmax_state_forward), merged, equal the one-launch aggregation of the all-gather scheme's rectangular graph for
+    the same rank; the two gradient launches (ops.softmax_state_backward with the MERGED log-sum-exp) add up to its
+    gradient.  (The exchange itself: tests/test_dist_gloo.py::test_local_first_split_scheme_matches_single_process.)"""
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.dist import PartitionedGraph, SplitGraph, merge_softmax_states
+    dev = torch.device("cuda:0")
+    n, C, t = 3001, 64, 0.3
+    ei = synth.powerlaw_graph(n, 20_000, seed=21, exponent=2.2).to(dev)
+    part = PartitionedGraph.from_edge_index(ei, n, rank, world)
+    sg = SplitGraph.from_edge_index(ei, n, rank, world)
+    assert sg.bounds == part.bounds and sg.local.n_edges + sg.remote.n_edges == part.graph.n_edges
+    assert sg.local.n_edges > 0 and sg.remote.n_edges > 0
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x_full = torch.randn(world * part.max_rows, C, device=dev, generator=gen)
+    probe = torch.randn(part.n_local, C, device=dev, generator=gen)
+    lo_p = rank * part.max_rows
+    xf = x_full.clone().requires_grad_(True)
+    ref = ops.gen_aggregate(xf, part.graph, aggr="softmax_sg", t=t)
+    (ref * probe).sum().backward()
+    x_loc = x_full[lo_p:lo_p + part.n_local].contiguous()
+    oa, la = ops.softmax_state_forward(x_loc, sg.local, t)
+    ob, lb = ops.softmax_state_forward(x_full, sg.remote, t)
+    out, L = merge_softmax_states(oa, la, (sg.local.deg > 0).unsqueeze(1), ob, lb, (sg.remote.deg > 0).unsqueeze(1))
+    torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-6)
+    g_rem = ops.softmax_state_backward(x_full, sg.remote, probe, L, t)
+    g_loc = ops.softmax_state_backward(x_loc, sg.local, probe, L, t)
+    total = g_rem.clone()
+    total[lo_p:lo_p + part.n_local] += g_loc
+    gs = max(1.0, float(xf.grad.abs().max()))
+    torch.testing.assert_close(total, xf.grad, rtol=1e-4, atol=2e-6 * gs)
+
+
 def _hip_local(x_full, graph, aggr="softmax", **kw):
     """local_aggregate for a gloo (CPU tensor) job whose per-rank compute runs on the GPU's HIP kernels."""
     from deep_gcns_torch_amd import ops

@@ -361,7 +361,7 @@ def test_products_shape_destination_range_against_the_oracle(kind):
         for sel, dt in ((~heavy, torch.float32), (heavy, torch.float64)):
             if not bool(sel.any()):
                 continue
-            xr = xh.to(dt).requires_grad_(True)
+            xr = xh.to(dt, copy=True).requires_grad_(True)
             part = sparse_ref.gen_propagate(xr, ei_r[:, sel], aggr=aggr, dim_size=hi - lo, **kw)
             (part * ph.to(dt)).sum().backward()
             ref += part.detach().double()

@@ -62,7 +62,8 @@ def test_graphed_training_step_equals_eager_steps():
 
 def test_graphed_forward_backward_with_the_dynamic_item_schedule():
     """The default (dynamic, device-side counters) item schedule of the per-edge encoder kernels inside a replayed graph:
-    the counters are re-armed by a memset node of every launch, so a replay must do the same work as an eager pass.
+    the counters are re-armed by a kernel of every launch (a memset node was not reliable, see the test below), so a replay
+    must do the same work as an eager pass.
     Forward outputs are schedule-independent (bit-equal); the weight gradients' partial sums are grouped by the schedule
     (rounding-level differences).  No optimizer here: Adam would turn those last bits into O(lr) differences."""
     import deep_gcns_torch_amd
@@ -112,11 +113,11 @@ def test_graphed_forward_backward_with_the_dynamic_item_schedule():
 
 def test_replayed_back_to_back_encoder_aggregations_lose_no_work_item():
     """Round-5 regression.  Consecutive per-edge-encoder aggregations of one captured step get the SAME workspace block
-    from torch's allocator, i.e. the same work-item counters.  While the library re-armed them with hipMemsetAsync, a
-    replayed graph ran that memset node before the last waves of the previous launch had made their final claim: the
-    counters then started at 1, the first item of a few queues -- rows 0 .. 2 of the ogbn-proteins cluster graph -- was
-    never processed and its output / arg-max ids were whatever the block held before (bench.py: ~10 % of the replayed
-    launches; an illegal address once the ids were used as addresses by the max backward).  Here: 24
+    from torch's allocator, i.e. the same work-item counters.  While the library re-armed them with hipMemsetAsync (a memset
+    NODE of the captured graph), ~10 % of the replayed launches found the counters of a few queues non-zero at their first
+    claims: the first item of those queues -- rows 0 .. 2 of the ogbn-proteins cluster graph -- was never processed and
+    its output / arg-max ids were whatever the block held before (bench.py; an illegal address once the ids were used as
+    addresses by the max backward).  Here: 24
     back-to-back launches (max: output and gradients both depend on the ids) in one graph, 30 replays, every output and
     every input gradient bit-equal to the eager pass; the buffers are poisoned between replays."""
     from deep_gcns_torch_amd import ops

@@ -92,11 +92,11 @@ def test_config3_deepergcn_res_plus_with_checkpointing():
                                        _oracle_propagate)
     gx = ins[0].grad.cpu().double()
     gate("config3 deepergcn8: input gradient vs float64 along the device's ReLU decisions (max error / max)",
-         float((gx - xh.grad).abs().max() / xh.grad.abs().max()), 3e-4)
+         float((gx - xh.grad).abs().max() / xh.grad.abs().max()), 1e-4)       # measured 4.6e-7
     errs = attribution.gradient_errors(m, host)
     worst = max(errs.items(), key=lambda kv: kv[1])
-    gate("config3 deepergcn8: worst parameter gradient vs float64 along the device's ReLU decisions", worst[1], 3e-4,
-         what=worst[0])
+    gate("config3 deepergcn8: worst parameter gradient vs float64 along the device's ReLU decisions", worst[1], 1e-4,
+         what=worst[0])                                     # measured 1.2e-6
 
 
 @pytest.mark.parametrize("conv", ["mr", "edge"])
@@ -118,10 +118,11 @@ def test_config2_dense_resgcn():
     out, gx = _run(m, case, _dev())
     # kNN graphs of the deeper blocks are built on fp32 FEATURES: a near-tie may legitimately resolve
     # differently from the CPU GEMM's summation order, so allow a vanishing fraction of deviating points
-    assert _frac_close(out, case["out"], 1e-3, 1e-3) > 0.995
+    from conftest import gate
+    gate("config2 resgcn4: fraction of logits further than 1e-3 (1 + |ref|) from the reference golden",
+         1.0 - _frac_close(out, case["out"], 1e-3, 1e-3), 1e-4)                    # measured 0
     g = case["grads"][0]
-    err = _rel_l2(gx, g)
-    assert err < 5e-2, f"relative L2 error of the input gradient {err}"
+    gate("config2 resgcn4: input gradient vs the reference golden (relative L2)", _rel_l2(gx, g), 1e-3)     # measured 2.5e-5
 
 
 def test_genconv_under_reversible_usage_patterns():

@@ -324,17 +324,25 @@ def test_deepergcn_fused_layers_equal_the_plain_model():
             model(x, ei)
         model.checkpoint_grad = ck
         model.load_state_dict(sd)                           # (the recording pass moved the running statistics)
-        host = arch_restated.DeeperGCN(num_layers=9, in_channels=32, hidden=64, num_tasks=10)
-        host.load_state_dict(plain.state_dict())
-        host = host.double().train()
-        host.checkpoint_grad = False
-        attribution.float64_backward_along(
-            dec, host, lambda mm: torch.nn.functional.nll_loss(mm(x.cpu().double(), ei.cpu()), y.cpu()),
-            config_replays.oracle_propagate)
-        errs = attribution.gradient_errors(model, host)
+        hosts = {}
+        for dt in (torch.float64, torch.float32):
+            host = arch_restated.DeeperGCN(num_layers=9, in_channels=32, hidden=64, num_tasks=10)
+            host.load_state_dict(plain.state_dict())
+            host = host.to(dt).train()
+            host.checkpoint_grad = False
+            attribution.float64_backward_along(
+                dec, host, lambda mm, dt=dt: torch.nn.functional.nll_loss(mm(x.cpu().to(dt), ei.cpu()), y.cpu()),
+                config_replays.oracle_propagate)
+            hosts[dt] = host
+        errs = attribution.gradient_errors(model, hosts[torch.float64])
+        # the yardstick for "fp32 rounding through nine training-mode BatchNorm layers": the SAME replay in float32 on the
+        # host (same branches, torch CPU kernels) against the float64 one
+        errs32 = attribution.gradient_errors(hosts[torch.float32], hosts[torch.float64])
         worst = max(errs.items(), key=lambda kv: kv[1])
-        gate(f"deepergcn9 {route}: worst parameter gradient vs float64 along its own ReLU decisions", worst[1], 3e-4,
-             what=worst[0])
+        worst32 = max(errs32.values())
+        gate(f"deepergcn9 {route}: worst parameter gradient vs float64 along its own ReLU decisions, in units of max(4 x the "
+             f"host's float32 replay of the same branches [{worst32:.2e}], 1e-4)", worst[1] / max(4 * worst32, 1e-4), 1.0,
+             what=f"{worst[0]} {worst[1]:.3e}")
     for (n0, b0), (n1, b1) in zip(plain.named_buffers(), fused.named_buffers()):
         torch.testing.assert_close(b1.float(), b0.float(), rtol=1e-4, atol=1e-5, msg=n0)
     # with dropout: runs, finite, and about the right fraction of the pre-activations is dropped
@@ -379,6 +387,7 @@ def test_checkpoint_with_kept_aggregation_equals_full_recomputation(aggr, kw):
     # no_grad launch of the full recomputation's first pass -- the passes then differ by fp32 rounding, not bit for bit
     exact = not (kw.get("learn_t") or kw.get("learn_p"))
     gscale = max(float(b.abs().max()) for b in g_ref)
+    worst_ne = 0.0
     for mode in ("reference", "never"):
         o, g = res[mode]
         if exact:
@@ -391,7 +400,12 @@ def test_checkpoint_with_kept_aggregation_equals_full_recomputation(aggr, kw):
             else:
                 floor = 1e-3 * gscale * b.numel() ** 0.5
                 err = float((a - b).double().norm() / max(float(b.double().norm()), floor))
-                assert err < 2e-3, (mode, err)
+                worst_ne = max(worst_ne, err)
+                assert err < 2e-4, (mode, err)
+    if not exact:
+        from conftest import gate
+        gate(f"checkpoint modes, {aggr} with a learnable exponent / temperature: worst parameter gradient, kept aggregation "
+             f"vs full recomputation (relative L2)", worst_ne, 2e-4)      # measured 2.6e-5
 
 
 def test_aggregation_stash_refuses_a_different_recomputation():
@@ -458,8 +472,13 @@ def test_composed_edge_embedding_in_a_res_plus_stack(aggr, kw, use_checkpoint):
     o1, g1 = run(True)
     o0, g0 = run(False)
     torch.testing.assert_close(o1, o0, rtol=2e-4, atol=2e-4 * float(o0.abs().max()))
+    worst_c = 0.0
     for a, b, p in zip(g1, g0, params):
         assert (a is None) == (b is None)
         if b is not None:
             scale = float(b.abs().max()) + 1e-12
-            assert float((a - b).abs().max()) / scale < 3e-3, tuple(p.shape)
+            worst_c = max(worst_c, float((a - b).abs().max()) / scale)
+            assert float((a - b).abs().max()) / scale < 5e-4, tuple(p.shape)
+    from conftest import gate
+    gate(f"composed edge embedding in a res+ stack, {aggr}, checkpoint={use_checkpoint}: worst parameter gradient, composed vs "
+         f"materialised embedding (max error / max)", worst_c, 5e-4)        # measured: 2e-6 (max), 1.2e-5 (power), 1.1e-4 (softmax)

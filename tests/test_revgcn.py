@@ -53,13 +53,20 @@ def _run(case, dev, impl="restated", composed=False):
     return hn.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
 
 
-def _check(case, hn, grads, rtol, gtol):
-    torch.testing.assert_close(hn, case["hn"], rtol=rtol, atol=rtol)
+def _check(case, hn, grads, rtol, gtol, tag=""):
+    from conftest import gate
+    hn_err = float(((hn - case["hn"]).abs() / (rtol + rtol * case["hn"].abs())).max())
+    gate(f"revgcn {case['name']} {tag}: last_norm output vs the reference golden, max error in units of (atol + rtol |ref|) "
+         f"at {rtol:g}", hn_err, 1.0)
     assert set(grads) == set(case["grads"])
+    worst, wk = 0.0, ""
     for k, g in case["grads"].items():
         scale = float(g.abs().max()) + 1e-12
         err = float((grads[k] - g).abs().max()) / scale
-        assert err < gtol, f"{k}: max error {err:.3e} of the gradient scale"
+        if err > worst:
+            worst, wk = err, k
+    gate(f"revgcn {case['name']} {tag}: worst parameter gradient vs the reference golden (max error / max)", worst, gtol,
+         what=wk)
 
 
 @pytest.mark.parametrize("impl", ["restated", "product", "product_composed"])
@@ -79,7 +86,7 @@ def test_restated_reversible_wrapper_matches_reference_on_cpu(case, impl):
                          composed=impl == "product_composed")
     finally:
         torch_message.GenMessagePassing.propagate = saved
-    _check(case, hn, grads, 1e-4, 2e-4)
+    _check(case, hn, grads, 1e-4, 2e-4, tag=f"cpu {impl}")
 
 
 @pytest.mark.gpu
@@ -99,9 +106,10 @@ def test_revgcn_reference_pattern_on_hip_kernels(case, impl):
         hn, grads = _run(case, torch.device("cuda:0"), "product" if impl.startswith("product") else impl)
     finally:
         gcn_revop.KEEP_AGGREGATION = keep
-    # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge
-    # on another device, so the gradient gate is relative to each tensor's scale (not elementwise)
-    _check(case, hn, grads, 2e-4, 2e-3)
+    # max aggregation routes a gradient to ONE arg-max edge: an input within an ulp of a tie may pick another edge on
+    # another device -- none does on these fixtures: round 5 recorded the actual errors (conftest.gate) and the gates
+    # are now 1e-5 (outputs, absolute and relative) and 1e-4 of each gradient's scale (rounds 1 - 4: 2e-4 / 2e-3)
+    _check(case, hn, grads, 1e-5, 1e-4, tag=f"gpu {impl}")       # measured: <= 1.3e-6 abs / 7e-6 (gpurun_out/test_gates.json)
 
 
 @pytest.mark.gpu
@@ -119,7 +127,7 @@ def test_revgcn_with_composed_edge_encoders_matches_the_reference(case, keep):
         hn, grads = _run(case, torch.device("cuda:0"), "product", composed=True)
     finally:
         gcn_revop.KEEP_AGGREGATION = saved
-    _check(case, hn, grads, 2e-4, 2e-3)
+    _check(case, hn, grads, 1e-5, 1e-4, tag=f"gpu composed keep={keep}")   # measured: <= 1.3e-6 abs / 1.2e-5
 
 
 @pytest.mark.gpu
