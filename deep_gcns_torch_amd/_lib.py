@@ -71,6 +71,10 @@ _SIGNATURES = {
     "dgcn_enc_max_bwd_num_partials": (C.c_int32, [C.c_int32]),
     "dgcn_enc_max_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                               C.c_int32, C.c_void_p, C.c_void_p]),
+    "dgcn_enc_compose_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dgcn_enc_compose_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dgcn_gen_aggr_egemm_supported": (C.c_int32, [C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dgcn_gen_aggr_egemm_fwd_f32": (C.c_int, [
@@ -137,6 +141,7 @@ _SIGNATURES = {
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
+    "dgcn_reduce_partials_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "dgcn_rows_num_partials": (C.c_int32, [C.c_int64, C.c_int32]),
     "dgcn_rows_stats_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_rows_bn_apply_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -216,6 +221,24 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().dgcn_strerror(rc)
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def sum_partials(parts: "torch.Tensor") -> "torch.Tensor":
+    """``parts.sum(0)`` of a contiguous fp32 (nparts, ...) block of per-workgroup partial sums in ONE launch
+    (dgcn_reduce_partials_f32: fixed order, bit-reproducible)."""
+    lib = load()
+    nparts = parts.size(0)
+    out = torch.empty(parts.shape[1:], device=parts.device, dtype=torch.float32)
+    width = out.numel()
+    if width == 0:
+        return out
+    if nparts == 0:
+        return out.zero_()
+    dev = parts.device
+    with device_ctx(dev):
+        check(lib.dgcn_reduce_partials_f32(parts.data_ptr(), nparts, width, out.data_ptr(), current_stream_handle(dev)),
+              "dgcn_reduce_partials_f32")
+    return out
 
 
 def ptr(t) -> int | None:

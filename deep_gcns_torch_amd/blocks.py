@@ -117,6 +117,61 @@ class ResPlusLayer(torch.nn.Module):
                               stats=stats, use_checkpoint=self.use_checkpoint)
 
 
+class _ComposeEncoder(torch.autograd.Function):
+    """(W', b') = (W_l We, W_l b_e + b_l) and its backward, one library launch each way (csrc/enc_compose.hip) instead of
+    matmul + addmv forward and four small GEMM / GEMV launches backward per coupling function."""
+
+    @staticmethod
+    def forward(ctx, layer_w, layer_b, enc_w, enc_b):
+        from . import _lib
+        lib = _lib.load()
+        dev = layer_w.device
+        lw, ew = layer_w.detach().contiguous(), enc_w.detach().contiguous()
+        lb = None if layer_b is None else layer_b.detach().contiguous()
+        eb = None if enc_b is None else enc_b.detach().contiguous()
+        C, H = lw.shape
+        F = ew.size(1)
+        out_w = torch.empty(C, F, device=dev, dtype=torch.float32)
+        out_b = torch.empty(C, device=dev, dtype=torch.float32) if (lb is not None or eb is not None) else None
+        with _lib.device_ctx(dev):
+            _lib.check(lib.dgcn_enc_compose_fwd_f32(lw.data_ptr(), _lib.ptr(lb), ew.data_ptr(), _lib.ptr(eb), C, H, F,
+                                                    out_w.data_ptr(), _lib.ptr(out_b), _lib.current_stream_handle(dev)),
+                       "dgcn_enc_compose_fwd_f32")
+        ctx.save_for_backward(lw, ew, eb)
+        ctx.has_lb = lb is not None
+        if out_b is None:
+            ctx.mark_non_differentiable()
+            return out_w, None
+        return out_w, out_b
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        from . import _lib
+        lib = _lib.load()
+        lw, ew, eb = ctx.saved_tensors
+        dev = lw.device
+        C, H = lw.shape
+        F = ew.size(1)
+        gw = torch.zeros(C, F, device=dev, dtype=torch.float32) if gw is None else gw.float().contiguous()
+        gb = None if gb is None else gb.float().contiguous()
+        need_l, need_e, need_eb = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and eb is not None
+        d_l = torch.empty(C, H, device=dev, dtype=torch.float32) if need_l else None
+        d_e = torch.empty(H, F, device=dev, dtype=torch.float32) if (need_e or need_eb) else None
+        d_eb = torch.empty(H, device=dev, dtype=torch.float32) if (need_eb and gb is not None) else None
+        with _lib.device_ctx(dev):
+            _lib.check(lib.dgcn_enc_compose_bwd_f32(lw.data_ptr(), ew.data_ptr(), _lib.ptr(eb), gw.data_ptr(), _lib.ptr(gb), C, H, F,
+                                                    _lib.ptr(d_l), _lib.ptr(d_e), _lib.ptr(d_eb),
+                                                    _lib.current_stream_handle(dev)), "dgcn_enc_compose_bwd_f32")
+        d_lb = gb if (ctx.has_lb and ctx.needs_input_grad[1]) else None
+        return d_l, d_lb, (d_e if need_e else None), d_eb
+
+
+def _compose_on_device(layer_w, layer_b, enc_w, enc_b) -> bool:
+    ts = [t for t in (layer_w, layer_b, enc_w, enc_b) if t is not None]
+    return (all(t.is_cuda and t.dtype == torch.float32 for t in ts) and enc_w.size(1) <= 16
+            and not torch.is_autocast_enabled())
+
+
 class ComposedEdgeEmbedding:
     """``edge_encoder(edge_attr)`` [repeated ``repeat`` times along the feature axis] WITHOUT building it.
 
@@ -171,6 +226,8 @@ class ComposedEdgeEmbedding:
         """(W', b') of ``layer_encoder(encoder(.))`` for a per-layer Linear(hidden -> C)."""
         if self.repeat != 1:
             raise ValueError("compose a group view, not the repeated embedding")
+        if _compose_on_device(layer_encoder.weight, layer_encoder.bias, self.encoder.weight, self.encoder.bias):
+            return _ComposeEncoder.apply(layer_encoder.weight, layer_encoder.bias, self.encoder.weight, self.encoder.bias)
         w = layer_encoder.weight @ self.encoder.weight                               # (C, 8)
         if self.encoder.bias is None:
             return w, layer_encoder.bias

@@ -348,7 +348,7 @@ class _LayerNormRows(torch.autograd.Function):
                                                     rows, C, stream),
                        "dgcn_rows_ln_act_bwd_f32")
             if need_p:
-                psum = partial.sum(0)                 # (2, C): sum g' | sum g' xhat over <= 1024 workgroup partials
+                psum = _lib.sum_partials(partial)     # (2, C): sum g' | sum g' xhat over <= 1024 workgroup partials, one launch
         gw = psum[1] if (has_w and ctx.needs_input_grad[1]) else None
         gb = psum[0] if (has_b and ctx.needs_input_grad[2]) else None
         return (dx.view(shape) if dx is not None else None), gw, gb, None, None, None, None, None
@@ -486,7 +486,7 @@ class _RowsLinear(torch.autograd.Function):
             if _lib.load().dgcn_rows_linear_supported(C, K):
                 gx, _, xsum = _rl_launch(g, weight.detach(), True, None, None, False, False, fuse_b)
                 if fuse_b:
-                    gb = xsum.sum(0)
+                    gb = _lib.sum_partials(xsum) if xsum.is_contiguous() else xsum.sum(0)
             else:
                 gx = g @ weight
         if ctx.needs_input_grad[1]:

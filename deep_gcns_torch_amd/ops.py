@@ -480,7 +480,7 @@ class _GenAggregate(torch.autograd.Function):
                         _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
             _lib.check(rc, "dgcn_gen_aggr_enc_bwd_f32" if enc is not None else "dgcn_gen_aggr_bwd_f32")
             if enc is not None:
-                gsum = gpart.sum(0)                      # fixed-order partials -> (C, 9) = dW | db
+                gsum = _lib.sum_partials(gpart)          # fixed-order partials -> (C, 9) = dW | db, one launch
                 if ctx.needs_input_grad[15]:
                     grad_w = gsum[:, :ENC_FEATURES].contiguous()
                 if b_enc is not None and ctx.needs_input_grad[16]:
@@ -522,7 +522,7 @@ class _GenAggregate(torch.autograd.Function):
                                                            feat.data_ptr(),
                                                            ENC_FEATURES, C, gpart.data_ptr(),
                                                            _lib.current_stream_handle(dev)), "dgcn_enc_max_bwd_weight_f32")
-            gsum = gpart.sum(0)
+            gsum = _lib.sum_partials(gpart)
             if ctx.needs_input_grad[15]:
                 grad_w = gsum[:, :ENC_FEATURES].contiguous()
             if b_enc is not None and ctx.needs_input_grad[16]:
@@ -546,7 +546,7 @@ class _GenAggregate(torch.autograd.Function):
                     feat.stride(0), w_enc.data_ptr(), n_feat, C, _lib.ptr(gf), gf.stride(0) if gf is not None else 0,
                     _lib.ptr(wpart), _lib.current_stream_handle(dev)), "dgcn_egemm_max_bwd_f32")
             if wpart is not None:
-                grad_w = wpart.sum(0)
+                grad_w = _lib.sum_partials(wpart)
         return (grad_x, grad_ea, grad_t, grad_p) + (None,) * 10 + (grad_feat, grad_w, grad_b)
 
 

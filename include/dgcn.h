@@ -248,6 +248,22 @@ int dgcn_enc_max_bwd_weight_f32(const float* gcoef, const int32_t* argmax, int32
                                 void* stream);
 
 /*
+ * Composition of the model-level edge encoder Linear(F -> hidden) (examples/ogb_eff/ogbn_proteins/model_rev.py:53,98;
+ * ogbn_proteins/model.py:90,107) with a GENConv's own edge_encoder = Linear(hidden -> C)
+ * (gcn_lib/sparse/torch_vertex.py:56-66) into the Linear(F -> C) that dgcn_gen_aggr_enc_{fwd,bwd}_f32 evaluate per edge:
+ *   out_w[c][f] = sum_h layer_w[c][h] enc_w[h][f],   out_b[c] = sum_h layer_w[c][h] enc_b[h] + layer_b[c]
+ * and its backward (what autograd builds for the two Linear calls in a row), one launch each:
+ *   grad_layer_w = grad_w enc_w^T + grad_b enc_b^T,  grad_enc_w = layer_w^T grad_w,  grad_enc_b = layer_w^T grad_b
+ * (grad_layer_b = grad_b: the caller's).  Row-major contiguous fp32; n_feat <= 16; biases may be NULL (with out_b /
+ * grad_b NULL when both are).  Fixed summation order: bit-reproducible.
+ */
+int dgcn_enc_compose_fwd_f32(const float* layer_w, const float* layer_b, const float* enc_w, const float* enc_b,
+                             int32_t channels, int32_t hidden, int32_t n_feat, float* out_w, float* out_b, void* stream);
+int dgcn_enc_compose_bwd_f32(const float* layer_w, const float* enc_w, const float* enc_b, const float* grad_w,
+                             const float* grad_b, int32_t channels, int32_t hidden, int32_t n_feat, float* grad_layer_w,
+                             float* grad_enc_w, float* grad_enc_b, void* stream);
+
+/*
  * The edge encoder of GENConv on WIDE edge features as the reference's models use it: the model computes ONE
  * (E, hidden) edge embedding and every GENConv owns edge_encoder = Linear(edge_feat_dim = hidden -> C)
  * (gcn_lib/sparse/torch_vertex.py:56-66; examples/ogb_eff/ogbn_proteins/model_rev.py:45-55,98-107;
@@ -497,6 +513,13 @@ int dgcn_dense_edge_reduce_bwd_inv_f32(const float* P, int64_t ldp, const float*
  * atomic-free edge backward into the Q half of the vertex-GEMM gradient. */
 int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int32_t C, float* dst, int64_t ld,
                           void* stream);
+
+/* out[w] = sum_s parts[s][w], s < nparts, w < width: the fixed-order sum of the per-workgroup partial blocks the backward
+ * entry points leave (enc_grad_partials of dgcn_gen_aggr_enc_bwd_f32 / dgcn_enc_max_bwd_weight_f32, grad_w_partials of
+ * dgcn_egemm_max_bwd_f32, the (d beta | d gamma) partials of dgcn_rows_ln_act_bwd_f32, the column sums of
+ * dgcn_rows_linear_f32's EPI = 2) -- what autograd's sum over the workgroup axis does in the reference's graph, in one launch
+ * instead of torch's memset + reduce pair.  Bit-reproducible. */
+int dgcn_reduce_partials_f32(const float* parts, int32_t nparts, int64_t width, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Node-wise BatchNorm1d on row-major (rows, C) features, optional fused ReLU  (SURVEY.md §8 f1).

@@ -88,9 +88,10 @@ REVGCN_OUT_ROWS = 1024
 
 def formula_init(model, seed):
     """Parameters as a function of (name, shape, seed) only: the generator builds the REFERENCE's classes, the GPU tests the
-    restated / product classes, whose constructors consume torch's RNG in a different order.  Scales follow nn.Linear /
-    LayerNorm defaults (U(-1/sqrt(fan_in), 1/sqrt(fan_in)); norm weights 1 +- 0.1, norm biases +- 0.1) so that the depth
-    behaves like a freshly initialised model."""
+    restated / product classes, whose constructors consume torch's RNG in a different order.  2-D parameters:
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) as nn.Linear; 1-D parameters whose name contains "norm" and ends in "weight":
+    1 +- 0.1; every other 1-D parameter (biases, and the affine pair of a norm that sits inside an MLP Sequential, whose
+    name is an index): +- 0.1; 1-element parameters (t / p) keep their configured values."""
     import zlib
     with torch.no_grad():
         for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):

@@ -29,7 +29,8 @@ def install_guard_allocator():
     if not torch.cuda.is_available():
         return False
     if not os.path.exists(GUARD_LIB):
-        raise RuntimeError(f"{GUARD_LIB} not built (python -c 'import __graft_entry__ as g; g.build()')")
+        import __graft_entry__
+        __graft_entry__._build_guard_allocator()          # host-only C++ against the HIP runtime: seconds with hipcc
     alloc = torch.cuda.memory.CUDAPluggableAllocator(GUARD_LIB, "dgcn_guard_malloc", "dgcn_guard_free")
     torch.cuda.memory.change_current_allocator(alloc)
     # a free must not synchronise the device while a hipGraph is being captured, and what a capture allocates or frees

@@ -20,6 +20,10 @@ RUN = os.path.join(ROOT, "tests", "guard_alloc", "run.py")
 
 
 def _guarded(args, timeout, no_blocking=False):
+    if not os.path.exists(os.path.join(ROOT, "tests", "guard_alloc", "libguard_alloc.so")):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__._build_guard_allocator()
     cmd = [sys.executable, RUN, "--timeout", str(timeout), "--log", f"/tmp/dgcn_guard_{os.getpid()}.log"]
     if no_blocking:
         cmd.append("--no-blocking")
