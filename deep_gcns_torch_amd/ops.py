@@ -214,7 +214,6 @@ class edge_grad_sink:
 
 
 _ZEROS = {}
-_DEBUG_AUX = None       # investigation only (tests/guard_alloc/bench_guarded.py): device counters of out-of-range arg-max ids
 
 
 def _zeros_cached(dev, n):
@@ -358,9 +357,6 @@ class _GenAggregate(torch.autograd.Function):
                     _lib.current_stream_handle(dev))
         _lib.check(rc, "dgcn_gen_aggr_egemm_fwd_f32" if egemm else
                    ("dgcn_gen_aggr_enc_fwd_f32" if enc else "dgcn_gen_aggr_fwd_f32"))
-        if _DEBUG_AUX is not None and enc and mode == _lib.AGGR_MAX and aux1 is not None:
-            _DEBUG_AUX["fwd"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).sum()
-            _DEBUG_AUX["fwd_rows"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).any(1).sum()
         if record:
             stash.items.append((slot_key, (out, aux1, aux2, range_flag, z_save)))
         if need_grad:
@@ -511,8 +507,6 @@ class _GenAggregate(torch.autograd.Function):
             if not ctx.needs_input_grad[0]:
                 grad_x = None
         if enc_winners and any(ctx.needs_input_grad[15:17]):
-            if _DEBUG_AUX is not None:
-                _DEBUG_AUX["bwd"] += ((aux1 < -1) | (aux1 >= graph.n_edges)).sum()
             feat, w_enc, b_enc = enc_w_args
             gpart = torch.empty(lib.dgcn_enc_max_bwd_num_partials(graph.n_dst), C, ENC_FEATURES + 1, device=dev,
                                 dtype=torch.float32)

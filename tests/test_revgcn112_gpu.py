@@ -49,15 +49,8 @@ def _record(name, data):
 
 @pytest.mark.parametrize("route", ["fused", "product", "graphed"])
 @pytest.mark.parametrize("aggr", ["max", "power"])
-def test_revgcn112_full_depth_against_the_reference(aggr, route, monkeypatch):
-    # dropout 0: the model file draws its shared mask as zeros_like(h).bernoulli_(1 - dropout) (model_rev.py:101).  On the
-    # device bernoulli_(1.0) is "uniform < 1.0" with the uniform drawn from (0, 1]: an element is 0 with probability 2^-24,
-    # i.e. ~18 % of the 3 M-element masks carry one zero (found here: one row of one layer off by 4e-2 in a random step;
-    # the CPU generator, which produced the fixture, never does).  The identity mask is pinned for this test.
-    orig_bernoulli = torch.Tensor.bernoulli_
-    monkeypatch.setattr(torch.Tensor, "bernoulli_",
-                        lambda self, p=0.5, **kw: self.fill_(1.0) if (not isinstance(p, torch.Tensor) and p == 1.0)
-                        else orig_bernoulli(self, p, **kw))
+def test_revgcn112_full_depth_against_the_reference(aggr, route):
+    # (dropout 0: conftest.identity_dropout_mask pins the identity mask the model draws with bernoulli_(1.0))
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
     from deep_gcns_torch_amd import fuse
