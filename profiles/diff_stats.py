@@ -10,6 +10,7 @@ import sys
 
 def short(n):
     n = n.replace("void ", "").replace("at::native::", "").replace("dgcn::(anonymous namespace)::", "dgcn::")
+    n = n.replace("(anonymous namespace)::", "")
     return n.split("(")[0][:110]
 
 
