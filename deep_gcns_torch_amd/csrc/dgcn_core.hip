@@ -13,27 +13,34 @@ __global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restr
 // out[w] = sum_s parts[s][w]: the per-workgroup partial sums every backward kernel of the library leaves (dW | db of the
 // encoders, d beta | d gamma of the norms, bias gradients, weight-gradient blocks), summed in ONE launch and in a fixed
 // order (bit-reproducible).  torch's sum(0) takes a memset + a reduce launch for these shapes: 144 of the 880 launches of
-// an eager RevGCN-8 step (benchmarks/launch_census.py).  A workgroup owns 64 columns; its four waves take the partials
-// s = w, w + 4, ... with four independent accumulators each and meet in LDS in wave order.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int64_t width,
+// an eager RevGCN-8 step (benchmarks/launch_census.py).  A workgroup owns 64 columns; its sixteen waves take the partials
+// s = w, w + 16, ... with four independent accumulators each and meet in LDS in wave order (four waves: 16.5 us per launch
+// at 1024 x 224 -- the loads of one wave are a dependent chain).
+constexpr int kRpWaves = 16;
+__global__ __launch_bounds__(kRpWaves * 64) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int64_t width,
                                                                float* __restrict__ out) {
-  __shared__ float red[4][64];
+  __shared__ float red[kRpWaves][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t col = static_cast<int64_t>(blockIdx.x) * 64 + lane;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < width) {
     int s = wave;
-    for (; s + 12 < nparts; s += 16) {
+    for (; s + 3 * kRpWaves < nparts; s += 4 * kRpWaves) {
       a0 += parts[static_cast<int64_t>(s) * width + col];
-      a1 += parts[static_cast<int64_t>(s + 4) * width + col];
-      a2 += parts[static_cast<int64_t>(s + 8) * width + col];
-      a3 += parts[static_cast<int64_t>(s + 12) * width + col];
+      a1 += parts[static_cast<int64_t>(s + kRpWaves) * width + col];
+      a2 += parts[static_cast<int64_t>(s + 2 * kRpWaves) * width + col];
+      a3 += parts[static_cast<int64_t>(s + 3 * kRpWaves) * width + col];
     }
-    for (; s < nparts; s += 4) a0 += parts[static_cast<int64_t>(s) * width + col];
+    for (; s < nparts; s += kRpWaves) a0 += parts[static_cast<int64_t>(s) * width + col];
   }
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (wave == 0 && col < width) out[col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (wave == 0 && col < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRpWaves; ++w) t += red[w][lane];
+    out[col] = t;
+  }
 }
 
 }  // namespace
@@ -42,7 +49,7 @@ extern "C" int dgcn_reduce_partials_f32(const float* parts, int32_t nparts, int6
   if (!parts || !out) return DGCN_E_NULL;
   if (nparts < 0 || width < 0) return DGCN_E_SHAPE;
   if (width == 0) return DGCN_OK;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + 63) / 64)), dim3(kRpWaves * 64), 0,
                      static_cast<hipStream_t>(stream), parts, nparts, width, out);
   return dgcn::launch_status();
 }
