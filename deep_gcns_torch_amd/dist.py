@@ -684,7 +684,13 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         rank = dist.get_rank(group)
         mr, C = sg.max_rows, xl.size(1)
         g = g.contiguous()
-        g_full = ctx.state_bwd(full, sg.remote, g, L, ctx.t).contiguous()      # gradient of the remote rows first ...
+        extra = {}
+        if ctx.state_bwd is _hip_state_fns()[1]:
+            from . import ops
+            prep = ops.softmax_state_prepare(g, L)          # one node-wise prologue for both launches (single-gather form)
+            if prep is not None:
+                extra = dict(prep=prep)
+        g_full = ctx.state_bwd(full, sg.remote, g, L, ctx.t, **extra).contiguous()   # gradient of the remote rows first ...
         if ctx.tensor_coll:
             back = g_full.new_empty(mr, C)
             work = dist.reduce_scatter_tensor(back, g_full, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -692,7 +698,7 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
             tmp = g_full.clone()
             work = dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=True)
             back = None
-        g_loc = ctx.state_bwd(xl, sg.local, g, L, ctx.t)                        # ... its reduce-scatter flies during this
+        g_loc = ctx.state_bwd(xl, sg.local, g, L, ctx.t, **extra)               # ... its reduce-scatter flies during this
         work.wait()
         if back is None:
             back = tmp.view(world, mr, C)[rank]

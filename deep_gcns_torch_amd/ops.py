@@ -607,11 +607,31 @@ def softmax_state_forward(x: torch.Tensor, graph: Graph, t: float = 1.0, relu_ep
     return out, L
 
 
+def softmax_state_prepare(g: torch.Tensor, L: torch.Tensor):
+    """The node-wise prologue of the single-gather softmax backward for a given log-sum-exp array: ``(g exp(-L), zeros,
+    range flag)``; shared by the backward launches of a split aggregation."""
+    lib = _lib.load()
+    dev = _lib.require_device(g, L)
+    g = g.float().contiguous()
+    L = L.float().contiguous()
+    C = g.size(1)
+    if C % 4 != 0:
+        return None
+    kshift = _zeros_cached(dev, C)
+    flag = (L.abs() >= SHIFT_SAFE_ABS_L).any().to(torch.int32).reshape(1)       # 1 = NOT safe (the forward's convention)
+    gshift = torch.empty_like(g)
+    with _lib.device_ctx(dev):
+        _lib.check(lib.dgcn_softmax_bwd_prep_f32(g.data_ptr(), L.data_ptr(), kshift.data_ptr(), gshift.data_ptr(), g.size(0), C,
+                                                 _lib.current_stream_handle(dev)), "dgcn_softmax_bwd_prep_f32")
+    return gshift, kshift, flag
+
+
 def softmax_state_backward(x: torch.Tensor, graph: Graph, g: torch.Tensor, L: torch.Tensor, t: float = 1.0,
-                           relu_eps: bool = True, eps: float = 1e-7) -> torch.Tensor:
+                           relu_eps: bool = True, eps: float = 1e-7, prep=None) -> torch.Tensor:
     """grad_x (graph.n_src, C) of  sum_i g_i . sum_e w_e m_e  with the weights w_e = exp(t m_e - L_i) held constant
     (softmax_sg / softmax without learnable t, gcn_lib/sparse/torch_message.py:54-58) for a GIVEN log-sum-exp array --
-    the merged one of a split aggregation."""
+    the merged one of a split aggregation.  ``prep = softmax_state_prepare(g, L)``: the single-gather form (one gathered
+    row per edge; the kernel falls back to gathering g and L when some |L| >= 80)."""
     lib = _lib.load()
     dev = _lib.require_device(x, g, L)
     x = _rows_f32(x)
@@ -622,11 +642,13 @@ def softmax_state_backward(x: torch.Tensor, graph: Graph, g: torch.Tensor, L: to
     ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    gshift, kshift, flag = prep if prep is not None else (None, None, None)
+    flags = _lib.FLAG_SHIFT_FLAG_IS_RANGE if prep is not None else 0
     with _lib.device_ctx(dev):
-        rc = lib.dgcn_gen_aggr_bwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_SOFTMAX, msg, 0,
-                                       float(t), 1.0, float(eps), None, None, g.data_ptr(), L.data_ptr(), None, None,
-                                       None, None, None, grad_x.data_ptr(), None, _lib.ptr(ws), ws_bytes,
-                                       _lib.current_stream_handle(dev))
+        rc = lib.dgcn_gen_aggr_bwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_SOFTMAX, msg, flags,
+                                       float(t), 1.0, float(eps), None, None, g.data_ptr(), L.data_ptr(), None,
+                                       _lib.ptr(gshift), _lib.ptr(kshift), _lib.ptr(flag), None, grad_x.data_ptr(), None,
+                                       _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
     _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
     return grad_x
 

@@ -130,12 +130,13 @@ def test_local_first_split_states_on_the_hip_kernels(world, rank):
     ob, lb = ops.softmax_state_forward(x_full, sg.remote, t)
     out, L = merge_softmax_states(oa, la, (sg.local.deg > 0).unsqueeze(1), ob, lb, (sg.remote.deg > 0).unsqueeze(1))
     torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-6)
-    g_rem = ops.softmax_state_backward(x_full, sg.remote, probe, L, t)
-    g_loc = ops.softmax_state_backward(x_loc, sg.local, probe, L, t)
-    total = g_rem.clone()
-    total[lo_p:lo_p + part.n_local] += g_loc
     gs = max(1.0, float(xf.grad.abs().max()))
-    torch.testing.assert_close(total, xf.grad, rtol=1e-4, atol=2e-6 * gs)
+    for prep in (None, ops.softmax_state_prepare(probe, L)):        # two-gather form, single-gather form
+        g_rem = ops.softmax_state_backward(x_full, sg.remote, probe, L, t, prep=prep)
+        g_loc = ops.softmax_state_backward(x_loc, sg.local, probe, L, t, prep=prep)
+        total = g_rem.clone()
+        total[lo_p:lo_p + part.n_local] += g_loc
+        torch.testing.assert_close(total, xf.grad, rtol=1e-4, atol=2e-6 * gs)
 
 
 def _hip_local(x_full, graph, aggr="softmax", **kw):
