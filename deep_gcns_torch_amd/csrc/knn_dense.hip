@@ -1138,6 +1138,11 @@ __global__ __launch_bounds__(256) void knn_planes_kernel(const float* __restrict
 // kernel's, or the exact kernel's chain when the row is redone), never by a mixture.
 template <int kFCap, int KC, int NW>
 __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const KnnParams P) {
+#ifdef DGCN_KNN_AGG_ALWAYS
+  constexpr bool kFAggAppend = true;
+#else
+  constexpr bool kFAggAppend = kFCap > 512;      // wave-aggregated appends where a quarter of the candidates are hits
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kFTM;
   const int N = P.N, K = P.K;
@@ -1354,44 +1359,68 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
     // take base + their rank among the group's hits.  A block without a hit in any of the four rows of this register
     // (K = 16: 98 % of the candidates miss) is skipped with one wave-uniform branch.  The lists are unordered sets, the
     // select ranks by (key, id): the emitted ids do not depend on the order of the appends.
-    const int seg = lane & ~15;                                       // first lane of this lane's 16-lane group
-    const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
-      const float tf = tauf[r];
-      const float sr = sq[r];
-      const int self = P.exclude_self ? i0 + r : -1;
-      float dist[4];
-      bool hit[4];
-      unsigned long long bal[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        dist[t] = (sr + (-2.f * acc[t][reg])) + sj[t];
-        hit[t] = in[t] && dist[t] <= tf && (col0 + 16 * t + li) != self;
-        bal[t] = __ballot(hit[t]);
+    if constexpr (kFAggAppend) {
+      const int seg = lane & ~15;                                       // first lane of this lane's 16-lane group
+      const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
+  #pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
+        const float tf = tauf[r];
+        const float sr = sq[r];
+        const int self = P.exclude_self ? i0 + r : -1;
+        float dist[4];
+        bool hit[4];
+        unsigned long long bal[4];
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dist[t] = (sr + (-2.f * acc[t][reg])) + sj[t];
+          hit[t] = in[t] && dist[t] <= tf && (col0 + 16 * t + li) != self;
+          bal[t] = __ballot(hit[t]);
+        }
+        if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;     // wave-uniform
+        int nseg[4], total = 0;
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          nseg[t] = __popcll((bal[t] >> seg) & 0xFFFFull);
+          total += nseg[t];
+        }
+        int base = 0;
+        if (li == 0 && total > 0) base = atomicAdd(&cnt[r], total);
+        base = __shfl(base, seg);
+        int before = 0;
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (hit[t]) {
+            const int pos = base + before + __popcll(bal[t] & segbelow);
+            if (pos < kFCap) {
+              ckey[r * kFCap + pos] = key_of(dist[t]);
+              cidx[r * kFCap + pos] = static_cast<uint32_t>(col0 + 16 * t + li);
+            }
+          }
+          before += nseg[t];
+        }
       }
-      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;     // wave-uniform
-      int nseg[4], total = 0;
+    } else {
+      // one LDS atomic per hit (round 4's form): cheaper in vector instructions when hits are rare (K = 16: 2 % of the
+      // candidates), serialises on the row's counter when they are not
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        nseg[t] = __popcll((bal[t] >> seg) & 0xFFFFull);
-        total += nseg[t];
-      }
-      int base = 0;
-      if (li == 0 && total > 0) base = atomicAdd(&cnt[r], total);
-      base = __shfl(base, seg);
-      int before = 0;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = lk * 4 + reg;
+        const float tf = tauf[r];
+        const float sr = sq[r];
+        const int self = P.exclude_self ? i0 + r : -1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (hit[t]) {
-          const int pos = base + before + __popcll(bal[t] & segbelow);
-          if (pos < kFCap) {
-            ckey[r * kFCap + pos] = key_of(dist[t]);
-            cidx[r * kFCap + pos] = static_cast<uint32_t>(col0 + 16 * t + li);
+        for (int t = 0; t < 4; ++t) {
+          const float dist = (sr + (-2.f * acc[t][reg])) + sj[t];
+          const int c = col0 + 16 * t + li;
+          if (in[t] && dist <= tf && c != self) {
+            const int pos = atomicAdd(&cnt[r], 1);
+            if (pos < kFCap) {
+              ckey[r * kFCap + pos] = key_of(dist);
+              cidx[r * kFCap + pos] = static_cast<uint32_t>(c);
+            }
           }
         }
-        before += nseg[t];
       }
     }
   }
