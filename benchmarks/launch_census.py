@@ -93,3 +93,13 @@ for k, c in kern.most_common(28):
 print("-- by issuing op (count)")
 for (i, o), c in owner.most_common(30):
     print(f"{c:5d}  {i}   [{o}]")
+# host side: self CPU time per op name (both the calling thread and autograd's device thread), and the wall time of the step
+cpu = Counter()
+cnt = Counter()
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CPU:
+        cpu[e.name[:70]] += e.self_cpu_time_total
+        cnt[e.name[:70]] += 1
+print(f"-- host: self CPU time by op (us, calls); total {sum(cpu.values()):.0f} us under the profiler")
+for k, t in cpu.most_common(40):
+    print(f"{t:9.0f} {cnt[k]:5d}  {k}")

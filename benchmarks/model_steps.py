@@ -82,8 +82,45 @@ run = GraphedStep(step, warmup=2) if graphed else step
 if not graphed:
     step()
 torch.cuda.synchronize()
+profs = None
+if os.environ.get("DGCN_HOST_PROFILE"):
+    # where the host time of an eager step goes: cProfile on the calling thread (forward, optimizer) and a second one on
+    # autograd's device thread (every backward node of a device tensor runs there), switched on from a hook of the loss
+    import cProfile
+    profs = (cProfile.Profile(), cProfile.Profile())
+    _backward = torch.Tensor.backward
+    _armed = []
+
+    def _arm(grad):
+        if not _armed:
+            _armed.append(1)
+            profs[1].enable()
+        return grad
+
+    def backward(self, *a, **kw):
+        self.register_hook(_arm)
+        return _backward(self, *a, **kw)
+
+    torch.Tensor.backward = backward
+    profs[0].enable()
 t0 = time.perf_counter()
 for _ in range(steps):
     run()
+t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
+if profs is not None:
+    import io
+    import pstats
+    profs[0].disable()
+    dst = os.path.join(ROOT, "gpurun_out", f"host_profile_{which}.txt")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, "w") as f:
+        f.write(f"{which}: host issue time {t_issue / steps * 1e3:.3f} ms per step over {steps} steps "
+                f"(cProfile on: slower than the plain run)\n")
+        for name, pr in zip(("calling thread", "autograd device thread"), profs):
+            out = io.StringIO()
+            st = pstats.Stats(pr, stream=out)
+            st.sort_stats("tottime").print_stats(40)
+            st.sort_stats("cumulative").print_stats(70)
+            f.write(f"\n================ {name} ================\n" + out.getvalue())
 print(f"{which}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step over {steps} steps (wall)")

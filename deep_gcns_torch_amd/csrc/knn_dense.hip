@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
     if constexpr (kFAggAppend) {
       const int seg = lane & ~15;                                       // first lane of this lane's 16-lane group
       const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
-  #pragma unroll
+#pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = lk * 4 + reg;  // the four 16-lane groups hold four different rows
         const float tf = tauf[r];
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
         float dist[4];
         bool hit[4];
         unsigned long long bal[4];
-  #pragma unroll
+#pragma unroll
         for (int t = 0; t < 4; ++t) {
           dist[t] = (sr + (-2.f * acc[t][reg])) + sj[t];
           hit[t] = in[t] && dist[t] <= tf && (col0 + 16 * t + li) != self;
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
         }
         if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;     // wave-uniform
         int nseg[4], total = 0;
-  #pragma unroll
+#pragma unroll
         for (int t = 0; t < 4; ++t) {
           nseg[t] = __popcll((bal[t] >> seg) & 0xFFFFull);
           total += nseg[t];
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
         if (li == 0 && total > 0) base = atomicAdd(&cnt[r], total);
         base = __shfl(base, seg);
         int before = 0;
-  #pragma unroll
+#pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (hit[t]) {
             const int pos = base + before + __popcll(bal[t] & segbelow);

@@ -524,3 +524,18 @@ def test_encoder_composition_kernels_match_the_two_linear_layers(C, H, F, biases
     gradsd = torch.autograd.grad(lossd, list(ld.parameters()) + list(ed.parameters()))
     for a, r in zip(gradsd, grads64):
         torch.testing.assert_close(a.cpu().double(), r, rtol=1e-5, atol=1e-5 * float(r.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(1024, 2, 112), (829, 112, 9), (52, 112, 224), (1, 7), (3, 5), (17, 1), (1000, 4097)])
+def test_sum_partials_is_the_fixed_order_sum_over_the_first_axis(shape):
+    """_lib.sum_partials (dgcn_reduce_partials_f32): one launch, bit-reproducible, against the float64 sum."""
+    from deep_gcns_torch_amd import _lib
+    dev = _dev()
+    p = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(dev)
+    out = _lib.sum_partials(p)
+    assert out.shape == p.shape[1:]
+    ref = p.double().sum(0)
+    scale = float(p.double().abs().sum(0).max())
+    assert float((out.double() - ref).abs().max()) <= 1e-6 * max(scale, 1.0)
+    assert torch.equal(out, _lib.sum_partials(p))
+    assert torch.equal(_lib.sum_partials(p[:0]), torch.zeros_like(out))
