@@ -139,6 +139,12 @@ _SIGNATURES = {
         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dgcn_edgeconv_bwd_input_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                              C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                              C.c_void_p]),
+    "dgcn_edgeconv_bwd_weight_num_partials": (C.c_int32, [C.c_int32, C.c_int32]),
+    "dgcn_edgeconv_bwd_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
     "dgcn_reduce_partials_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -114,27 +114,50 @@ __global__ __launch_bounds__(kWgThreads) void bn_apply_kernel(const BnApplyParam
   const int n0 = tn * kTile, c0 = tc * kTile;
   const int lx = threadIdx.x % kTile;  // fast index
   const int ly = threadIdx.x / kTile;  // 0..3
-  // read: rows = points, fast = channels (coalesced along c)
-  for (int i = ly; i < kTile; i += 4) {
-    const int n = n0 + i, c = c0 + lx;
-    float v = 0.f;
-    if (n < P.N && c < P.C) {
-      const int64_t o = (static_cast<int64_t>(b) * P.N + n) * P.C + c;
-      float scale = 1.f, shift = 0.f;
-      if (P.bnbuf) { scale = P.bnbuf[c]; shift = P.bnbuf[P.C + c]; }
-      const float sel = (scale >= 0.f || !P.vmin) ? P.vmax[o] : P.vmin[o];
-      v = fmaf(scale, sel, shift);
+  // read: rows = points, fast = channels (coalesced along c).  All 16 loads of a thread are issued before the first
+  // use (clamped addresses instead of a branch around each load: a branch per element makes every load wait for its
+  // own round trip); a lane reads vmax OR vmin, whichever its channel's scale selects
+  {
+    const int c = c0 + lx;
+    const bool cok = c < P.C;
+    const int cr = cok ? c : 0;
+    float scale = 1.f, shift = 0.f;
+    if (P.bnbuf) { scale = P.bnbuf[cr]; shift = P.bnbuf[P.C + cr]; }
+    const float* __restrict__ src = (scale >= 0.f || !P.vmin) ? P.vmax : P.vmin;
+    float v[kTile / 4];
+#pragma unroll
+    for (int u = 0; u < kTile / 4; ++u) {
+      const int n = n0 + ly + 4 * u;
+      v[u] = src[(static_cast<int64_t>(b) * P.N + min(n, P.N - 1)) * P.C + cr];
     }
-    tile[i][lx] = v;
+#pragma unroll
+    for (int u = 0; u < kTile / 4; ++u) {
+      const int n = n0 + ly + 4 * u;
+      tile[ly + 4 * u][lx] = (cok && n < P.N) ? fmaf(scale, v[u], shift) : 0.f;
+    }
   }
   __syncthreads();
   // write: rows = channels, fast = points (coalesced along n)
-  for (int i = ly; i < kTile; i += 4) {
-    const int c = c0 + i, n = n0 + lx;
-    if (c < P.C && n < P.N) {
-      float v = tile[lx][i];
-      if (P.res) v = fmaf(P.res_scale, P.res[b * P.rb + c * P.rc + n * P.rn], v);
-      P.out[(static_cast<int64_t>(b) * P.C + c) * P.N + n] = v;
+  {
+    const int n = n0 + lx;
+    const bool nok = n < P.N;
+    const int nr = nok ? n : 0;
+    float rv[kTile / 4];
+    if (P.res) {
+#pragma unroll
+      for (int u = 0; u < kTile / 4; ++u) {
+        const int c = min(c0 + ly + 4 * u, P.C - 1);
+        rv[u] = P.res[b * P.rb + c * P.rc + nr * P.rn];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTile / 4; ++u) {
+      const int c = c0 + ly + 4 * u;
+      if (c < P.C && nok) {
+        float v = tile[lx][ly + 4 * u];
+        if (P.res) v = fmaf(P.res_scale, rv[u], v);
+        P.out[(static_cast<int64_t>(b) * P.C + c) * P.N + n] = v;
+      }
     }
   }
 }
@@ -162,27 +185,45 @@ __global__ __launch_bounds__(kWgThreads) void bn_bwd_prep_kernel(const BnBwdPrep
   const int lx = threadIdx.x % kTile;
   const int ly = threadIdx.x / kTile;
   for (int c0 = 0; c0 < P.C; c0 += kTile) {
-    // read g channel-major: rows = channels, fast = points
-    for (int i = ly; i < kTile; i += 4) {
-      const int c = c0 + i, n = n0 + lx;
-      float v = 0.f;
-      if (c < P.C && n < P.N) v = P.g[b * P.gb + c * P.gc + n * P.gn];
-      tile[i][lx] = v;
+    // read g channel-major: rows = channels, fast = points (all 16 loads of a thread in flight: see bn_apply_kernel)
+    {
+      const int n = n0 + lx;
+      const bool nok = n < P.N;
+      const int nr = nok ? n : 0;
+      float gv[kTile / 4];
+#pragma unroll
+      for (int u = 0; u < kTile / 4; ++u) {
+        const int c = min(c0 + ly + 4 * u, P.C - 1);
+        gv[u] = P.g[b * P.gb + c * P.gc + nr * P.gn];
+      }
+#pragma unroll
+      for (int u = 0; u < kTile / 4; ++u) tile[ly + 4 * u][lx] = (nok && c0 + ly + 4 * u < P.C) ? gv[u] : 0.f;
     }
     __syncthreads();
     float s1 = 0.f, s2 = 0.f;  // this thread: channel c0+lx, points n0+ly, +4, ...
     const int c = c0 + lx;
+    const bool cok = c < P.C;
+    const int cr = cok ? c : 0;
     float scale = 1.f;
-    if (P.bnbuf && c < P.C) scale = P.bnbuf[c];
-    for (int i = ly; i < kTile; i += 4) {
-      const int n = n0 + i;
-      if (c < P.C && n < P.N) {
-        const int64_t o = (static_cast<int64_t>(b) * P.N + n) * P.C + c;
-        const float gv = tile[lx][i];
-        const float sel = (scale >= 0.f || !P.vmin) ? P.vmax[o] : P.vmin[o];
-        P.gsel[o] = gv * scale;
-        s1 += gv;
-        s2 = fmaf(gv, sel, s2);
+    if (P.bnbuf) scale = P.bnbuf[cr];
+    {
+      const float* __restrict__ src = (scale >= 0.f || !P.vmin) ? P.vmax : P.vmin;
+      float sv[kTile / 4];
+#pragma unroll
+      for (int u = 0; u < kTile / 4; ++u) {
+        const int n = min(n0 + ly + 4 * u, P.N - 1);
+        sv[u] = src[(static_cast<int64_t>(b) * P.N + n) * P.C + cr];
+      }
+#pragma unroll
+      for (int u = 0; u < kTile / 4; ++u) {
+        const int i = ly + 4 * u;
+        const int n = n0 + i;
+        if (cok && n < P.N) {
+          const float g1 = tile[lx][i];
+          P.gsel[(static_cast<int64_t>(b) * P.N + n) * P.C + c] = g1 * scale;
+          s1 += g1;
+          s2 = fmaf(g1, sv[u], s2);
+        }
       }
     }
     if (P.partial) {

@@ -39,73 +39,168 @@ struct GemmParams {
                    //    [(W1-W2)^T | W2^T] on the fly; bias [M/2] applies to the first half only
 };
 
-constexpr int kTJ = 4;    // 16-column MFMA tiles per wave pass -> 64 output columns
-constexpr int kGemmKC = 64;  // channels staged in LDS per step
+constexpr int kGemmKC = 64;    // contraction indices (channels) per LDS tile
+constexpr int kGemmMC = 128;   // output columns per LDS tile: eight 16-column MFMA tiles per wave pass
+constexpr int kGemmPad = 16;   // row padding (floats): the four lane groups of an MFMA operand read land 16 banks apart
 
-// effective B operand: W[c][m] (plain) or the EdgeConv split [(W1-W2)^T | W2^T] formed on the fly
-__device__ __forceinline__ float gemm_b(const GemmParams& P, int k, int j) {
-  if (k >= P.C || j >= P.M) return 0.f;
-  if (P.conv_split) {
-    const int half = P.M / 2;
-    const float* wr = P.W + static_cast<int64_t>(j < half ? j : j - half) * (2 * P.C);
-    return (j < half) ? wr[k] - wr[P.C + k] : wr[P.C + k];
-  }
-  return P.W[static_cast<int64_t>(k) * P.M + j];
+// bits of v where ok, zero bits otherwise: a select that the compiler cannot turn into a branch around the load that
+// produced v (a branch per element makes every load of a tile fill wait for its own L2 round trip)
+__device__ __forceinline__ float gemm_keep(float v, bool ok) {
+  return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u));
 }
 
-__global__ __launch_bounds__(kWgThreads) void vertex_gemm_kernel(const GemmParams P) {
-  __shared__ float wt[kGemmKC][kTJ * 16];  // 16 KB: the weight tile shared by the 4 waves (= 4 point tiles)
+// Persistent workgroups: with C <= 64 one LDS tile holds the whole contraction for 128 output columns, a workgroup
+// forms it ONCE (coalesced 16-byte loads along the contiguous axis of the weight, all of a thread's loads in flight
+// together) and walks its share of the 16-point tiles under it; the A operands of a tile (16 values per lane) are loaded
+// before the tile is formed, so the two latencies overlap.  The result tile leaves through a per-wave LDS buffer as
+// whole 512-byte rows of the point-major output.  (Rounds 1 - 4: one workgroup per four point tiles, each re-forming
+// the weight tile element by element -- 64 different cache lines per load instruction for the Conv2d layout and a
+// dependent branch per element: 28 us per layer at shape D, most of it the tile fill.)
+__global__ __launch_bounds__(kWgThreads, 2) void vertex_gemm_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(16))) float wt[kGemmKC][kGemmMC + kGemmPad];       // 36 KB
+  __shared__ __attribute__((aligned(16))) float ot[kWavesPerWg][16][kGemmMC + 4];      // 33 KB: per-wave result rows
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int tiles_n = (P.N + 15) / 16;
   const int total_tiles = P.B * tiles_n;
-  const int tile = min(blockIdx.x * kWavesPerWg + wave, total_tiles - 1);  // clamp: all waves hit the barriers
-  const bool tile_ok = blockIdx.x * kWavesPerWg + wave < total_tiles;
-  const int b = tile / tiles_n;
-  const int n0 = (tile % tiles_n) * 16;
+  const int groups = (total_tiles + kWavesPerWg - 1) / kWavesPerWg;
   const int li = lane & 15, lk = lane >> 4;
-  const int n = n0 + li;
-  const bool n_ok = n < P.N;
-  const float* xa = P.x + static_cast<int64_t>(b) * P.sb + static_cast<int64_t>(min(n, P.N - 1)) * P.sn;
-  const int col_tiles = (P.M + 15) / 16;
+  const bool single = P.C <= kGemmKC;
+  const bool wvec = P.conv_split && P.C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.W) & 15u) == 0;
+  const bool ovec = P.M % 4 == 0 && (reinterpret_cast<uintptr_t>(P.out) & 15u) == 0;
+  const int half = P.M / 2;
 
-  for (int ct0 = 0; ct0 < col_tiles; ct0 += kTJ) {
-    f32x4 acc[kTJ];
+  for (int m0 = 0; m0 < P.M; m0 += kGemmMC) {
+    bool filled = false;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+      const int tile = min(grp * kWavesPerWg + wave, total_tiles - 1);    // clamp: all waves hit the barriers
+      const bool tile_ok = grp * kWavesPerWg + wave < total_tiles;
+      const int b = tile / tiles_n;
+      const int n0 = (tile % tiles_n) * 16;
+      const bool n_ok = n0 + li < P.N;
+      const float* xa = P.x + static_cast<int64_t>(b) * P.sb + static_cast<int64_t>(min(n0 + li, P.N - 1)) * P.sn;
+      f32x4 acc[8];
 #pragma unroll
-    for (int t = 0; t < kTJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < P.C; kc += kGemmKC) {
-      __syncthreads();
-      for (int e = threadIdx.x; e < kGemmKC * kTJ * 16; e += kWgThreads) {
-        const int kk = e / (kTJ * 16), jj = e % (kTJ * 16);
-        wt[kk][jj] = gemm_b(P, kc + kk, ct0 * 16 + jj);
-      }
-      __syncthreads();
-      const int kend = min(kGemmKC, P.C - kc);
-      for (int k0 = 0; k0 < kend; k0 += 4) {
-        const int k = kc + k0 + lk;
-        const float a = (k < P.C && n_ok) ? xa[static_cast<int64_t>(k) * P.sc] : 0.f;
+      for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < P.C; kc += kGemmKC) {
+        // A operands of the chunk: lane (point li, kq = lk) holds channels kc + 4 q + kq
+        float av[kGemmKC / 4];
 #pragma unroll
-        for (int t = 0; t < kTJ; ++t) {
-          const float bv = wt[k0 + lk][t * 16 + li];   // rows past C hold zeros
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[t], 0, 0, 0);
+        for (int q = 0; q < kGemmKC / 4; ++q) {
+          const int k = kc + 4 * q + lk;
+          av[q] = gemm_keep(xa[static_cast<int64_t>(min(k, P.C - 1)) * P.sc], k < P.C && n_ok);
+        }
+        if (!(single && filled)) {
+          __syncthreads();
+          if (wvec) {
+            // Conv2d weight [M/2][2C]: column j of the effective operand is row r = j mod M/2, W1[r] - W2[r] (j < M/2)
+            // or W2[r]; a wave reads four rows, 64 channels = 256 contiguous bytes each, per pass
+            const int k4 = (lane & 15) * 4;
+            float4 wa[8], wb[8];
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+              const int jj = m0 + ps * 16 + (threadIdx.x >> 4);
+              const bool ok = jj < P.M && kc + k4 < P.C;
+              const int r = ok ? (jj < half ? jj : jj - half) : 0;
+              const float* wr = P.W + static_cast<int64_t>(r) * (2 * P.C) + (ok ? kc + k4 : 0);
+              wa[ps] = *reinterpret_cast<const float4*>(wr);
+              wb[ps] = *reinterpret_cast<const float4*>(wr + P.C);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+              const int jl = ps * 16 + (threadIdx.x >> 4);
+              const int jj = m0 + jl;
+              const bool ok = jj < P.M && kc + k4 < P.C;
+              const bool top = jj < half;
+              wt[k4][jl] = ok ? (top ? wa[ps].x - wb[ps].x : wb[ps].x) : 0.f;
+              wt[k4 + 1][jl] = ok ? (top ? wa[ps].y - wb[ps].y : wb[ps].y) : 0.f;
+              wt[k4 + 2][jl] = ok ? (top ? wa[ps].z - wb[ps].z : wb[ps].z) : 0.f;
+              wt[k4 + 3][jl] = ok ? (top ? wa[ps].w - wb[ps].w : wb[ps].w) : 0.f;
+            }
+          } else {
+            constexpr int kPer = 8;
+            for (int e0 = threadIdx.x; e0 < kGemmKC * kGemmMC; e0 += kWgThreads * kPer) {
+              float v[kPer];
+#pragma unroll
+              for (int u = 0; u < kPer; ++u) {
+                const int e = e0 + u * kWgThreads;
+                const int kk = e / kGemmMC, jl = e % kGemmMC;
+                const int k = kc + kk, jj = m0 + jl;
+                const bool ok = k < P.C && jj < P.M;
+                const int kr = ok ? k : 0, jr = ok ? jj : 0;
+                if (P.conv_split) {                              // (uniform over the launch)
+                  const bool top = jr < half;
+                  const float* wr = P.W + static_cast<int64_t>(top ? jr : jr - half) * (2 * P.C);
+                  const float w1 = wr[kr], w2 = wr[P.C + kr];
+                  v[u] = gemm_keep(top ? w1 - w2 : w2, ok);
+                } else {
+                  v[u] = gemm_keep(P.W[static_cast<int64_t>(kr) * P.M + jr], ok);
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < kPer; ++u) {
+                const int e = e0 + u * kWgThreads;
+                wt[e / kGemmMC][e % kGemmMC] = v[u];
+              }
+            }
+          }
+          __syncthreads();
+          filled = true;
+        }
+#pragma unroll
+        for (int q = 0; q < kGemmKC / 4; ++q) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float bv = wt[4 * q + lk][t * 16 + li];        // rows past C and columns past M hold zeros
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv, acc[t], 0, 0, 0);
+          }
         }
       }
-    }
-    if (tile_ok) {
+      // acc[t][r] = out row n0 + 4 lk + r, column m0 + 16 t + li
+      if (ovec) {
 #pragma unroll
-      for (int t = 0; t < kTJ; ++t) {
-        const int j = (ct0 + t) * 16 + li;
-        if (j < P.M) {
-          const float bj = (P.bias && (!P.conv_split || j < P.M / 2)) ? P.bias[j] : 0.f;
+        for (int t = 0; t < 8; ++t) {
+          const int j = m0 + t * 16 + li;
+          const float bj = (P.bias && j < P.M && (!P.conv_split || j < half)) ? P.bias[j] : 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = n0 + lk * 4 + r;
-            if (row < P.N) P.out[(static_cast<int64_t>(b) * P.N + row) * P.M + j] = acc[t][r] + bj;
+          for (int r = 0; r < 4; ++r) ot[wave][lk * 4 + r][t * 16 + li] = acc[t][r] + bj;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int idx = ps * kWave + lane;
+          const int row = idx >> 5, c4 = (idx & 31) * 4;
+          if (tile_ok && n0 + row < P.N && m0 + c4 < P.M) {
+            *reinterpret_cast<float4*>(P.out + (static_cast<int64_t>(b) * P.N + n0 + row) * P.M + m0 + c4) =
+                *reinterpret_cast<const float4*>(&ot[wave][row][c4]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else if (tile_ok) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int j = m0 + t * 16 + li;
+          if (j < P.M) {
+            const float bj = (P.bias && (!P.conv_split || j < half)) ? P.bias[j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = n0 + lk * 4 + r;
+              if (row < P.N) P.out[(static_cast<int64_t>(b) * P.N + row) * P.M + j] = acc[t][r] + bj;
+            }
           }
         }
       }
     }
   }
+}
+
+int gemm_grid(int64_t tiles) {
+  const int64_t groups = (tiles + kWavesPerWg - 1) / kWavesPerWg;
+  return static_cast<int>(groups < 2 * kNumCU ? groups : 2 * kNumCU);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -606,8 +701,7 @@ extern "C" int dgcn_vertex_gemm_f32(const float* x, int64_t sb, int64_t sc, int6
   if (B < 0 || C <= 0 || N <= 0 || M <= 0) return DGCN_E_SHAPE;
   if (B == 0) return DGCN_OK;
   GemmParams P{x, sb, sc, sn, B, C, N, M, W, bias, out, 0};
-  const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
-  const int grid = static_cast<int>((tiles + kWavesPerWg - 1) / kWavesPerWg);
+  const int grid = gemm_grid(static_cast<int64_t>(B) * ((N + 15) / 16));
   hipLaunchKernelGGL(vertex_gemm_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
   return launch_status();
 }
@@ -621,8 +715,7 @@ extern "C" int dgcn_edgeconv_pq_f32(const float* x, int64_t sb, int64_t sc, int6
   if (B < 0 || C <= 0 || N <= 0 || Cout <= 0) return DGCN_E_SHAPE;
   if (B == 0) return DGCN_OK;
   GemmParams P{x, sb, sc, sn, B, C, N, 2 * Cout, conv_w, bias, out, 1};
-  const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
-  const int grid = static_cast<int>((tiles + kWavesPerWg - 1) / kWavesPerWg);
+  const int grid = gemm_grid(static_cast<int64_t>(B) * ((N + 15) / 16));
   hipLaunchKernelGGL(vertex_gemm_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
   return launch_status();
 }

@@ -18,6 +18,8 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 USE_INVERSE_LISTS = True      # dense edge backward: dQ through inverse neighbour lists (False: LDS-privatised atomics)
+EDGECONV_BWD_KERNELS = True   # EdgeConv2d's dx and [dW | db] from dP | dQ in csrc/edgeconv_bwd.hip (False: rounds 1 - 4's
+                              # library calls -- sub, cat, baddbmm, permute-copy, split-K bmm, three sums: A/B measurements)
 USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fallback inside the library)
 KNN_BF16_PIPE = True    # distance tiles of the filter pass on the bf16 matrix pipe (C in {32, 64}); False: fp32 MFMA (A/B)
 
@@ -446,6 +448,35 @@ class _EdgeConv2dFused(torch.autograd.Function):
                                                      dPQ.data_ptr() + 4 * Cout, 2 * Cout, stream),
                            "dgcn_reduce_parts_f32")
         gx = gW = gb = ggamma = gbeta = None
+        if EDGECONV_BWD_KERNELS:
+            want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+            with _lib.device_ctx(dev):
+                if ctx.needs_input_grad[0]:
+                    gx3 = torch.empty(B, C, N, device=dev, dtype=torch.float32)
+                    res = ctx.res_scale is not None
+                    _lib.check(lib.dgcn_edgeconv_bwd_input_f32(
+                        dPQ.data_ptr(), W2.data_ptr(), g3.data_ptr() if res else None, g3.stride(0), g3.stride(1),
+                        g3.stride(2), float(ctx.res_scale) if res else 0.0, B, C, N, Cout, gx3.data_ptr(), stream),
+                        "dgcn_edgeconv_bwd_input_f32")
+                    gx = gx3.reshape(x_shape)
+                if want_w:
+                    wparts = torch.empty(lib.dgcn_edgeconv_bwd_weight_num_partials(B, N), Cout * 2 * C + Cout,
+                                         device=dev, dtype=torch.float32)
+                    _lib.check(lib.dgcn_edgeconv_bwd_weight_f32(
+                        dPQ.data_ptr(), x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, Cout,
+                        wparts.data_ptr(), stream), "dgcn_edgeconv_bwd_weight_f32")
+            if want_w:
+                wsum = _lib.sum_partials(wparts)             # [dW1 | dW2] in the weight's layout, then db
+                if ctx.needs_input_grad[1]:
+                    gW = wsum[:Cout * 2 * C].view(w_shape)
+                if has_bias and ctx.needs_input_grad[2]:
+                    gb = wsum[Cout * 2 * C:]
+            if has_bn and gamma is not None:
+                if ctx.needs_input_grad[3]:
+                    ggamma = coef[0]
+                if ctx.needs_input_grad[4]:
+                    gbeta = coef[1]
+            return (gx, gW, gb, ggamma, gbeta) + (None,) * 11
         w1, w2h = W2[:, :C], W2[:, C:]
         if ctx.needs_input_grad[0]:
             wc = torch.cat([w1 - w2h, w2h], dim=0)                          # (2Cout, C)

@@ -509,6 +509,22 @@ int dgcn_dense_edge_reduce_bwd_inv_f32(const float* P, int64_t ldp, const float*
                                        const float* gsq, const float* sel_scale, float* dP, float* dQ,
                                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* What is left of EdgeConv2d's backward once dPQ [B][N][2 Cout] = [dP | dQ] exists (P = (W1 - W2) x + b, Q = W2 x with
+ * conv_w = [W1 | W2] the (Cout, 2C, 1, 1) Conv2d weight of BasicConv: gcn_lib/dense/torch_vertex.py:31-35,
+ * gcn_lib/dense/torch_nn.py:48-60; the reference's autograd runs conv2d_backward over the (B, 2C, N, k) edge tensor).
+ *   dgcn_edgeconv_bwd_input_f32:  dx [B][C][N] = (W1 - W2)^T dP + W2^T dQ (+ res_scale * g: the skip connection of
+ *       ResDynBlock2d, torch_vertex.py:101; g = the upstream gradient (B, C, N) with element strides, or NULL).
+ *   dgcn_edgeconv_bwd_weight_f32: partials [dgcn_edgeconv_bwd_weight_num_partials(B, N)][Cout * 2C + Cout], each block
+ *       = [dW1 | dW2] in conv_w's layout (dW1 = dP^T x, dW2 = (dQ - dP)^T x) followed by db = sum dP, over that
+ *       workgroup's points; x (B, C, N) with element strides.  Sum the blocks with dgcn_reduce_partials_f32.
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32: an fma chain), fixed order, any C / Cout. */
+int dgcn_edgeconv_bwd_input_f32(const float* dpq, const float* conv_w, const float* g, int64_t gsb, int64_t gsc,
+                                int64_t gsn, float res_scale, int32_t B, int32_t C, int32_t N, int32_t Cout, float* dx,
+                                void* stream);
+int32_t dgcn_edgeconv_bwd_weight_num_partials(int32_t B, int32_t N);
+int dgcn_edgeconv_bwd_weight_f32(const float* dpq, const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
+                                 int32_t C, int32_t N, int32_t Cout, float* partials, void* stream);
+
 /* dst[row*ld + c] = sum_s parts[s][row][c]  (fixed order; C % 4 == 0): combines the dq_parts of the
  * atomic-free edge backward into the Q half of the vertex-GEMM gradient. */
 int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int32_t C, float* dst, int64_t ld,
