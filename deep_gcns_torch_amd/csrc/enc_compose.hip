@@ -15,6 +15,14 @@ namespace {
 
 constexpr int kCmpF = 16;      // raw edge features supported (F <= 16; the reference's models have 8)
 
+// v where ok, +0 otherwise, as integer bits: a select the compiler cannot turn back into a branch around the load that
+// produced v.  (`if (f < F) acc = fma(w, We[..], acc)` compiled to a branch per element with a full wait behind each
+// load -- 64 dependent L2 round trips per wave, 9 us for 200 k multiply-adds; with clamped addresses the 17 loads of an
+// iteration are in flight together.)
+__device__ __forceinline__ float cmp_keep(float v, bool ok) {
+  return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u));
+}
+
 // W'[c][f] = sum_h Wl[c][h] We[h][f],  b'[c] = sum_h Wl[c][h] be[h] + bl[c].  One wave per row c, lanes over h.
 __global__ __launch_bounds__(kWave) void enc_compose_fwd_kernel(const float* __restrict__ Wl, const float* __restrict__ bl,
                                                                 const float* __restrict__ We, const float* __restrict__ be,
@@ -26,11 +34,12 @@ __global__ __launch_bounds__(kWave) void enc_compose_fwd_kernel(const float* __r
   for (int f = 0; f <= kCmpF; ++f) acc[f] = 0.f;
   for (int h = lane; h < H; h += kWave) {
     const float w = Wl[static_cast<int64_t>(c) * H + h];
+    float e[kCmpF + 1];
 #pragma unroll
-    for (int f = 0; f < kCmpF; ++f) {
-      if (f < F) acc[f] = fmaf(w, We[static_cast<int64_t>(h) * F + f], acc[f]);
-    }
-    if (be) acc[kCmpF] = fmaf(w, be[h], acc[kCmpF]);
+    for (int f = 0; f < kCmpF; ++f) e[f] = cmp_keep(We[static_cast<int64_t>(h) * F + min(f, F - 1)], f < F);
+    e[kCmpF] = cmp_keep((be ? be : Wl)[h], be != nullptr);       // (Wl: any readable address of >= H floats)
+#pragma unroll
+    for (int f = 0; f <= kCmpF; ++f) acc[f] = fmaf(w, e[f], acc[f]);
   }
 #pragma unroll
   for (int f = 0; f <= kCmpF; ++f) {
@@ -59,14 +68,15 @@ __global__ __launch_bounds__(kWave) void enc_compose_bwd_kernel(const float* __r
     if (!dWl) return;
     float g[kCmpF];
 #pragma unroll
-    for (int f = 0; f < kCmpF; ++f) g[f] = f < F ? dWc[static_cast<int64_t>(c) * F + f] : 0.f;
+    for (int f = 0; f < kCmpF; ++f) g[f] = cmp_keep(dWc[static_cast<int64_t>(c) * F + min(f, F - 1)], f < F);
     const float gb = (dbc && be) ? dbc[c] : 0.f;
     for (int h = lane; h < H; h += kWave) {
+      float e[kCmpF];
+#pragma unroll
+      for (int f = 0; f < kCmpF; ++f) e[f] = We[static_cast<int64_t>(h) * F + min(f, F - 1)];   // (g[f] = 0 past F)
       float a = (be ? gb * be[h] : 0.f);
 #pragma unroll
-      for (int f = 0; f < kCmpF; ++f) {
-        if (f < F) a = fmaf(g[f], We[static_cast<int64_t>(h) * F + f], a);
-      }
+      for (int f = 0; f < kCmpF; ++f) a = fmaf(g[f], e[f], a);
       dWl[static_cast<int64_t>(c) * H + h] = a;
     }
     return;
@@ -78,11 +88,12 @@ __global__ __launch_bounds__(kWave) void enc_compose_bwd_kernel(const float* __r
   for (int f = 0; f <= kCmpF; ++f) acc[f] = 0.f;
   for (int c = lane; c < C; c += kWave) {
     const float w = Wl[static_cast<int64_t>(c) * H + h];
+    float e[kCmpF + 1];
 #pragma unroll
-    for (int f = 0; f < kCmpF; ++f) {
-      if (f < F) acc[f] = fmaf(w, dWc[static_cast<int64_t>(c) * F + f], acc[f]);
-    }
-    if (dbc) acc[kCmpF] = fmaf(w, dbc[c], acc[kCmpF]);
+    for (int f = 0; f < kCmpF; ++f) e[f] = cmp_keep(dWc[static_cast<int64_t>(c) * F + min(f, F - 1)], f < F);
+    e[kCmpF] = cmp_keep((dbc ? dbc : dWc)[c], dbc != nullptr);    // (dWc: any readable address of >= C floats)
+#pragma unroll
+    for (int f = 0; f <= kCmpF; ++f) acc[f] = fmaf(w, e[f], acc[f]);
   }
 #pragma unroll
   for (int f = 0; f <= kCmpF; ++f) {
