@@ -1457,11 +1457,20 @@ size_t knn_prep_lds_bytes(int C) {
 }
 
 // rank of the ns-sample threshold for a list capacity `cap` (see the comment at the call site)
+// Margin of the sample threshold above K, in units of sqrt(unit * K) (unit = N / samples).  The number of candidates
+// below the r-th smallest of ns uniformly placed samples is r + BetaBinomial(N - ns, r, ns - r + 1) whatever the data:
+// with the 3.2 of rounds 3 - 4 between 0.6 and 5 of the 32,768 rows of a config-2 layer were expected to end with fewer
+// than K candidates, and ONE such row costs a launch of the exact kernel with real work (30 - 39 us instead of 4.6 us:
+// measured per dilation, profiles/r05_knn_by_dilation.md).  4.0 (4.8 below eight sample ranks, where the relative spread
+// is largest) brings the expectation under 0.25 (0.01) rows per layer; where the list capacity is too close for any
+// rank to clear both ends (cap 512 from K = 128 on) nothing changes: the mid-point clamp below decides.
+inline double knn_z(double ranks_of_k) { return ranks_of_k < 8.0 ? 4.8 : 4.0; }
+
 int knn_sample_rank(int N, int K, int cap, int nsamples = kFSamples) {
   const double ns = nsamples, unit = N / ns;
   const double r0 = K / unit;
   const double sd0 = unit * sqrt(r0 > 1.0 ? r0 : 1.0);
-  double target = K + 3.2 * sd0 + 2.0 * unit;
+  double target = K + knn_z(r0) * sd0 + 2.0 * unit;
   const double mid = 0.5 * (K + static_cast<double>(cap));
   if (target > mid) target = mid;
   const int r = static_cast<int>(ceil(target / unit));
