@@ -89,10 +89,13 @@ def res_plus_layer(norm, conv, h, edge_index, edge_attr=None, p: float = 0.0, tr
             # (edge features are an INPUT of the checkpoint, as in the reference's checkpoint(self.gcns[layer], h2,
             # edge_index, edge_emb): a tensor with history must not be reached through a closure, its graph would be
             # walked once per layer)
+            # (h_ enters this function for the skip connection only: its gradient may leave as a view of the upstream one)
             if stash is None:
-                out = _conv_res(conv, h2_, edge_index, ea_, h_, want_stats)
+                with node_ops.residual_gradient_is_last_use():
+                    out = _conv_res(conv, h2_, edge_index, ea_, h_, want_stats)
             else:
-                with ops.stash_aggregation(stash, "replay" if torch.is_grad_enabled() else "record"):
+                with ops.stash_aggregation(stash, "replay" if torch.is_grad_enabled() else "record"), \
+                        node_ops.residual_gradient_is_last_use():
                     out = _conv_res(conv, h2_, edge_index, ea_, h_, want_stats)
             return out if want_stats else (out, None)
         # the second output (statistics) is not differentiable; checkpoint hands it through

@@ -19,6 +19,8 @@ sweep (gcn_lib/sparse/torch_nn.py:50-71, gcn_lib/sparse/torch_vertex.py:70-76).
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 from torch import nn
@@ -457,9 +459,35 @@ def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum, out=None):
     return y, stats, xsum
 
 
+class _ResidualGradView(threading.local):
+    on = False
+
+
+_RES_GRAD_VIEW = _ResidualGradView()
+
+
+class residual_gradient_is_last_use:
+    """``with residual_gradient_is_last_use():`` -- the caller promises that the ``residual`` tensors of the
+    ``rows_linear`` calls inside have NO other consumer in the graph being recorded (``blocks.res_plus_layer`` inside
+    its checkpoint: ``h`` enters the recomputed function for the skip connection only).  Their gradient -- the upstream
+    gradient itself -- is then handed on as a fresh view object, which a leaf can take over instead of cloning it: the
+    reentrant ``torch.utils.checkpoint`` copied the (N, C) skip gradient once per layer (26 x 87 MB per DeeperGCN-28
+    step).  Without the promise the gradient is returned as it came: a view stolen by a leaf that a second consumer
+    then accumulates into in place would overwrite the upstream gradient."""
+
+    def __enter__(self):
+        self.prev, _RES_GRAD_VIEW.on = _RES_GRAD_VIEW.on, True
+        return self
+
+    def __exit__(self, *exc):
+        _RES_GRAD_VIEW.on = self.prev
+        return False
+
+
 class _RowsLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, want_stats: bool):
+        ctx.res_view = _RES_GRAD_VIEW.on
         w = weight.detach()
         b = None if bias is None else bias.detach().float().contiguous()
         y, stats, _ = _rl_launch(x, w, False, b, residual, False, want_stats, False)
@@ -493,7 +521,9 @@ class _RowsLinear(torch.autograd.Function):
             gw = rows_tn(g, x)
         if need_b and gb is None:
             gb = g.sum(0)
-        gres = g if ctx.needs_input_grad[3] else None
+        gres = None
+        if ctx.needs_input_grad[3]:
+            gres = g.view_as(g) if ctx.res_view else g      # (see residual_gradient_is_last_use)
         return gx, gw, gb, gres, None
 
 

@@ -539,3 +539,42 @@ def test_sum_partials_is_the_fixed_order_sum_over_the_first_axis(shape):
     assert float((out.double() - ref).abs().max()) <= 1e-6 * max(scale, 1.0)
     assert torch.equal(out, _lib.sum_partials(p))
     assert torch.equal(_lib.sum_partials(p[:0]), torch.zeros_like(out))
+
+
+def test_residual_gradient_view_scope_keeps_the_upstream_gradient_intact():
+    """node_ops.residual_gradient_is_last_use: inside it the residual's gradient leaves rows_linear as a view of the
+    upstream gradient (a leaf takes it over instead of cloning it); outside it -- or with a second consumer of the
+    residual -- gradients accumulate as usual and the upstream gradient is never written to."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    torch.manual_seed(3)
+    rows, K, C = 4099, 64, 64
+    x = torch.randn(rows, K, device=dev)
+    w = torch.randn(C, K, device=dev, requires_grad=True)
+    b = torch.randn(C, device=dev, requires_grad=True)
+    probe = torch.randn(rows, C, device=dev)
+
+    def run(scoped, twice):
+        r = torch.randn(rows, C, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).requires_grad_(True)
+        w.grad = b.grad = None
+        if scoped:
+            with node_ops.residual_gradient_is_last_use():
+                y = node_ops.rows_linear(x, w, b, residual=r)
+        else:
+            y = node_ops.rows_linear(x, w, b, residual=r)
+        g_seen = {}
+
+        def keep(g):
+            g_seen["g"] = g
+
+        y.register_hook(keep)
+        loss = (y * probe).sum() + ((r * 2.0).sum() if twice else 0.0)
+        loss.backward()
+        return r.grad, g_seen["g"]
+
+    for scoped, twice in ((False, False), (False, True), (True, False)):
+        rg, g = run(scoped, twice)
+        assert torch.equal(g, probe)                                   # the upstream gradient is what it was
+        assert torch.equal(rg, probe + 2.0 if twice else probe), (scoped, twice)
+        if scoped:
+            assert rg.data_ptr() == g.data_ptr()                       # taken over, not cloned
