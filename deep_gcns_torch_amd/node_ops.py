@@ -488,6 +488,7 @@ class _RowsLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, want_stats: bool):
         ctx.res_view = _RES_GRAD_VIEW.on
+        ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) statistics output
         w = weight.detach()
         b = None if bias is None else bias.detach().float().contiguous()
         y, stats, _ = _rl_launch(x, w, False, b, residual, False, want_stats, False)
@@ -501,6 +502,8 @@ class _RowsLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gstats):
         from .nn_util import splitk_xt_g
+        if g is None:
+            return None, None, None, None, None
         x, weight = ctx.saved_tensors
         g = g.float()
         if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
