@@ -2,7 +2,7 @@
 # Round 5: the full GPU suite, smoke, the driver-style default bench, RevGCN-8 kernel breakdown.  Writes gpurun_out/r5e/*
 set -u
 R=$PWD
-out=$R/gpurun_out/r5g
+out=$R/gpurun_out/r5h
 mkdir -p $out
 export PYTHONUNBUFFERED=1
 echo "== full GPU suite (the driver's command, without -x)" | tee $out/00_index.log
