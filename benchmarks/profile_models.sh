@@ -2,7 +2,7 @@
 # Per-step kernel statistics of benchmarks/model_steps.py models (3 and 13 steps each, differenced by
 # profiles/diff_stats.py):   bash benchmarks/profile_models.sh OUTDIR MODEL [MODEL ...]
 R=$PWD
-O=$1; shift
+O=$(realpath -m "$1"); shift      # (absolute: the runs below happen in /tmp)
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
