@@ -23,6 +23,9 @@ SHAPES = [  # B, C, N, Cout
     (1, 4, 17, 4),
     (2, 33, 70, 18),        # odd C: 2C = 66, the scalar load path of the input kernel (K = 36 is a multiple of 4)
     (1, 16, 64, 7),         # K = 14: not a multiple of 4
+    (2, 96, 128, 80),       # N % 64 == 0 with 2 Cout > 128 and C > 64: the staged store under the chunked contraction,
+                            # two channel blocks; the weight kernel's 16-byte loads with two row and two channel blocks
+    (1, 64, 64, 72),        # 2 Cout = 144: one point-tile group, contraction in two chunks
 ]
 
 
