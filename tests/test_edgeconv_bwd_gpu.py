@@ -112,7 +112,10 @@ def test_edgeconv_backward_argument_checks():
     assert lib.dgcn_edgeconv_bwd_weight_num_partials(0, 5) == 0
 
 
-@pytest.mark.parametrize("B,C,N,Cout,k,res", [(2, 64, 1024, 64, 16, 1.0), (2, 9, 600, 64, 8, None), (1, 24, 333, 40, 5, None)])
+@pytest.mark.parametrize("B,C,N,Cout,k,res", [(2, 64, 1024, 64, 16, 1.0), (2, 9, 600, 64, 8, None), (1, 24, 333, 40, 5, None),
+                                              # C > 64 and 2 Cout > 128: the P | Q producer's chunked contraction and
+                                              # second column block, the backward kernels' second blocks
+                                              (1, 96, 256, 80, 6, None), (2, 80, 128, 80, 4, 0.5)])
 @pytest.mark.parametrize("norm", ["batch", None])
 def test_edgeconv_layer_gradients_match_the_float64_graph_and_the_library_glue(B, C, N, Cout, k, res, norm):
     """The whole layer (forward + backward through the C ABI) against the reference's formulation in float64, and the
