@@ -148,6 +148,8 @@ _SIGNATURES = {
     "dgcn_reduce_parts_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                         C.c_void_p]),
     "dgcn_reduce_partials_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dgcn_reduce_partials_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]),
     "dgcn_rows_num_partials": (C.c_int32, [C.c_int64, C.c_int32]),
     "dgcn_rows_stats_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dgcn_rows_bn_apply_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -245,6 +247,24 @@ def sum_partials(parts: "torch.Tensor") -> "torch.Tensor":
         check(lib.dgcn_reduce_partials_f32(parts.data_ptr(), nparts, width, out.data_ptr(), current_stream_handle(dev)),
               "dgcn_reduce_partials_f32")
     return out
+
+
+def sum_partials_split(parts: "torch.Tensor"):
+    """``parts.sum(0)`` of a contiguous fp32 (nparts, rows, inner) block as two contiguous tensors: ``[:, :-1]`` (rows,
+    inner - 1) and ``[:, -1]`` (rows,) -- one launch, no slicing copies (dgcn_reduce_partials_split_f32)."""
+    lib = load()
+    nparts, rows, inner = parts.shape
+    dev = parts.device
+    out = torch.empty(rows, inner - 1, device=dev, dtype=torch.float32)
+    last = torch.empty(rows, device=dev, dtype=torch.float32)
+    if rows == 0:
+        return out, last
+    if nparts == 0:
+        return out.zero_(), last.zero_()
+    with device_ctx(dev):
+        check(lib.dgcn_reduce_partials_split_f32(parts.data_ptr(), nparts, rows, inner, out.data_ptr(), last.data_ptr(),
+                                                 current_stream_handle(dev)), "dgcn_reduce_partials_split_f32")
+    return out, last
 
 
 def ptr(t) -> int | None:

@@ -17,8 +17,13 @@ __global__ void axpy_kernel(float a, const float* __restrict__ x, float* __restr
 // s = w, w + 16, ... with four independent accumulators each and meet in LDS in wave order (four waves: 16.5 us per launch
 // at 1024 x 224 -- the loads of one wave are a dependent chain).
 constexpr int kRpWaves = 16;
+// With out_last (dgcn_reduce_partials_split_f32) the summed block is read as [rows][inner] and leaves as two contiguous
+// arrays: columns 0 .. inner - 2 of every row in out [rows][inner - 1], the last column in out_last [rows] -- the
+// (C, F + 1) = [dW | db] blocks of the per-edge encoder, whose two halves autograd wants as separate contiguous tensors
+// (slicing the summed block cost two copy launches per coupling function).
 __global__ __launch_bounds__(kRpWaves * 64) void reduce_partials_kernel(const float* __restrict__ parts, int nparts, int64_t width,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, float* __restrict__ out_last,
+                                                               int inner) {
   __shared__ float red[kRpWaves][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t col = static_cast<int64_t>(blockIdx.x) * 64 + lane;
@@ -39,7 +44,14 @@ __global__ __launch_bounds__(kRpWaves * 64) void reduce_partials_kernel(const fl
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < kRpWaves; ++w) t += red[w][lane];
-    out[col] = t;
+    if (out_last) {
+      const int64_t r = col / inner;
+      const int f = static_cast<int>(col - r * inner);
+      if (f == inner - 1) out_last[r] = t;
+      else out[r * (inner - 1) + f] = t;
+    } else {
+      out[col] = t;
+    }
   }
 }
 
@@ -50,7 +62,18 @@ extern "C" int dgcn_reduce_partials_f32(const float* parts, int32_t nparts, int6
   if (nparts < 0 || width < 0) return DGCN_E_SHAPE;
   if (width == 0) return DGCN_OK;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + 63) / 64)), dim3(kRpWaves * 64), 0,
-                     static_cast<hipStream_t>(stream), parts, nparts, width, out);
+                     static_cast<hipStream_t>(stream), parts, nparts, width, out, static_cast<float*>(nullptr), 1);
+  return dgcn::launch_status();
+}
+
+extern "C" int dgcn_reduce_partials_split_f32(const float* parts, int32_t nparts, int64_t rows, int32_t inner, float* out,
+                                              float* out_last, void* stream) {
+  if (!parts || !out || !out_last) return DGCN_E_NULL;
+  if (nparts < 0 || rows < 0 || inner < 2) return DGCN_E_SHAPE;
+  const int64_t width = rows * inner;
+  if (width == 0) return DGCN_OK;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + 63) / 64)), dim3(kRpWaves * 64), 0,
+                     static_cast<hipStream_t>(stream), parts, nparts, width, out, out_last, inner);
   return dgcn::launch_status();
 }
 

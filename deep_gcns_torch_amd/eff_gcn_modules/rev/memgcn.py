@@ -12,6 +12,13 @@ from .gcn_revop import InvertibleModuleWrapper  # noqa: F401  (model_rev.py reac
 __all__ = ["GroupAdditiveCoupling", "InvertibleModuleWrapper"]
 
 
+
+def _sum_of(parts):
+    """``sum(parts)`` without the launch for ``0 + parts[0]`` when there is one part (group = 2: the input of F_0 is the
+    other group itself, the same values bit for bit).  For passes that record no graph only."""
+    return parts[0] if len(parts) == 1 else sum(parts)
+
+
 class GroupAdditiveCoupling(torch.nn.Module):
     def __init__(self, Fms, split_dim=-1, group=2):
         super().__init__()
@@ -36,8 +43,11 @@ class GroupAdditiveCoupling(torch.nn.Module):
         equal up to the rounding of the reconstruction)."""
         xs = torch.chunk(x, self.group, dim=self.split_dim)
         extra = self._arg_chunks(args)
-        y_in = sum(xs[1:])
         if not torch.is_grad_enabled() and x.dim() == 2 and self.split_dim in (-1, 1):
+            # (no graph is recorded here: with one other group its view serves as F_0's input, no ``0 + x`` launch.  Where a
+            #  graph IS recorded the fresh tensor is needed: a view of a buffer that is written to afterwards -- the
+            #  column blocks of x in fused_backward -- fails autograd's version check of the saved input)
+            y_in = _sum_of(xs[1:])
             # the reversible wrapper's forward (no graph): every y_i is written straight into its columns of the result
             y = torch.empty_like(x)
             for i, yv in enumerate(torch.chunk(y, self.group, dim=1)):
@@ -48,6 +58,7 @@ class GroupAdditiveCoupling(torch.nn.Module):
                         y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
             return y
         ys = []
+        y_in = sum(xs[1:])
         for i in range(self.group):
             y_in = xs[i] + self.Fms[i](y_in, edge_index, *extra[i])
             ys.append(y_in)

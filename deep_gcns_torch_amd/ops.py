@@ -476,11 +476,11 @@ class _GenAggregate(torch.autograd.Function):
                         _lib.ptr(grad_ea), _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
             _lib.check(rc, "dgcn_gen_aggr_enc_bwd_f32" if enc is not None else "dgcn_gen_aggr_bwd_f32")
             if enc is not None:
-                gsum = _lib.sum_partials(gpart)          # fixed-order partials -> (C, 9) = dW | db, one launch
+                gw_sum, gb_sum = _lib.sum_partials_split(gpart)     # fixed-order partials -> dW (C, 8) and db (C,), one launch
                 if ctx.needs_input_grad[15]:
-                    grad_w = gsum[:, :ENC_FEATURES].contiguous()
+                    grad_w = gw_sum
                 if b_enc is not None and ctx.needs_input_grad[16]:
-                    grad_b = gsum[:, ENC_FEATURES].contiguous()
+                    grad_b = gb_sum
             if winners:
                 feat, w_enc, b_enc = ctx.enc
                 if b_enc is not None and ctx.needs_input_grad[16]:
@@ -516,11 +516,11 @@ class _GenAggregate(torch.autograd.Function):
                                                            feat.data_ptr(),
                                                            ENC_FEATURES, C, gpart.data_ptr(),
                                                            _lib.current_stream_handle(dev)), "dgcn_enc_max_bwd_weight_f32")
-            gsum = _lib.sum_partials(gpart)
+            gw_sum, gb_sum = _lib.sum_partials_split(gpart)
             if ctx.needs_input_grad[15]:
-                grad_w = gsum[:, :ENC_FEATURES].contiguous()
+                grad_w = gw_sum
             if b_enc is not None and ctx.needs_input_grad[16]:
-                grad_b = gsum[:, ENC_FEATURES].contiguous()
+                grad_b = gb_sum
         if winners and (ctx.needs_input_grad[14] or ctx.needs_input_grad[15]):
             feat, w_enc, b_enc = ctx.enc
             n_feat = feat.size(1)

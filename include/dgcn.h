@@ -536,6 +536,11 @@ int dgcn_reduce_parts_f32(const float* parts, int32_t nsplit, int64_t rows, int3
  * dgcn_rows_linear_f32's EPI = 2) -- what autograd's sum over the workgroup axis does in the reference's graph, in one launch
  * instead of torch's memset + reduce pair.  Bit-reproducible. */
 int dgcn_reduce_partials_f32(const float* parts, int32_t nparts, int64_t width, float* out, void* stream);
+/* The same sum over blocks of shape [rows][inner], leaving as two contiguous arrays: out [rows][inner - 1] (all columns but
+ * the last) and out_last [rows] (the last column): the [dW | db] blocks of dgcn_gen_aggr_enc_bwd_f32 /
+ * dgcn_enc_max_bwd_weight_f32 as the weight and bias gradients autograd hands on.  inner >= 2. */
+int dgcn_reduce_partials_split_f32(const float* parts, int32_t nparts, int64_t rows, int32_t inner, float* out,
+                                   float* out_last, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Node-wise BatchNorm1d on row-major (rows, C) features, optional fused ReLU  (SURVEY.md §8 f1).

@@ -578,3 +578,17 @@ def test_residual_gradient_view_scope_keeps_the_upstream_gradient_intact():
         assert torch.equal(rg, probe + 2.0 if twice else probe), (scoped, twice)
         if scoped:
             assert rg.data_ptr() == g.data_ptr()                       # taken over, not cloned
+
+
+@pytest.mark.parametrize("shape", [(829, 112, 9), (52, 64, 9), (3, 5, 2), (1024, 7, 17), (1, 1, 2)])
+def test_sum_partials_split_leaves_the_last_column_apart(shape):
+    """_lib.sum_partials_split (dgcn_reduce_partials_split_f32) = sum_partials followed by the two slices, bit for bit."""
+    from deep_gcns_torch_amd import _lib
+    dev = _dev()
+    p = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(dev)
+    whole = _lib.sum_partials(p)
+    a, b = _lib.sum_partials_split(p)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == (shape[1], shape[2] - 1) and b.shape == (shape[1],)
+    assert torch.equal(a, whole[:, :-1]) and torch.equal(b, whole[:, -1])
+    a0, b0 = _lib.sum_partials_split(p[:0])
+    assert not a0.any() and not b0.any()
