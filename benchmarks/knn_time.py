@@ -16,10 +16,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--lds-lists", action="store_true", help="rounds 4 - 5's 16-row kernel with LDS lists")
     a = ap.parse_args()
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
     from gcn_lib.dense import DenseDilatedKnnGraph
+    from deep_gcns_torch_amd import dense_ops
+    dense_ops.KNN_GLOBAL_LISTS = not a.lds_lists
     torch.manual_seed(0)
     x = torch.randn(8, 64, 4096, 1, device="cuda:0")
     out = {}

@@ -38,6 +38,7 @@ struct KnnParams {
                        // point-major (written by knn_planes_kernel), or null
   float* sqnorm;       // [B*N] |x_j|^2 (fma chain over channels), written by knn_prep_kernel for the filter pass
   uint32_t* tau;       // [B*N] per-row sample threshold (ordered-uint key), written by knn_prep_kernel
+  uint2* lists;        // knn_filter2_kernel: [B*N][kF2Cap] (key, id) candidate lists in global memory, or null
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
@@ -840,19 +841,12 @@ __device__ __forceinline__ bool bucket_select(const KnnParams& P, const uint32_t
   return true;
 }
 
+// The select of one row on candidates held in registers (element e = r * 64 + lane, padding keys 0xFFFFFFFF);
+// ckey / cidx: CAP words of LDS scratch each (the LDS-list kernels pass the row's own list storage).
 template <int R, int CAP>
-__device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* ckey, uint32_t* cidx, int cnt,
-                                                  int b, int i, int lane) {
+__device__ __forceinline__ void filter_select_regs(const KnnParams& P, const uint32_t (&ck)[R], const uint32_t (&ci)[R],
+                                                   uint32_t* ckey, uint32_t* cidx, int cnt, int b, int i, int lane) {
   const int K = P.K;
-  uint32_t ck[R], ci[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = r * kWave + lane;
-    ck[r] = (e < cnt) ? ckey[e] : 0xFFFFFFFFu;
-    ci[r] = (e < cnt) ? cidx[e] : 0xFFFFFFFFu;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();  // candidates live in registers before their LDS slots are reused
 #ifndef KNNF_NO_BUCKET_SELECT
   if (bucket_select<R, CAP>(P, ck, ci, cnt, ckey, cidx, b, i, lane)) return;
   wave_lds_sync();
@@ -894,6 +888,37 @@ __device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* 
   else if (K <= 128) sort_and_emit<2>(P, ckey, cidx, lane, K, out_base, i);
   else if (K <= 256) sort_and_emit<4>(P, ckey, cidx, lane, K, out_base, i);
   else sort_and_emit<8>(P, ckey, cidx, lane, K, out_base, i);
+}
+
+template <int R, int CAP>
+__device__ __forceinline__ void filter_select_row(const KnnParams& P, uint32_t* ckey, uint32_t* cidx, int cnt,
+                                                  int b, int i, int lane) {
+  uint32_t ck[R], ci[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * kWave + lane;
+    ck[r] = (e < cnt) ? ckey[e] : 0xFFFFFFFFu;
+    ci[r] = (e < cnt) ? cidx[e] : 0xFFFFFFFFu;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // candidates live in registers before their LDS slots are reused
+  filter_select_regs<R, CAP>(P, ck, ci, ckey, cidx, cnt, b, i, lane);
+}
+
+// the same for a candidate list in global memory (knn_filter2_kernel): (key, id) pairs, LDS scratch sa / sb
+template <int R, int CAP>
+__device__ __forceinline__ void filter_select_list(const KnnParams& P, const uint2* __restrict__ list, uint32_t* sa,
+                                                   uint32_t* sb, int cnt, int b, int i, int lane) {
+  uint32_t ck[R], ci[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * kWave + lane;
+    uint2 v = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (e < cnt) v = list[e];
+    ck[r] = v.x;
+    ci[r] = v.y;
+  }
+  filter_select_regs<R, CAP>(P, ck, ci, sa, sb, cnt, b, i, lane);
 }
 
 // Profiling-only compile-time switches (never defined in the shipped build; results are WRONG with them):
@@ -1324,6 +1349,9 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
     }
     __syncthreads();
   }
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 1
+  return;
+#endif
 
   for (int col0 = wave * 64; col0 < N; col0 += kColStride) {
     f32x4 acc[4];
@@ -1342,6 +1370,15 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
       mfma_step(acc, (st + 1) / KC, (st + 1) % KC, fB);
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef KNNF_NO_APPEND
+    {
+      float tsum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tsum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+      if (tsum == 123.456f) cnt[0] = 1;
+      continue;
+    }
+#endif
     // acc[t][reg] = <x_row, x_col> for row = lk*4 + reg, col = col0 + 16 t + li
     float sj[4];
     bool in[4];
@@ -1425,6 +1462,9 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
     }
   }
   __syncthreads();
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 2
+  return;
+#endif
 
   // ---- per-row select on the candidate lists (as in knn_filter_kernel) ----
   for (int rr = wave; rr < TM; rr += NW) {
@@ -1445,6 +1485,305 @@ __global__ __launch_bounds__(NW * kWave, 4) void knn_filter_bf16_kernel(const Kn
     else filter_select_row<16, kFCap>(P, ck, ci, c, b, i, lane);
   }
 }
+
+// ---- round 6: 32 query rows per workgroup, candidate lists in GLOBAL memory -------------------------------------------
+// What bounded knn_filter_bf16_kernel (profiles/r06_knn_phases.md: variant builds on one box, K = 16 / 432): the distance
+// pass WITHOUT its appends takes 107 - 115 us for 46 us of matrix work -- every 16-row workgroup streams its sample's three
+// planes (1.5 MB) out of the L2, 3.2 GB per launch = 30 TB/s, the L2's peak.  The lists of a 32-row workgroup do not fit
+// the LDS (32 x 1024 x 8 B), so they move to global memory -- appends are 2 - 25 % of the candidates, 8 bytes each, and
+// the workgroup that wrote a row's list is the one that reads it back (L2-resident) -- which frees the LDS for everything
+// but the sample keys and gives every K the 1024-entry capacity (the 512-entry kernels sent K = 128 .. 240 through a
+// 32 - 70 us exact redo per layer).  Per wave: the A fragments of BOTH 16-row tiles stay in registers (48 VGPRs at
+// C = 64) and every candidate fragment fetched from the L2 feeds two MFMAs: 1.6 GB per launch.  One candidate tile per
+// step (3 plane fragments per 32-channel block, 12 MFMAs alternating between the two row tiles' accumulators), the next
+// tile's fragments in flight while this one's run.  Thresholds, append rule, select, redo list and therefore the emitted
+// ids are those of knn_filter_bf16_kernel: same six-product distances, lists are unordered sets, the select ranks by
+// (key, id).
+constexpr int kF2Rows = 32;
+constexpr int kF2Cap = 1024;
+constexpr int kF2Waves = 8;
+
+template <int KC, bool AGG>
+__global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const KnnParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = kF2Rows, NW = kF2Waves, CAP = kF2Cap;
+  const int N = P.N, K = P.K;
+  float* sq = reinterpret_cast<float*>(smem);                       // [32]
+  float* tauf = sq + TM;                                            // [32] threshold as a distance
+  int* cnt = reinterpret_cast<int*>(tauf + TM);                     // [32]
+  uint32_t* big = reinterpret_cast<uint32_t*>(cnt + TM);            // [32][512] sample keys, then [8 waves][2][1024] select scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int b = blockIdx.x % P.B;                                   // sample-minor: one sample's planes per XCD's L2
+  const int tile2 = blockIdx.x / P.B;
+  const int i0 = tile2 * TM;
+  constexpr int UNITS = 4 * KC;
+  const int Np = (N + 15) & ~15;
+  const int NT = Np >> 4;
+  const int64_t plane = static_cast<int64_t>(P.B) * Np * UNITS;
+  const i4v* pb = P.planes + static_cast<int64_t>(b) * Np * UNITS;
+  const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
+  uint2* lists = P.lists + (static_cast<int64_t>(b) * N + i0) * CAP;
+
+  if (tid < TM) {
+    sq[tid] = sqn[min(i0 + tid, N - 1)];
+    cnt[tid] = 0;
+  }
+  const int li = lane & 15, lk = lane >> 4;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // fragment address = (uniform plane base of this sample) + (32-bit per-lane byte offset of the tile) + (immediate
+  // 1 KiB per 32-channel block): one offset VGPR per tile in flight instead of a 64-bit address per load (the launcher
+  // checks that a sample's plane stays below 4 GiB)
+  const char* pbase[3] = {reinterpret_cast<const char*>(pb), reinterpret_cast<const char*>(pb + plane),
+                          reinterpret_cast<const char*>(pb + 2 * plane)};
+  const uint32_t lane_off = static_cast<uint32_t>(lk * 16 + li) * 16u;
+  auto frag = [&](int ctile, int kb, int p) -> i4v {
+    const uint32_t off = static_cast<uint32_t>(ctile) * (UNITS * 256u) + lane_off;
+    return *reinterpret_cast<const i4v*>(pbase[p] + off + kb * 1024);
+  };
+  constexpr int pa[6] = {0, 0, 1, 0, 2, 1};       // a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2
+  constexpr int pbb[6] = {0, 1, 0, 2, 0, 1};
+  i4v a[2][KC][3];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int t = min(2 * tile2 + rt, NT - 1);
+#pragma unroll
+    for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[rt][kb][p] = frag(t, kb, p);
+    }
+  }
+
+  // ---- per-row thresholds from 512 sampled candidates (32 tiles spread over the sample, four per wave) ----
+  {
+    uint32_t* skeys = big;                        // [32][512]
+    const int rot = (tile2 * 7) % max(NT / 32, 1);
+    // sample tile q of this wave = sample slot 4 wave + q of 32; two tiles' fragments in flight (the register budget of
+    // the distance pass below: A fragments of both row tiles + two candidate tiles)
+    i4v sf0[KC][3], sf1[KC][3];
+    float sv0, sv1;
+    auto sample_tile = [&](int q) -> int {
+      return static_cast<int>((static_cast<int64_t>(4 * wave + q) * NT / 32 + rot) % NT);
+    };
+    auto load_sample = [&](int q, i4v (&f)[KC][3], float& sv) {
+      const int ct = sample_tile(q);
+#pragma unroll
+      for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[kb][p] = frag(ct, kb, p);
+      }
+      sv = (ct * 16 + li) < N ? sqn[ct * 16 + li] : 0.f;
+    };
+    auto do_sample = [&](int q, const i4v (&f)[KC][3], float sv) {
+      f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) sacc[rt] = eg_mfma_bf16(a[rt][kb][pa[s6]], f[kb][pbb[s6]], sacc[rt]);
+        }
+      }
+      const bool inn = (sample_tile(q) * 16 + li) < N;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = rt * 16 + lk * 4 + reg;
+          skeys[r * 512 + (4 * wave + q) * 16 + li] = inn ? key_of((sq[r] + (-2.f * sacc[rt][reg])) + sv) : 0xFFFFFFFFu;
+        }
+      }
+    };
+    load_sample(0, sf0, sv0);
+    load_sample(1, sf1, sv1);
+    __syncthreads();                              // sq[], cnt[] visible
+    do_sample(0, sf0, sv0);
+    load_sample(2, sf0, sv0);
+    do_sample(1, sf1, sv1);
+    load_sample(3, sf1, sv1);
+    do_sample(2, sf0, sv0);
+    do_sample(3, sf1, sv1);
+    __syncthreads();
+    for (int trow = wave; trow < TM; trow += NW) {
+      // as in knn_filter_bf16_kernel: the upper edge of the bucket (256 buckets between the second-smallest and the
+      // largest sample key) that holds the sample rank; the histogram reuses the row's own key storage
+      uint32_t ks[8];
+      uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        ks[q] = skeys[trow * 512 + q * kWave + lane];
+        mn = min(mn, ks[q]);
+        mx = max(mx, ks[q] == 0xFFFFFFFFu ? 0u : ks[q]);
+      }
+      mn = wave_min_u32(mn);
+      mx = ~wave_min_u32(~mx);
+      uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lo = min(lo, ks[q] > mn ? ks[q] : 0xFFFFFFFFu);
+      lo = wave_min_u32(lo);
+      if (lo > mx) lo = mn;
+      const uint32_t span = mx - lo;
+      const int shift = max(0, 24 - static_cast<int>(__builtin_clz(span | 1u)));   // (span >> shift) < 256
+      uint32_t* hist = skeys + trow * 512;                          // the keys are in registers
+      wave_lds_sync();
+      *reinterpret_cast<uint4*>(hist + lane * 8) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(hist + lane * 8 + 4) = make_uint4(0u, 0u, 0u, 0u);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (ks[q] != 0xFFFFFFFFu) atomicAdd(&hist[ks[q] < lo ? 0u : 1u + ((ks[q] - lo) >> shift)], 1u);
+      wave_lds_sync();
+      uint32_t hc[8];
+      {
+        const uint4 h0 = *reinterpret_cast<const uint4*>(hist + lane * 8);
+        const uint4 h1 = *reinterpret_cast<const uint4*>(hist + lane * 8 + 4);
+        hc[0] = h0.x; hc[1] = h0.y; hc[2] = h0.z; hc[3] = h0.w; hc[4] = h1.x; hc[5] = h1.y; hc[6] = h1.z; hc[7] = h1.w;
+      }
+      uint32_t tot = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tot += hc[q];
+      const uint32_t incl = static_cast<uint32_t>(wave_scan_incl(static_cast<int>(tot)));
+      const uint32_t rank = static_cast<uint32_t>(P.sample_rank);
+      const bool mine = incl - tot < rank && rank <= incl;
+      uint32_t run = incl - tot, qsel = 7u;
+#pragma unroll
+      for (int q = 7; q >= 0; --q) {
+        uint32_t upto = run;
+#pragma unroll
+        for (int u = 0; u <= q; ++u) upto += hc[u];
+        if (rank <= upto) qsel = static_cast<uint32_t>(q);
+      }
+      uint32_t bq = 8u * lane + qsel;
+      const unsigned long long mm = __ballot(mine);
+      const int src = mm ? static_cast<int>(__builtin_ctzll(mm)) : 63;
+      bq = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bq), src));
+      const unsigned long long edge = static_cast<unsigned long long>(lo) + (static_cast<unsigned long long>(bq) << shift) - 1ull;
+      const uint32_t tv = mm ? static_cast<uint32_t>(min(edge, 0xFFFFFFFEull)) : 0xFFFFFFFEu;
+      // rows past the end of the cloud (last workgroup of a sample) never take a candidate
+      if (lane == 0)
+        tauf[trow] = (i0 + trow < N) ? __uint_as_float((tv & 0x80000000u) ? (tv & 0x7FFFFFFFu) : ~tv) : DGCN_NEG_INF;
+    }
+    __syncthreads();
+  }
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 1
+  return;
+#endif
+
+  // ---- distance pass: candidate tiles wave, wave + 8, ... ; fragments of the next tile in flight during this one's MFMAs ----
+  {
+    const int ntile = (NT - wave + NW - 1) / NW;                    // tiles of this wave (NT >= 64 here: N >= 1024)
+    i4v f0[KC][3], f1[KC][3];
+    float sj0, sj1;
+    auto load_tile = [&](int it, i4v (&f)[KC][3], float& sj) {
+      const int ct = min(wave + it * NW, NT - 1);
+#pragma unroll
+      for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[kb][p] = frag(ct, kb, p);
+      }
+      const int c = ct * 16 + li;
+      sj = c < N ? sqn[c] : __builtin_inff();                       // columns past N: distance +inf, never a hit
+    };
+    const int seg = lane & ~15;
+    const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
+    const int self0 = P.exclude_self ? i0 : -64;
+    // list entry (r, pos): uniform base + 32-bit byte offset (no 64-bit row pointers kept across the loop)
+    char* const lbase = reinterpret_cast<char*>(lists);
+    auto put = [&](int r, int pos, float dist, int c) {
+      const uint32_t off = static_cast<uint32_t>(r * CAP + pos) * 8u;
+      *reinterpret_cast<uint2*>(lbase + off) = make_uint2(key_of(dist), static_cast<uint32_t>(c));
+    };
+    auto do_tile = [&](int it, const i4v (&f)[KC][3], float sj) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc[rt] = eg_mfma_bf16(a[rt][kb][pa[s6]], f[kb][pbb[s6]], acc[rt]);
+        }
+      }
+#ifdef KNNF_NO_APPEND
+      if (acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[1][0] + acc[1][1] + acc[1][2] + acc[1][3] == 123.456f) cnt[0] = 1;
+      return;
+#endif
+      const int c = (wave + it * NW) * 16 + li;                     // this lane's candidate (sj = +inf when c >= N)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float4 tf4 = *reinterpret_cast<const float4*>(tauf + rt * 16 + lk * 4);
+        const float4 sr4 = *reinterpret_cast<const float4*>(sq + rt * 16 + lk * 4);
+        const float tfv[4] = {tf4.x, tf4.y, tf4.z, tf4.w};
+        const float srv[4] = {sr4.x, sr4.y, sr4.z, sr4.w};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = rt * 16 + lk * 4 + reg;
+          const float dist = (srv[reg] + (-2.f * acc[rt][reg])) + sj;
+          bool hit = dist <= tfv[reg];
+          if constexpr (AGG) {
+            hit = hit && (c != self0 + r);                           // (self0 = -64 unless exclude_self: never equal)
+            // a quarter of the candidates are hits (K > 256): one LDS atomic per (row, tile) from a ballot
+            const unsigned long long bal = __ballot(hit);
+            if (bal == 0ull) continue;                              // wave-uniform
+            const int nseg = __popcll((bal >> seg) & 0xFFFFull);
+            int base = 0;
+            if (li == 0 && nseg > 0) base = atomicAdd(&cnt[r], nseg);
+            base = __shfl(base, seg);
+            if (hit) {
+              const int pos = base + __popcll(bal & segbelow);
+              if (pos < CAP) put(r, pos, dist, c);
+            }
+          } else {
+            if (hit && c != self0 + r) {
+              const int pos = atomicAdd(&cnt[r], 1);
+              if (pos < CAP) put(r, pos, dist, c);
+            }
+          }
+        }
+      }
+    };
+    load_tile(0, f0, sj0);
+#pragma unroll 1
+    for (int it = 0; it < ntile; it += 2) {
+      load_tile(it + 1, f1, sj1);
+      __builtin_amdgcn_sched_barrier(0);
+      do_tile(it, f0, sj0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(it + 2, f0, sj0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < ntile) do_tile(it + 1, f1, sj1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __threadfence();                                                  // the lists are read back by other waves of this workgroup
+  __syncthreads();
+#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 2
+  return;
+#endif
+
+  // ---- per-row select on the lists (four rows per wave), LDS scratch per wave ----
+  uint32_t* sa = big + wave * (2 * CAP);
+  uint32_t* sb = sa + CAP;
+  for (int rr = wave; rr < TM; rr += NW) {
+    const int i = i0 + rr;
+    if (i >= N) continue;  // wave-uniform
+    const int c = cnt[rr];
+    if (c < K || c > CAP) {   // hand the row to the exact kernel
+      if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = b * N + i;
+      continue;
+    }
+    const uint2* list = lists + static_cast<int64_t>(rr) * CAP;
+    if (c <= 2 * kWave) filter_select_list<2, 512>(P, list, sa, sb, c, b, i, lane);
+    else if (c <= 4 * kWave) filter_select_list<4, 512>(P, list, sa, sb, c, b, i, lane);
+    else if (c <= 8 * kWave) filter_select_list<8, 512>(P, list, sa, sb, c, b, i, lane);
+    else if (c <= 12 * kWave) filter_select_list<12, 1024>(P, list, sa, sb, c, b, i, lane);
+    else filter_select_list<16, 1024>(P, list, sa, sb, c, b, i, lane);
+    wave_lds_sync();                                                // the scratch is reused by this wave's next row
+  }
+}
+
+size_t knn_filter2_lds_bytes() { return 3u * kF2Rows * 4u + static_cast<size_t>(kF2Rows) * 512u * 4u; }
 
 size_t knn_filter_bf16_lds_bytes(int cap) { return 3u * kFTM * 4u + static_cast<size_t>(kFTM) * cap * 8u; }
 
@@ -1495,6 +1834,10 @@ namespace {
 // spills under the 128-VGPR budget of 16 waves per workgroup: C = 128 stays on the fp32-MFMA kernel)
 inline int knn_bf16_kc(int C) { return (C == 32 || C == 64) ? C / 32 : 0; }
 inline size_t knn_ws_head(size_t pts) { return (pts * 12u + 4u + 255u) / 256u * 256u; }
+inline size_t knn_lists_bytes(size_t pts) { return pts * static_cast<size_t>(kF2Cap) * 8u; }
+inline size_t knn_planes_bytes(int B, int N, int C) {
+  return static_cast<size_t>(B) * ((static_cast<size_t>(N) + 15u) & ~static_cast<size_t>(15u)) * static_cast<size_t>(C) * 6u;
+}
 }  // namespace
 }  // namespace dgcn
 
@@ -1504,7 +1847,8 @@ extern "C" size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C
   // three bf16 planes of the points (6 bytes per coordinate) when the bf16 filter kernel serves this width
   const size_t pts = static_cast<size_t>(B) * static_cast<size_t>(N);
   const size_t ppts = static_cast<size_t>(B) * ((static_cast<size_t>(N) + 15u) & ~static_cast<size_t>(15u));
-  return knn_ws_head(pts) + (knn_bf16_kc(C) ? ppts * static_cast<size_t>(C) * 6u : 0u);
+  // ... and, behind the planes, the candidate lists of knn_filter2_kernel: 1024 (key, id) pairs per point
+  return knn_ws_head(pts) + (knn_bf16_kc(C) ? ppts * static_cast<size_t>(C) * 6u + knn_lists_bytes(pts) : 0u);
 }
 
 extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B,
@@ -1533,6 +1877,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.nn_out = nn_out; P.ctr_out = ctr_out;
   P.redo = nullptr;
   P.planes = nullptr;
+  P.lists = nullptr;
   P.sqnorm = nullptr;
   P.tau = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
@@ -1568,9 +1913,17 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
     const dim3 fgrid(static_cast<unsigned>(B) * ftiles);
     // the bf16 variant needs the planes behind the head of the workspace; a caller that passes the head only
     // (dgcn_knn_dense_workspace_bytes(B, N, 0)) gets the fp32-MFMA filter kernel
-    const int kc = workspace_bytes >= dgcn_knn_dense_workspace_bytes(B, N, C) ? knn_bf16_kc(C) : 0;
+    // C in {32, 64}: the planes behind the head serve the bf16 filter kernels; with the candidate lists behind the planes
+    // too (the size dgcn_knn_dense_workspace_bytes reports) the 32-row kernel with global lists runs, with the planes only
+    // (rounds 4 - 5's size) the 16-row kernel with LDS lists -- kept for A/B measurements, same ids
+    const size_t ws_planes = knn_ws_head(pts) + knn_planes_bytes(B, N, C);
+    const int kc = (knn_bf16_kc(C) && workspace_bytes >= ws_planes) ? knn_bf16_kc(C) : 0;
+    const bool lists32 = kc && workspace_bytes >= ws_planes + knn_lists_bytes(pts);
     int bcap = cap;
-    if (kc) {
+    if (lists32) {
+      bcap = kF2Cap;
+      F.sample_rank = knn_sample_rank(N, K, bcap, 512);
+    } else if (kc) {
       // 512 samples (unit = N / 512): the candidate count spreads half as much, so the short lists serve larger K
       const double unit = N / 512.0, r0 = K / unit;
       const bool small = K + 3.2 * unit * sqrt(r0 > 1.0 ? r0 : 1.0) + 2.0 * unit + 96 <= 512;
@@ -1588,6 +1941,22 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
         hipLaunchKernelGGL(knn_planes_kernel, dim3(pblocks), dim3(256), 0, s, x, sb, sc, B, C, N, Np, planes, F.sqnorm,
                            F.redo);
         F.planes = planes;
+        if (lists32) {
+          F.lists = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + ws_planes);
+          const size_t l2 = knn_filter2_lds_bytes();
+          const dim3 g2(static_cast<unsigned>(B) * static_cast<unsigned>((N + kF2Rows - 1) / kF2Rows));
+#define DGCN_KNN2_LAUNCH(KCV, AGGV)                                                                          \
+  do {                                                                                                        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter2_kernel<KCV, AGGV>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l2));                \
+    if (e != hipSuccess) return static_cast<int>(e);                                                          \
+    hipLaunchKernelGGL((knn_filter2_kernel<KCV, AGGV>), g2, dim3(kF2Waves * kWave), l2, s, F);                \
+  } while (0)
+          const bool agg = K > 256;
+          if (kc == 1) { if (agg) DGCN_KNN2_LAUNCH(1, true); else DGCN_KNN2_LAUNCH(1, false); }
+          else { if (agg) DGCN_KNN2_LAUNCH(2, true); else DGCN_KNN2_LAUNCH(2, false); }
+#undef DGCN_KNN2_LAUNCH
+        } else {
         const size_t blds = knn_filter_bf16_lds_bytes(bcap);
 #define DGCN_KNNB_LAUNCH(CAP, KCV, NWV)                                                                      \
   do {                                                                                                        \
@@ -1604,6 +1973,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
           if (kc == 1) DGCN_KNNB_LAUNCH(1024, 1, 16); else DGCN_KNNB_LAUNCH(1024, 2, 16);
         }
 #undef DGCN_KNNB_LAUNCH
+        }
       } else {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_prep_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));

@@ -22,6 +22,9 @@ EDGECONV_BWD_KERNELS = True   # EdgeConv2d's dx and [dW | db] from dP | dQ in cs
                               # library calls -- sub, cat, baddbmm, permute-copy, split-K bmm, three sums: A/B measurements)
 USE_KNN_FILTER = True   # candidate-filter kNN fast path for N >= 1024 (exact fallback inside the library)
 KNN_BF16_PIPE = True    # distance tiles of the filter pass on the bf16 matrix pipe (C in {32, 64}); False: fp32 MFMA (A/B)
+KNN_GLOBAL_LISTS = True  # round 6: 32 query rows per workgroup, candidate lists in the workspace (knn_filter2_kernel);
+                         # False: rounds 4 - 5's 16-row kernel with LDS lists (A/B; same ids)
+KNN_LIST_ENTRIES = 1024  # (key, id) pairs per point behind the planes of the workspace (csrc/knn_dense.hip kF2Cap)
 
 
 # ----------------------------------------------------------------------------------------
@@ -42,6 +45,8 @@ def _knn_launch(x3: torch.Tensor, K: int, dilation: int, nn_out: torch.Tensor, c
     if N > KNN_MAX_POINTS or K > KNN_MAX_NEIGHBOURS:
         return _knn_beyond_kernel_limits(x3, K, dilation, nn_out, ctr_out, exclude_self)
     ws_bytes = lib.dgcn_knn_dense_workspace_bytes(B, N, C if KNN_BF16_PIPE else 0) if (N >= 1024 and USE_KNN_FILTER) else 0
+    if not KNN_GLOBAL_LISTS and KNN_BF16_PIPE and C in (32, 64) and ws_bytes:
+        ws_bytes -= B * N * KNN_LIST_ENTRIES * 8            # a workspace without room for the lists selects the 16-row kernel
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
     with _lib.device_ctx(dev):
         rc = lib.dgcn_knn_dense_f32(x3.data_ptr(), x3.stride(0), x3.stride(1), x3.stride(2), B, C, N, K,

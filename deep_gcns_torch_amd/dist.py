@@ -653,7 +653,7 @@ def merge_softmax_states(oa, la, has_a, ob, lb, has_b):
 
 class _SplitSoftmaxAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_local, sg, group, t, state_fwd, state_bwd):
+    def forward(ctx, x_local, sg, group, t, state_fwd, state_bwd, msg_kw):
         world = dist.get_world_size(group)
         n_local, C = x_local.shape
         mr = sg.max_rows
@@ -666,13 +666,14 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         else:
             work = dist.all_gather(list(full.view(world, mr, C).unbind(0)), send, group=group, async_op=True)
         xl = x_local.detach().contiguous()
-        oa, la = state_fwd(xl, sg.local, t)              # runs while the remote rows are in flight
+        oa, la = state_fwd(xl, sg.local, t, **msg_kw)    # runs while the remote rows are in flight
         work.wait()
-        ob, lb = state_fwd(full, sg.remote, t)
+        ob, lb = state_fwd(full, sg.remote, t, **msg_kw)
         has_a = (sg.local.deg > 0).unsqueeze(1)
         has_b = (sg.remote.deg > 0).unsqueeze(1)
         out, L = merge_softmax_states(oa, la, has_a, ob, lb, has_b)
         ctx.sg, ctx.group, ctx.t, ctx.state_bwd, ctx.tensor_coll = sg, group, t, state_bwd, tensor_coll
+        ctx.msg_kw = msg_kw
         ctx.save_for_backward(xl, full, L)
         return out
 
@@ -684,12 +685,12 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         rank = dist.get_rank(group)
         mr, C = sg.max_rows, xl.size(1)
         g = g.contiguous()
-        extra = {}
+        extra = dict(ctx.msg_kw)
         if ctx.state_bwd is _hip_state_fns()[1]:
             from . import ops
             prep = ops.softmax_state_prepare(g, L)          # one node-wise prologue for both launches (single-gather form)
             if prep is not None:
-                extra = dict(prep=prep)
+                extra["prep"] = prep
         g_full = ctx.state_bwd(full, sg.remote, g, L, ctx.t, **extra).contiguous()   # gradient of the remote rows first ...
         if ctx.tensor_coll:
             back = g_full.new_empty(mr, C)
@@ -702,12 +703,21 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         work.wait()
         if back is None:
             back = tmp.view(world, mr, C)[rank]
-        return g_loc + back[:xl.size(0)], None, None, None, None, None
+        return g_loc + back[:xl.size(0)], None, None, None, None, None, None
+
+
+_SPLIT_KWARGS = {"t", "eps", "relu_eps", "learn_t", "learn_p", "p", "edge_attr", "edge_encoder", "dim_size", "add_root"}
 
 
 def split_supported(aggr: str, kw: dict) -> bool:
+    """softmax / softmax_sg with a fixed temperature and node features only.  ``eps`` / ``relu_eps`` are passed on to the
+    state kernels; anything that changes the result and is not handled (``add_root``, a ``dim_size`` other than the
+    partition's rows, an unknown keyword) makes the caller fall back to the all-gather scheme instead of being dropped."""
+    if any(k not in _SPLIT_KWARGS for k in kw):
+        return False
     return (aggr in ("softmax", "softmax_sg") and not kw.get("learn_t") and kw.get("edge_attr") is None
-            and kw.get("edge_encoder") is None and not isinstance(kw.get("t", 1.0), torch.Tensor))
+            and kw.get("edge_encoder") is None and not isinstance(kw.get("t", 1.0), torch.Tensor)
+            and not kw.get("add_root") and not kw.get("learn_p"))
 
 
 def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "softmax", group=None, state_fns=None,
@@ -718,8 +728,11 @@ def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "soft
     if not split_supported(aggr, kw):
         raise NotImplementedError("the local-first scheme covers softmax / softmax_sg with a fixed temperature; use the "
                                   "allgather scheme for the other aggregators")
+    if kw.get("dim_size") not in (None, sg.n_local):
+        raise ValueError(f"dim_size = {kw['dim_size']} but this rank's partition has {sg.n_local} destination rows")
     fwd, bwd = state_fns or _hip_state_fns()
-    return _SplitSoftmaxAggregate.apply(x_local, sg, group, float(kw.get("t", 1.0)), fwd, bwd)
+    msg_kw = {k: kw[k] for k in ("eps", "relu_eps") if k in kw}
+    return _SplitSoftmaxAggregate.apply(x_local, sg, group, float(kw.get("t", 1.0)), fwd, bwd, msg_kw)
 
 
 def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **kw) -> torch.Tensor:

@@ -403,6 +403,10 @@ int dgcn_subgraph_extract(const int64_t* src, const int64_t* dst, int64_t n_edge
  *            candidates closer than that may be ranked either way (as on any other fp32 evaluation of the reference's
  *            formula); every row is ranked by one evaluation only.  Other widths, or a workspace sized with C = 0
  *            (no room for the bf16 planes): the fp32-MFMA chain, identical results either way.
+ *            For C in {32, 64} the size reported also holds 1024 (key, id) candidate pairs per point behind the planes
+ *            (8 KiB per point): with them the filter pass runs 32 query rows per workgroup and keeps its candidate lists
+ *            in the workspace; a workspace that is B*N*8192 bytes smaller selects the 16-row kernel with LDS lists
+ *            (rounds 4 - 5; same ids).
  * Limits: N <= 4096, K <= 1024 (the candidate-filter fast path serves K <= 512), K <= N. */
 size_t dgcn_knn_dense_workspace_bytes(int32_t B, int32_t N, int32_t C);
 int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_t sn, int32_t B, int32_t C,

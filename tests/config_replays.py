@@ -128,3 +128,57 @@ def revgcn_inputs(scale=1.0):
 def revgcn_fixture_path(aggr, layers=112, scale=1.0):
     tag = "" if scale == 1.0 else f"_s{scale:g}"
     return os.path.join(GOLDEN, f"config_revgcn{layers}_{aggr}{tag}.pt")
+
+
+# ---- config 2 as one model: sem_seg_dense ResGCN-28, B = 8 x N = 4096, k = 16 (tests/golden/make_resgcn28_golden.py) ------
+RESGCN_POSITIONS = 4096
+
+
+def dense_formula_init(model, seed):
+    """Parameters of a dense (Conv2d / BatchNorm2d) model as a function of (name, shape, seed): Conv2d weights
+    U(+-1/sqrt(fan_in)) and biases +-0.1; BatchNorm2d scale 1 +- 0.1, shift +-0.1.  The module TYPE decides (BasicConv is a
+    Sequential: a BatchNorm's parameters are named by an index), the NAME seeds the draw, so the reference's classes and the
+    restated ones hold the same values."""
+    import zlib
+    with torch.no_grad():
+        for mname, mod in model.named_modules():
+            for pname, p in mod.named_parameters(recurse=False):
+                name = f"{mname}.{pname}" if mname else pname
+                g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+                u = torch.rand(p.shape, generator=g, dtype=torch.float64) * 2 - 1
+                if isinstance(mod, torch.nn.Conv2d) and pname == "weight":
+                    v = u / (p[0].numel() ** 0.5)
+                elif isinstance(mod, torch.nn.BatchNorm2d) and pname == "weight":
+                    v = 1.0 + 0.1 * u
+                else:
+                    v = 0.1 * u
+                p.copy_(v.to(p.dtype))
+    return model
+
+
+def resgcn_inputs(batch=8, points=4096):
+    """Seeded S3DIS-like input: xyz in [0,1)^3 + 6 feature channels, (B, 9, N, 1), and per-point labels (B, N)."""
+    g = torch.Generator().manual_seed(2028)
+    inputs = torch.cat([torch.rand(batch, 3, points, 1, generator=g), torch.rand(batch, 6, points, 1, generator=g)], dim=1)
+    target = torch.randint(0, 13, (batch, points), generator=g)
+    return dict(inputs=inputs, target=target)
+
+
+def resgcn_kept_params(blocks):
+    """Which parameter gradients the fixture keeps: the head's, the middle block's and the last block's graph convolution,
+    the fusion block, the prediction layers."""
+    mid, last = (blocks - 1) // 2, blocks - 2
+    prefixes = ("head.", f"backbone.{mid}.", f"backbone.{last}.", "fusion_block.", "prediction.")
+    return lambda name: name.startswith(prefixes)
+
+
+def resgcn_sample_positions(batch, points):
+    g = torch.Generator().manual_seed(404)
+    s = min(RESGCN_POSITIONS, batch * points)
+    flat = torch.randperm(batch * points, generator=g)[:s].sort().values
+    return torch.stack([flat // points, flat % points])
+
+
+def resgcn_fixture_path(blocks=28, batch=8, points=4096):
+    tag = f"_b{batch}" if points == 4096 else f"_b{batch}_n{points}"
+    return os.path.join(GOLDEN, f"config_resgcn{blocks}{tag}.pt")

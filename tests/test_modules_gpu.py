@@ -335,7 +335,7 @@ def test_knn_on_real_valued_features_at_shape_D_against_the_oracle(kind, K):
     assert mine.shape == (2, B, N, K) and mine.dtype == torch.int64
     assert torch.equal(mine[1].cpu(), torch.arange(N).view(1, N, 1).expand(B, N, K))
     mine = mine[0].cpu()
-    n_det = n_all = n_oracle_checked = 0
+    n_det = n_all = n_oracle_checked = n_vs_oracle = n_vs_f64 = n_oracle_vs_f64 = 0
     for b in range(B):
         val, idx, bud, d64 = truth[b]
         gap = val[:, 1:K + 1] - val[:, :K]                                # gap[r] = d(r+1) - d(r), r = 0..K-1
@@ -352,11 +352,25 @@ def test_knn_on_real_valued_features_at_shape_D_against_the_oracle(kind, K):
         assert bool((torch.sort(got, dim=1).values.diff(dim=1) != 0).all()) if K > 1 else True
         n_det += int(det.sum())
         n_all += det.numel()
-        if b < 2:                                                         # the oracle's own ranking on two samples
-            ref = dense_ref.dense_knn_matrix(x[b:b + 1], K)[0, 0]
-            assert torch.equal(ref[det], idx[:, :K][det]), "the rounding budget does not cover the reference's own fp32 evaluation"
-            n_oracle_checked += int(det.sum())
+        # the oracle's own ranking (the reference's fp32 association on this host's BLAS), every sample
+        ref = dense_ref.dense_knn_matrix(x[b:b + 1], K)[0, 0]
+        assert torch.equal(ref[det], idx[:, :K][det]), "the rounding budget does not cover the reference's own fp32 evaluation"
+        n_oracle_checked += int(det.sum())
+        n_vs_oracle += int((got != ref).sum())
+        n_vs_f64 += int((got != idx[:, :K]).sum())
+        n_oracle_vs_f64 += int((ref != idx[:, :K]).sum())
     frac = n_det / n_all
+    # THE COUNT (VERDICT r5 weak #1a): of the B x N x K emitted positions, how many ids differ from the oracle's on this host,
+    # next to how many of the oracle's own differ from the float64 ranking (the same kind of disagreement: two candidates
+    # closer than fp32 resolves, ranked by two different fp32 evaluations)
+    print(f"[knn {kind} K={K}] ids that differ from the oracle's: {n_vs_oracle} of {n_all} ({n_vs_oracle / n_all:.2e}); device vs "
+          f"float64 ranking: {n_vs_f64} ({n_vs_f64 / n_all:.2e}); oracle vs float64 ranking: {n_oracle_vs_f64} "
+          f"({n_oracle_vs_f64 / n_all:.2e})")
+    from conftest import gate
+    gate(f"knn shape D {kind} K={K}: fraction of emitted ids that differ from oracle/dense_ref.dense_knn_matrix (all 8 samples)",
+         n_vs_oracle / n_all, 2e-2 if K > 16 else 2e-3)
+    gate(f"knn shape D {kind} K={K}: ids off the float64 ranking, device / (3 x oracle + 32)",
+         n_vs_f64 / (3 * n_oracle_vs_f64 + 32), 1.0)
     print(f"[knn {kind} K={K}] {n_det} of {n_all} neighbour positions determined beyond fp32 rounding ({frac:.4f}): ids "
           f"equal to the float64 ranking there (oracle checked on {n_oracle_checked}); the remaining "
           f"{n_all - n_det} rank-consistent within the budget")
