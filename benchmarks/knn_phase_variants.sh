@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 CS=deep_gcns_torch_amd/csrc
-VARIANTS=("s1:-DKNNF_STOP_AFTER=1" "s2:-DKNNF_STOP_AFTER=2" "noappend:-DKNNF_STOP_AFTER=2 -DKNNF_NO_APPEND" ${EXTRA_VARIANTS})
+VARIANTS=("s1:-DKNNF_STOP_AFTER=1" "s2:-DKNNF_STOP_AFTER=2" "noappend:-DKNNF_STOP_AFTER=2 -DKNNF_NO_APPEND" "noloads:-DKNNF_STOP_AFTER=2 -DKNNF_NO_APPEND -DKNNF_NO_LOADS" "nomfma:-DKNNF_STOP_AFTER=2 -DKNNF_NO_APPEND -DKNNF_NO_MFMA2")
 if [ "$1" = build ]; then
   mkdir -p scratch
   for v in "${VARIANTS[@]}"; do

@@ -46,6 +46,12 @@ def install(reference_root=None, fuse_models=True):
             utils_mod.__path__.append(ref_utils)
         if reference_root not in sys.path:
             sys.path.append(reference_root)
+    if os.environ.get("DGCN_NO_WARMUP") != "1":
+        try:
+            from . import graph
+            graph.warm_up()                    # graph-build module load off the first real build (GPU hosts only)
+        except Exception:                      # noqa: BLE001 -- a warm-up must never keep install() from registering modules
+            pass
     from . import fuse
     if fuse_models:
         fuse.enable_import_hook()

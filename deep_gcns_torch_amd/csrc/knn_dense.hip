@@ -39,6 +39,7 @@ struct KnnParams {
   float* sqnorm;       // [B*N] |x_j|^2 (fma chain over channels), written by knn_prep_kernel for the filter pass
   uint32_t* tau;       // [B*N] per-row sample threshold (ordered-uint key), written by knn_prep_kernel
   uint2* lists;        // knn_filter2_kernel: [B*N][kF2Cap] (key, id) candidate lists in global memory, or null
+  int* list_cnt;       // [B*N] candidates appended per row (may exceed the capacity: the row is then redone)
   int exclude_self;    // 1: the query point itself is never a neighbour (torch_cluster.knn_graph, loop=False)
   int sample_rank;     // rank of the sample threshold used by the candidate pre-filter (0 = disabled)
   int64_t* nn_out;     // [B, N, Kout] neighbour ids
@@ -1503,7 +1504,7 @@ constexpr int kF2Rows = 32;
 constexpr int kF2Cap = 1024;
 constexpr int kF2Waves = 8;
 
-template <int KC, bool AGG>
+template <int KC, bool EXCL>
 __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const KnnParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = kF2Rows, NW = kF2Waves, CAP = kF2Cap;
@@ -1511,7 +1512,7 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
   float* sq = reinterpret_cast<float*>(smem);                       // [32]
   float* tauf = sq + TM;                                            // [32] threshold as a distance
   int* cnt = reinterpret_cast<int*>(tauf + TM);                     // [32]
-  uint32_t* big = reinterpret_cast<uint32_t*>(cnt + TM);            // [32][512] sample keys, then [8 waves][2][1024] select scratch
+  uint32_t* big = reinterpret_cast<uint32_t*>(cnt + TM + 32);       // [32][512] sample keys, then [8 waves][1024] hit stage
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -1668,48 +1669,76 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
     __syncthreads();
   }
 #if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 1
+  if (tid < TM && i0 + tid < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tid] = -1;   // (select + redo skipped)
   return;
 #endif
 
-  // ---- distance pass: candidate tiles wave, wave + 8, ... ; fragments of the next tile in flight during this one's MFMAs ----
+  // ---- distance pass.  A wave takes PAIRS of candidate tiles (pair q = tiles 2q, 2q + 1; pairs wave, wave + 8, ...) and
+  // walks a pair one 32-channel block at a time: 6 fragment loads (two tiles x three planes), 24 MFMAs into FOUR
+  // accumulators (2 row tiles x 2 candidate tiles) issued round-robin, so that an MFMA depends on the one four back --
+  // with two accumulators (rounds 4 - 5, and this kernel's first version) every MFMA waits for the one two back and an
+  // issue slot of another wave in between costs the dependent one ~43 cycles (MI355X_MICROARCH.md, per-instruction
+  // constants): 210 cycles per MFMA and wave at four waves per SIMD, measured on both kernels
+  // (profiles/r06_knn_filter_counters.md).  The next step's fragments are in flight while this step's MFMAs run.
   {
-    const int ntile = (NT - wave + NW - 1) / NW;                    // tiles of this wave (NT >= 64 here: N >= 1024)
-    i4v f0[KC][3], f1[KC][3];
-    float sj0, sj1;
-    auto load_tile = [&](int it, i4v (&f)[KC][3], float& sj) {
-      const int ct = min(wave + it * NW, NT - 1);
+    const int NP = (NT + 1) >> 1;                                   // tile pairs of the sample
+    const int npair = (NP - wave + NW - 1) / NW;                    // pairs of this wave
+    constexpr int NSTEP = KC;                                       // steps per pair
+    i4v fA[2][3], fB[2][3];
+    auto load_step = [&](int q, int kb, i4v (&f)[2][3]) {
+#ifdef KNNF_NO_LOADS
+      if (q > 0) return;
+#endif
 #pragma unroll
-      for (int kb = 0; kb < KC; ++kb) {
+      for (int t = 0; t < 2; ++t) {
+        const int ct = min(2 * (wave + q * NW) + t, NT - 1);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f[kb][p] = frag(ct, kb, p);
+        for (int p = 0; p < 3; ++p) f[t][p] = frag(ct, kb, p);
       }
-      const int c = ct * 16 + li;
-      sj = c < N ? sqn[c] : __builtin_inff();                       // columns past N: distance +inf, never a hit
     };
-    const int seg = lane & ~15;
-    const unsigned long long segbelow = ((1ull << (lane & 15)) - 1ull) << seg;
-    const int self0 = P.exclude_self ? i0 : -64;
-    // list entry (r, pos): uniform base + 32-bit byte offset (no 64-bit row pointers kept across the loop)
-    char* const lbase = reinterpret_cast<char*>(lists);
-    auto put = [&](int r, int pos, float dist, int c) {
-      const uint32_t off = static_cast<uint32_t>(r * CAP + pos) * 8u;
-      *reinterpret_cast<uint2*>(lbase + off) = make_uint2(key_of(dist), static_cast<uint32_t>(c));
-    };
-    auto do_tile = [&](int it, const i4v (&f)[KC][3], float sj) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto mfma_step = [&](f32x4 (&acc)[2][2], int kb, const i4v (&f)[2][3]) {
+#ifdef KNNF_NO_MFMA2
 #pragma unroll
-      for (int kb = 0; kb < KC; ++kb) {
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) {
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt) acc[rt] = eg_mfma_bf16(a[rt][kb][pa[s6]], f[kb][pbb[s6]], acc[rt]);
-        }
+        for (int p = 0; p < 3; ++p) acc[0][t][p] += __int_as_float(f[t][p][0] ^ f[t][p][3]);
       }
-#ifdef KNNF_NO_APPEND
-      if (acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[1][0] + acc[1][1] + acc[1][2] + acc[1][3] == 123.456f) cnt[0] = 1;
       return;
 #endif
-      const int c = (wave + it * NW) * 16 + li;                     // this lane's candidate (sj = +inf when c >= N)
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc[rt][t] = eg_mfma_bf16(a[rt][kb][pa[s6]], f[t][pbb[s6]], acc[rt][t]);
+        }
+      }
+    };
+    // Epilogue of a pair: 16 (row, candidate) distances per lane.  Hits are 2 - 25 % of them, so a branch per distance
+    // (rounds 4 - 5's form, and this kernel's first) runs its body -- an LDS atomic, the key, a store -- for 1.4 active
+    // lanes on average, 11 to 32 times per pair: 18 instructions per distance, 118 us per launch once the loads no longer
+    // hide it (profiles/r06_knn_phases.md; a per-wave LDS stage in front of the stores did not help: the cost is
+    // instruction issue, not the stores).  Here the 16 compares only set bits; the distances go to a lane-private LDS
+    // column; then the wave loops over ROUNDS -- every lane with a bit left takes its lowest one -- so the body runs
+    // 2 - 3 times per pair at K = 16 (9 at K = 432) with as many lanes as have hits.  Lists are unordered sets: the order
+    // of the appends does not reach the output.
+    float* dl = reinterpret_cast<float*>(big) + wave * (16 * kWave);  // [16 slots][64 lanes], where the sample keys were
+    char* const lbase = reinterpret_cast<char*>(lists);
+    auto epilogue = [&](int q, const f32x4 (&acc)[2][2], const float (&sj)[2]) {
+#ifdef KNNF_NO_APPEND
+      {
+        float tsum = sj[0] + sj[1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) tsum += acc[rt][t][0] + acc[rt][t][1] + acc[rt][t][2] + acc[rt][t][3];
+        }
+        if (tsum == 123.456f) cnt[0] = 1;
+        return;
+      }
+#endif
+      const int c0 = 2 * (wave + q * NW) * 16 + li;                 // candidate of t = 0; t = 1: + 16
+      uint32_t bits = 0u;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const float4 tf4 = *reinterpret_cast<const float4*>(tauf + rt * 16 + lk * 4);
@@ -1718,72 +1747,130 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
         const float srv[4] = {sr4.x, sr4.y, sr4.z, sr4.w};
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int r = rt * 16 + lk * 4 + reg;
-          const float dist = (srv[reg] + (-2.f * acc[rt][reg])) + sj;
-          bool hit = dist <= tfv[reg];
-          if constexpr (AGG) {
-            hit = hit && (c != self0 + r);                           // (self0 = -64 unless exclude_self: never equal)
-            // a quarter of the candidates are hits (K > 256): one LDS atomic per (row, tile) from a ballot
-            const unsigned long long bal = __ballot(hit);
-            if (bal == 0ull) continue;                              // wave-uniform
-            const int nseg = __popcll((bal >> seg) & 0xFFFFull);
-            int base = 0;
-            if (li == 0 && nseg > 0) base = atomicAdd(&cnt[r], nseg);
-            base = __shfl(base, seg);
-            if (hit) {
-              const int pos = base + __popcll(bal & segbelow);
-              if (pos < CAP) put(r, pos, dist, c);
-            }
-          } else {
-            if (hit && c != self0 + r) {
-              const int pos = atomicAdd(&cnt[r], 1);
-              if (pos < CAP) put(r, pos, dist, c);
-            }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int k = rt * 8 + reg * 2 + t;                      // slot: row = rt * 16 + lk * 4 + reg, candidate c0 + 16 t
+            const float dist = (srv[reg] + (-2.f * acc[rt][t][reg])) + sj[t];
+            bool hit = dist <= tfv[reg];
+            if constexpr (EXCL) hit = hit && (c0 + 16 * t) != i0 + rt * 16 + lk * 4 + reg;
+            bits |= hit ? (1u << k) : 0u;
+            dl[k * kWave + lane] = dist;
           }
         }
       }
+      while (__ballot(bits != 0u) != 0ull) {                        // rounds: wave-uniform trip count
+        if (bits != 0u) {
+          const int k = __builtin_ctz(bits);
+          bits &= bits - 1u;
+          const float dist = dl[k * kWave + lane];                   // (written by this lane: no barrier needed)
+          const int r = (k >> 3) * 16 + lk * 4 + ((k >> 1) & 3);
+          const int c = c0 + ((k & 1) << 4);
+          const int pos = atomicAdd(&cnt[r], 1);
+          if (pos < CAP)
+            *reinterpret_cast<uint2*>(lbase + static_cast<uint32_t>(r * CAP + pos) * 8u) =
+                make_uint2(key_of(dist), static_cast<uint32_t>(c));
+        }
+      }
     };
-    load_tile(0, f0, sj0);
+    auto load_sj = [&](int q, float (&sj)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c = (2 * (wave + q * NW) + t) * 16 + li;
+        sj[t] = c < N ? sqn[min(c, N - 1)] : __builtin_inff();        // columns past N: distance +inf, never a hit
+      }
+    };
+    load_step(0, 0, fA);
 #pragma unroll 1
-    for (int it = 0; it < ntile; it += 2) {
-      load_tile(it + 1, f1, sj1);
-      __builtin_amdgcn_sched_barrier(0);
-      do_tile(it, f0, sj0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_tile(it + 2, f0, sj0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (it + 1 < ntile) do_tile(it + 1, f1, sj1);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < npair; ++q) {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float sj[2];
+      load_sj(q, sj);                                                 // requested BEFORE the next step's fragments (in-order returns)
+      if constexpr (NSTEP == 1) {
+        // one step per pair: alternate the buffers by hand over two pairs
+        load_step(q + 1, 0, fB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(acc, 0, fA);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(q, acc, sj);
+        if (++q >= npair) break;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        load_sj(q, sj);
+        load_step(q + 1, 0, fA);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(acc, 0, fB);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(q, acc, sj);
+      } else {
+#pragma unroll
+        for (int st = 0; st < NSTEP; st += 2) {
+          load_step(q, st + 1, fB);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(acc, st, fA);
+          __builtin_amdgcn_sched_barrier(0);
+          const bool more = st + 2 < NSTEP;
+          load_step(more ? q : q + 1, more ? st + 2 : 0, fA);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_step(acc, st + 1, fB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        epilogue(q, acc, sj);
+      }
     }
   }
-  __threadfence();                                                  // the lists are read back by other waves of this workgroup
+  // the rows' candidate counts, for the select kernel (the end of a kernel is the only fence the lists need: an
+  // agent-scope __threadfence() per wave in the first version of this kernel -- lists read back by the same launch --
+  // wrote back and invalidated the XCD's L2 once per wave: 100 - 140 us per launch, profiles/r06_knn_phases.md)
   __syncthreads();
-#if defined(KNNF_STOP_AFTER) && KNNF_STOP_AFTER == 2
+#if defined(KNNF_STOP_AFTER)
+  if (tid < TM && i0 + tid < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tid] = -1;   // (select + redo skipped)
   return;
 #endif
-
-  // ---- per-row select on the lists (four rows per wave), LDS scratch per wave ----
-  uint32_t* sa = big + wave * (2 * CAP);
-  uint32_t* sb = sa + CAP;
-  for (int rr = wave; rr < TM; rr += NW) {
-    const int i = i0 + rr;
-    if (i >= N) continue;  // wave-uniform
-    const int c = cnt[rr];
-    if (c < K || c > CAP) {   // hand the row to the exact kernel
-      if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = b * N + i;
-      continue;
-    }
-    const uint2* list = lists + static_cast<int64_t>(rr) * CAP;
-    if (c <= 2 * kWave) filter_select_list<2, 512>(P, list, sa, sb, c, b, i, lane);
-    else if (c <= 4 * kWave) filter_select_list<4, 512>(P, list, sa, sb, c, b, i, lane);
-    else if (c <= 8 * kWave) filter_select_list<8, 512>(P, list, sa, sb, c, b, i, lane);
-    else if (c <= 12 * kWave) filter_select_list<12, 1024>(P, list, sa, sb, c, b, i, lane);
-    else filter_select_list<16, 1024>(P, list, sa, sb, c, b, i, lane);
-    wave_lds_sync();                                                // the scratch is reused by this wave's next row
-  }
+  if (tid < TM && i0 + tid < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tid] = cnt[tid];
 }
 
-size_t knn_filter2_lds_bytes() { return 3u * kF2Rows * 4u + static_cast<size_t>(kF2Rows) * 512u * 4u; }
+// ---- the select of knn_filter2_kernel's lists: one wave per query row, any row order, high occupancy --------------------
+// (inside the filter kernel the four rows of a wave ran one after the other at 16 waves per CU: 76 - 195 us per launch;
+// as its own launch 32,768 independent waves: the same code, profiles/r06_knn_phases.md)
+constexpr int kSelWaves = 4;
+__global__ __launch_bounds__(kSelWaves * kWave) void knn_select_lists_kernel(const KnnParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CAP = kF2Cap;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kSelWaves + wave;
+  if (row >= static_cast<int64_t>(P.B) * P.N) return;              // wave-uniform
+  const int b = static_cast<int>(row / P.N), i = static_cast<int>(row % P.N);
+  uint32_t* sa = reinterpret_cast<uint32_t*>(smem) + wave * (2 * CAP);
+  uint32_t* sb = sa + CAP;
+  const int c = P.list_cnt[row];
+#if defined(KNNF_STOP_AFTER)
+  if (c < 0) return;
+#endif
+  if (c < P.K || c > CAP) {   // hand the row to the exact kernel
+    if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = static_cast<int>(row);
+    return;
+  }
+  const uint2* list = P.lists + row * CAP;
+  if (c <= 2 * kWave) filter_select_list<2, 512>(P, list, sa, sb, c, b, i, lane);
+  else if (c <= 4 * kWave) filter_select_list<4, 512>(P, list, sa, sb, c, b, i, lane);
+  else if (c <= 8 * kWave) filter_select_list<8, 512>(P, list, sa, sb, c, b, i, lane);
+  else if (c <= 12 * kWave) filter_select_list<12, 1024>(P, list, sa, sb, c, b, i, lane);
+  else filter_select_list<16, 1024>(P, list, sa, sb, c, b, i, lane);
+}
+
+size_t knn_select_lds_bytes() { return static_cast<size_t>(kSelWaves) * 2u * kF2Cap * 4u; }
+
+// sq / tauf / cnt + the per-wave stage counters, and the sample keys (later: the hit stages)
+size_t knn_filter2_lds_bytes() { return (3u * kF2Rows + 32u) * 4u + static_cast<size_t>(kF2Rows) * 512u * 4u; }
 
 size_t knn_filter_bf16_lds_bytes(int cap) { return 3u * kFTM * 4u + static_cast<size_t>(kFTM) * cap * 8u; }
 
@@ -1834,7 +1921,7 @@ namespace {
 // spills under the 128-VGPR budget of 16 waves per workgroup: C = 128 stays on the fp32-MFMA kernel)
 inline int knn_bf16_kc(int C) { return (C == 32 || C == 64) ? C / 32 : 0; }
 inline size_t knn_ws_head(size_t pts) { return (pts * 12u + 4u + 255u) / 256u * 256u; }
-inline size_t knn_lists_bytes(size_t pts) { return pts * static_cast<size_t>(kF2Cap) * 8u; }
+inline size_t knn_lists_bytes(size_t pts) { return pts * static_cast<size_t>(kF2Cap) * 8u + (pts * 4u + 255u) / 256u * 256u; }
 inline size_t knn_planes_bytes(int B, int N, int C) {
   return static_cast<size_t>(B) * ((static_cast<size_t>(N) + 15u) & ~static_cast<size_t>(15u)) * static_cast<size_t>(C) * 6u;
 }
@@ -1878,6 +1965,7 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
   P.redo = nullptr;
   P.planes = nullptr;
   P.lists = nullptr;
+  P.list_cnt = nullptr;
   P.sqnorm = nullptr;
   P.tau = nullptr;
   P.exclude_self = exclude_self ? 1 : 0;
@@ -1943,18 +2031,21 @@ extern "C" int dgcn_knn_dense_f32(const float* x, int64_t sb, int64_t sc, int64_
         F.planes = planes;
         if (lists32) {
           F.lists = reinterpret_cast<uint2*>(static_cast<char*>(workspace) + ws_planes);
+          F.list_cnt = reinterpret_cast<int*>(static_cast<char*>(workspace) + ws_planes + pts * static_cast<size_t>(kF2Cap) * 8u);
           const size_t l2 = knn_filter2_lds_bytes();
           const dim3 g2(static_cast<unsigned>(B) * static_cast<unsigned>((N + kF2Rows - 1) / kF2Rows));
-#define DGCN_KNN2_LAUNCH(KCV, AGGV)                                                                          \
+#define DGCN_KNN2_LAUNCH(KCV, EX)                                                                            \
   do {                                                                                                        \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter2_kernel<KCV, AGGV>),                     \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter2_kernel<KCV, EX>),                       \
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l2));                \
     if (e != hipSuccess) return static_cast<int>(e);                                                          \
-    hipLaunchKernelGGL((knn_filter2_kernel<KCV, AGGV>), g2, dim3(kF2Waves * kWave), l2, s, F);                \
+    hipLaunchKernelGGL((knn_filter2_kernel<KCV, EX>), g2, dim3(kF2Waves * kWave), l2, s, F);                  \
   } while (0)
-          const bool agg = K > 256;
-          if (kc == 1) { if (agg) DGCN_KNN2_LAUNCH(1, true); else DGCN_KNN2_LAUNCH(1, false); }
-          else { if (agg) DGCN_KNN2_LAUNCH(2, true); else DGCN_KNN2_LAUNCH(2, false); }
+          if (kc == 1) { if (exclude_self) DGCN_KNN2_LAUNCH(1, true); else DGCN_KNN2_LAUNCH(1, false); }
+          else { if (exclude_self) DGCN_KNN2_LAUNCH(2, true); else DGCN_KNN2_LAUNCH(2, false); }
+          const size_t l3 = knn_select_lds_bytes();
+          const dim3 g3(static_cast<unsigned>((pts + kSelWaves - 1) / kSelWaves));
+          hipLaunchKernelGGL(knn_select_lists_kernel, g3, dim3(kSelWaves * kWave), l3, s, F);
 #undef DGCN_KNN2_LAUNCH
         } else {
         const size_t blds = knn_filter_bf16_lds_bytes(bcap);
