@@ -481,6 +481,18 @@ def extras(dev, level="default"):
                                                "fwd+bwd+Adam", ms_per_step=r28["ms_per_step"], peak_mem_gb=r28["peak_mem_gb"],
                                       edges_per_s=8 * 4096 * 16 * 28 / (r28["ms_per_step"] * 1e-3), cpu_baseline=None,
                                       cpu_baseline_note=CPU_NOTE)
+    # the same step replayed as ONE hipGraph: ~620 launches at ~25 us of host time each bound the eager step, not the device
+    try:
+        from deep_gcns_torch_amd.graphs import GraphedStep
+
+        def make_dense_g():
+            m, _ = make_dense()
+            return m, _adam(m.parameters(), capturable=True)
+        g28 = _variant(dev, make_dense_g, lambda m, opt: GraphedStep(dense_step_of(m, opt), warmup=2), 5, 1)
+        out["resgcn28_train_step_hipgraph"] = dict(ms_per_step=g28["ms_per_step"], peak_mem_gb=g28["peak_mem_gb"],
+                                                   edges_per_s=8 * 4096 * 16 * 28 / (g28["ms_per_step"] * 1e-3))
+    except Exception as exc:   # noqa: BLE001 -- reported, the eager number stands
+        out["resgcn28_train_step_hipgraph"] = {"error": repr(exc)[:200]}
     sect["dense"] = time.perf_counter() - t_sect
     _trace("dense section done")
     t_sect = time.perf_counter()

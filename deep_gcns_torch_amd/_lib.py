@@ -89,6 +89,8 @@ _SIGNATURES = {
                                           C.c_int32, C.c_void_p]),
     "dgcn_softmax_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_void_p]),
+    "dgcn_softmax_state_merge_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dgcn_graph_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "dgcn_graph_csr_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -669,9 +669,13 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         oa, la = state_fwd(xl, sg.local, t, **msg_kw)    # runs while the remote rows are in flight
         work.wait()
         ob, lb = state_fwd(full, sg.remote, t, **msg_kw)
-        has_a = (sg.local.deg > 0).unsqueeze(1)
-        has_b = (sg.remote.deg > 0).unsqueeze(1)
-        out, L = merge_softmax_states(oa, la, has_a, ob, lb, has_b)
+        if state_fwd is _hip_state_fns()[0]:
+            from . import ops
+            out, L = ops.softmax_state_merge(oa, la, sg.local, ob, lb, sg.remote)      # one launch, in place in (oa, la)
+        else:
+            has_a = (sg.local.deg > 0).unsqueeze(1)
+            has_b = (sg.remote.deg > 0).unsqueeze(1)
+            out, L = merge_softmax_states(oa, la, has_a, ob, lb, has_b)
         ctx.sg, ctx.group, ctx.t, ctx.state_bwd, ctx.tensor_coll = sg, group, t, state_bwd, tensor_coll
         ctx.msg_kw = msg_kw
         ctx.save_for_backward(xl, full, L)
@@ -706,30 +710,109 @@ class _SplitSoftmaxAggregate(torch.autograd.Function):
         return g_loc + back[:xl.size(0)], None, None, None, None, None, None
 
 
+class _AllGatherRowsAsync(torch.autograd.Function):
+    """``_AllGatherRows`` whose forward only STARTS the collective: the caller waits on ``holder["work"]`` before the first
+    use of the returned rows (the local-source aggregation runs in between).  Backward = reduce-scatter(sum), as there."""
+
+    @staticmethod
+    def forward(ctx, x_local, max_rows: int, group, holder):
+        world = dist.get_world_size(group)
+        n_local, C = x_local.shape
+        ctx.n_local, ctx.max_rows, ctx.group = n_local, max_rows, group
+        send = x_local.new_zeros(max_rows, C)
+        send[:n_local] = x_local
+        full = x_local.new_empty(world * max_rows, C)
+        if _supports_tensor_collectives(group):
+            holder["work"] = dist.all_gather_into_tensor(full, send, group=group, async_op=True)
+        else:
+            holder["work"] = dist.all_gather(list(full.view(world, max_rows, C).unbind(0)), send, group=group, async_op=True)
+        holder["send"] = send                      # kept alive until the wait
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        return _AllGatherRows.backward(ctx, g_full) + (None,)
+
+
+class _TouchGrad(torch.autograd.Function):
+    """``out`` unchanged, but ``other`` receives a zero gradient: keeps a collective's backward in the graph of a rank whose
+    rows have no remote-source edge (every rank must enter the reduce-scatter)."""
+
+    @staticmethod
+    def forward(ctx, out, other):
+        ctx.shape, ctx.dtype, ctx.device = other.shape, other.dtype, other.device
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, torch.zeros(ctx.shape, dtype=ctx.dtype, device=ctx.device)
+
+
+def _split_composed_aggregate(x_local, sg, aggr, group, local_aggregate, kw):
+    """add / mean / max over a SplitGraph: the two partial aggregations are this library's kernels (each with its own
+    autograd function), the (n, C) merge is elementwise torch whose backward autograd derives:
+      add:   a + b                      mean: (add_a + add_b) / max(deg, 1)
+      max:   the larger of the two partial maxima (a row without edges in one set takes the other's)
+    The remote rows travel while the local-source part runs.  (Power-mean is NOT composed from partial outputs: the
+    reference clamps the mean of m^p to [1e-7, 100] before the root, torch_message.py:70-74, so a partial output whose
+    mean fell below the clamp -- every message of the part at eps -- no longer determines sum m^p; measured 4 % error on
+    such rows.  It stays on the all-gather scheme until the kernels export the pre-clamp sum.)"""
+    holder = {}
+    full = _AllGatherRowsAsync.apply(x_local, sg.max_rows, group, holder)
+    base = aggr
+    part_aggr = "add" if base == "mean" else base
+    a = local_aggregate(x_local, sg.local, aggr=part_aggr, **kw)
+    holder.pop("work").wait()
+    holder.clear()
+    b = local_aggregate(full, sg.remote, aggr=part_aggr, **kw)
+    if sg.remote.n_edges == 0 or not b.requires_grad:
+        a = _TouchGrad.apply(a, full)
+    da, db = sg.local.deg.unsqueeze(1).to(a.dtype), sg.remote.deg.unsqueeze(1).to(a.dtype)
+    if base == "add":
+        return a + b
+    if base == "mean":
+        return (a + b) / (da + db).clamp_min(1.0)
+    if base == "max":
+        both = (da > 0) & (db > 0)
+        return torch.where(both, torch.maximum(a, b), torch.where(da > 0, a, b))
+    raise NotImplementedError(aggr)
+
+
+_SPLIT_COMPOSED = ("add", "mean", "max")
 _SPLIT_KWARGS = {"t", "eps", "relu_eps", "learn_t", "learn_p", "p", "edge_attr", "edge_encoder", "dim_size", "add_root"}
 
 
 def split_supported(aggr: str, kw: dict) -> bool:
-    """softmax / softmax_sg with a fixed temperature and node features only.  ``eps`` / ``relu_eps`` are passed on to the
-    state kernels; anything that changes the result and is not handled (``add_root``, a ``dim_size`` other than the
+    """Node features only; softmax / softmax_sg with a fixed temperature (exact merge of the partial states from their
+    log-sum-exps, one HIP launch), add / mean / max (partial aggregations merged elementwise).  ``eps`` /
+    ``relu_eps`` are passed on to the kernels; anything that changes the result and is not handled (``add_root``, a ``dim_size`` other than the
     partition's rows, an unknown keyword) makes the caller fall back to the all-gather scheme instead of being dropped."""
     if any(k not in _SPLIT_KWARGS for k in kw):
         return False
-    return (aggr in ("softmax", "softmax_sg") and not kw.get("learn_t") and kw.get("edge_attr") is None
-            and kw.get("edge_encoder") is None and not isinstance(kw.get("t", 1.0), torch.Tensor)
-            and not kw.get("add_root") and not kw.get("learn_p"))
+    if kw.get("edge_attr") is not None or kw.get("edge_encoder") is not None or kw.get("add_root"):
+        return False
+    if aggr in _SPLIT_COMPOSED:               # partial aggregations merged elementwise
+        return True
+    return (aggr in ("softmax", "softmax_sg") and not kw.get("learn_t") and not isinstance(kw.get("t", 1.0), torch.Tensor)
+            and not kw.get("learn_p"))
 
 
 def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "softmax", group=None, state_fns=None,
-                        **kw) -> torch.Tensor:
+                        local_aggregate=None, **kw) -> torch.Tensor:
     """Local-first aggregation of this rank's destination rows (``SplitGraph``).  softmax / softmax_sg with a fixed
     temperature (BASELINE config 4); ``state_fns = (forward, backward)`` defaults to the HIP entry points
     (``ops.softmax_state_forward`` / ``_backward``), the gloo tests inject torch restatements."""
     if not split_supported(aggr, kw):
-        raise NotImplementedError("the local-first scheme covers softmax / softmax_sg with a fixed temperature; use the "
-                                  "allgather scheme for the other aggregators")
+        raise NotImplementedError("the local-first scheme covers softmax / softmax_sg with a fixed temperature and add / "
+                                  "mean / max on node features; use the allgather scheme otherwise")
     if kw.get("dim_size") not in (None, sg.n_local):
         raise ValueError(f"dim_size = {kw['dim_size']} but this rank's partition has {sg.n_local} destination rows")
+    if aggr in _SPLIT_COMPOSED:
+        if local_aggregate is None:
+            from . import ops
+            local_aggregate = ops.gen_aggregate
+        ckw = {k: v for k, v in kw.items() if k in ("eps", "relu_eps")}
+        return _split_composed_aggregate(x_local, sg, aggr, group, local_aggregate, ckw)
     fwd, bwd = state_fns or _hip_state_fns()
     msg_kw = {k: kw[k] for k in ("eps", "relu_eps") if k in kw}
     return _SplitSoftmaxAggregate.apply(x_local, sg, group, float(kw.get("t", 1.0)), fwd, bwd, msg_kw)
@@ -739,7 +822,6 @@ def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **
     """Scheme-agnostic entry: ``part`` is a PartitionedGraph (all-gather scheme) or a TransposedGraph."""
     if isinstance(part, SplitGraph):
         kw.pop("pipeline_chunks", None)
-        kw.pop("local_aggregate", None)
         return split_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
     if isinstance(part, TransposedGraph):
         return transposed_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
@@ -749,17 +831,78 @@ def aggregate(x_local: torch.Tensor, part, aggr: str = "softmax", group=None, **
     return partitioned_gen_aggregate(x_local, part, aggr=aggr, group=group, **kw)
 
 
+def exchange_bytes(edge_index: torch.Tensor, num_nodes: int, channels: int, rank: int, world: int,
+                   node_groups: Optional[int] = None, bounds: Optional[List[int]] = None) -> dict:
+    """Bytes THIS rank receives per direction (forward; the backward sends the same amount back) under each scheme, and how
+    its edges split by the owner of the source -- computed from the edge list alone, no collective:
+      allgather / split: (W - 1) padded row blocks of C channels;   halo: the distinct remote source rows of its edges;
+      transposed: the rows of the other ranks in its channel block + the group-local exchange of the output."""
+    src, dst = edge_index[0], edge_index[1]
+    if bounds is None:
+        bounds = balanced_bounds(torch.bincount(dst, minlength=num_nodes), world)
+    max_rows = (max(bounds[r + 1] - bounds[r] for r in range(world)) + 3) // 4 * 4
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = (dst >= lo) & (dst < hi)
+    lsrc = src[mine]
+    own = (lsrc >= lo) & (lsrc < hi)
+    n_edges, n_own = int(mine.sum()), int(own.sum())
+    n_halo = int(torch.unique(lsrc[~own]).numel())
+    out = dict(edges=n_edges, local_source_edges=n_own, remote_source_edges=n_edges - n_own, halo_rows=n_halo,
+               rows=hi - lo, allgather=(world - 1) * max_rows * channels * 4, halo=n_halo * channels * 4)
+    out["split"] = out["allgather"]
+    if node_groups is None:
+        node_groups = default_node_groups(channels, world)
+    if world > 1 and transposed_supported(channels, world, None, node_groups):
+        wc = world // node_groups
+        cw = channels // wc
+        eq = equal_row_bounds(num_nodes, world)
+        mr = (max(eq[r + 1] - eq[r] for r in range(world)) + 3) // 4 * 4
+        out["transposed"] = (world - 1) * mr * cw * 4 + (wc - 1) * mr * cw * 4
+    return out
+
+
+def choose_scheme(costs: dict, aggr: Optional[str] = None, kw: Optional[dict] = None) -> str:
+    """The scheme ``build_partition("auto")`` takes, from ``exchange_bytes`` (of the rank with the largest halo when the
+    caller reduced it): the halo exchange when the partition references few remote rows (at most half the bytes of the
+    best dense scheme: its all-to-all is irregular and pays a gather copy on the owner); otherwise the channel-transposed
+    scheme where it applies (W / 2 times fewer bytes than the all-gather); otherwise the all-gather volume -- as the
+    local-first ``split`` when the aggregator has an associative partial state and at least a quarter of the edges have
+    a local source (that share of the kernel time hides the exchange), plain ``allgather`` if not."""
+    dense = min(costs.get("transposed", costs["allgather"]), costs["allgather"])
+    if costs["halo"] * 2 <= dense:
+        return "halo"
+    if "transposed" in costs:
+        return "transposed"
+    if aggr is not None and split_supported(aggr, kw or {}) and costs["local_source_edges"] * 4 >= costs["edges"]:
+        return "split"
+    return "allgather"
+
+
 def build_partition(edge_index: torch.Tensor, num_nodes: int, channels: int, rank: int, world: int,
                     scheme: str = "auto", edge_attr=None, need_transpose: bool = True,
-                    node_groups: Optional[int] = None):
-    """``scheme``: "transposed", "allgather", "halo" or "auto" (transposed whenever it applies: it moves several times
-    fewer bytes per rank; graphs whose partitions reference few remote rows are the all-gather scheme's case).
+                    node_groups: Optional[int] = None, aggr: Optional[str] = None, group=None):
+    """``scheme``: "transposed", "allgather", "halo", "split" or "auto" = ``choose_scheme`` on the bytes each scheme moves
+    for THIS graph (``exchange_bytes``; the ranks agree on the largest halo with one all-reduce when a process group is
+    up): a locality-ordered graph takes the halo exchange, a graph whose partitions reference every row the
+    channel-transposed scheme (where the channel count allows it) or the all-gather / local-first pair.
     ``node_groups`` (transposed only): None = ``default_node_groups(channels, world)``."""
     if node_groups is None:
         node_groups = default_node_groups(channels, world)
     if scheme == "auto":
-        ok = world > 1 and transposed_supported(channels, world, edge_attr, node_groups)
-        scheme = "transposed" if ok else "allgather"
+        if world <= 1:
+            scheme = "allgather"
+        else:
+            costs = exchange_bytes(edge_index, num_nodes, channels, rank, world, node_groups)
+            if edge_attr is not None:
+                costs.pop("transposed", None)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) == world:
+                t = torch.tensor([costs["halo"], -costs["local_source_edges"] * 4 + costs["edges"]],
+                                 device=edge_index.device, dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)      # every rank takes the same decision
+                costs["halo"] = int(t[0])
+                if int(t[1]) > 0:                                          # some rank has < 1/4 local-source edges
+                    costs["local_source_edges"] = 0
+            scheme = choose_scheme(costs, aggr, {} if edge_attr is None else {"edge_attr": edge_attr})
     if scheme == "transposed":
         return TransposedGraph.from_edge_index(edge_index, num_nodes, rank, world, need_transpose=need_transpose,
                                                node_groups=node_groups)

@@ -607,6 +607,29 @@ def softmax_state_forward(x: torch.Tensor, graph: Graph, t: float = 1.0, relu_ep
     return out, L
 
 
+def softmax_state_merge(out_a: torch.Tensor, lse_a: torch.Tensor, graph_a: Graph, out_b: torch.Tensor, lse_b: torch.Tensor,
+                        graph_b: Graph):
+    """``(out, L)`` of the softmax aggregation over the UNION of two disjoint edge sets of the same destination rows from
+    the two partial ``softmax_state_forward`` results, one launch (``dgcn_softmax_state_merge_f32``); written into
+    ``out_a`` / ``lse_a``."""
+    lib = _lib.load()
+    dev = _lib.require_device(out_a, lse_a, out_b, lse_b)
+    n, C = out_a.shape
+    if graph_a.n_dst != n or graph_b.n_dst != n or out_b.shape != out_a.shape:
+        raise ValueError("the two partial states must cover the same destination rows")
+    if C % 4 != 0:                                   # (the aggregation kernels serve such widths; the merge does not)
+        both = ((graph_a.deg > 0) & (graph_b.deg > 0)).unsqueeze(1)
+        only_a = (graph_a.deg > 0).unsqueeze(1)
+        w = torch.where(both, torch.sigmoid(lse_a - lse_b), only_a.to(out_a.dtype).expand_as(out_a))
+        return w * out_a + (1.0 - w) * out_b, torch.where(both, torch.logaddexp(lse_a, lse_b), torch.where(only_a, lse_a, lse_b))
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_softmax_state_merge_f32(out_a.data_ptr(), lse_a.data_ptr(), graph_a.rowptr.data_ptr(), out_b.data_ptr(),
+                                              lse_b.data_ptr(), graph_b.rowptr.data_ptr(), out_a.data_ptr(), lse_a.data_ptr(),
+                                              n, C, _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_softmax_state_merge_f32")
+    return out_a, lse_a
+
+
 def softmax_state_prepare(g: torch.Tensor, L: torch.Tensor):
     """The node-wise prologue of the single-gather softmax backward for a given log-sum-exp array: ``(g exp(-L), zeros,
     range flag)``; shared by the backward launches of a split aggregation."""

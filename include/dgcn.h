@@ -335,6 +335,17 @@ int dgcn_power_bwd_prep_f32(const dgcn_graph* g, const float* grad_out, const fl
 int dgcn_softmax_bwd_prep_f32(const float* g, const float* L, const float* kshift, float* out,
                               int64_t n_rows, int32_t channels, void* stream);
 
+/* Merge of two partial softmax aggregations of the same destination rows over DISJOINT edge sets (the local-source and
+ * the remote-source edges of a destination partition, deep_gcns_torch_amd/dist.py SplitGraph): from
+ * (out_a, lse_a) and (out_b, lse_b) as dgcn_gen_aggr_fwd_f32 writes them (out + aux1 = log-sum-exp; 0 for rows without
+ * edges -- the two CSR row pointers say which rows those are)
+ *   out = sigmoid(lse_a - lse_b) out_a + sigmoid(lse_b - lse_a) out_b,   lse = logaddexp(lse_a, lse_b)
+ * exactly the aggregation over the union (gcn_lib/sparse/torch_message.py:54-58).  All arrays [n_rows, channels] fp32
+ * contiguous and 16-byte aligned, channels % 4 == 0; out / lse may alias out_a / lse_a. */
+int dgcn_softmax_state_merge_f32(const float* out_a, const float* lse_a, const int32_t* rowptr_a, const float* out_b,
+                                 const float* lse_b, const int32_t* rowptr_b, float* out, float* lse, int64_t n_rows,
+                                 int32_t channels, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Device-side graph structure.  The reference keeps a COO edge_index and re-partitions it on
  * the host every epoch (utils/data_util.py:43-61 random_partition_graph / generate_sub_graphs: scipy CSR slicing;

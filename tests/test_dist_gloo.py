@@ -475,3 +475,84 @@ def test_local_first_split_scheme_matches_single_process(world, t):
         lo, hi = bounds[rank], bounds[rank + 1]
         torch.testing.assert_close(out, ref[lo:hi].detach(), rtol=1e-10, atol=1e-12)
         torch.testing.assert_close(gx, x.grad[lo:hi], rtol=1e-10, atol=1e-12)
+
+
+# ---- local-first scheme for the aggregators with an associative partial state (round 6) --------------------------------
+def _split_composed_worker(rank, world, port, aggr, kw, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_gcns_torch_amd.dist import SplitGraph, build_partition, aggregate, split_supported, exchange_bytes, choose_scheme
+        torch.set_num_threads(2)
+        n, C = 257, 16
+        ei = synth.tricky_graph()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(n, C, generator=g, dtype=torch.float64)
+        probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+        part = build_partition(ei, n, C, rank, world, scheme="split")
+        assert isinstance(part, SplitGraph) and split_supported(aggr, kw)
+        assert not split_supported(aggr, dict(kw, add_root=True)) and not split_supported(aggr, dict(kw, bogus=1))
+        assert not split_supported("power", {"p": 2.0})             # (clamped partial means do not merge: dist.py)
+        xl = x[part.lo:part.hi].clone().requires_grad_(True)
+        pk = dict(kw)
+        p_param = None
+        if pk.get("learn_p"):
+            p_param = torch.tensor([pk["p"]], dtype=torch.float64, requires_grad=True)
+            pk["p"] = p_param
+        out = aggregate(xl, part, aggr=aggr, local_aggregate=_oracle_local, **pk)
+        # (a rank whose rows have no in-edge at all -- the tricky graph has one -- returns constants: keep the loss
+        # differentiable there, every rank must enter the backward's collective)
+        ((out * probe[part.lo:part.hi]).sum() + 0.0 * xl.sum()).backward()
+        gp = (p_param.grad.detach() if p_param is not None and p_param.grad is not None
+              else torch.zeros(1, dtype=torch.float64))
+        costs = exchange_bytes(ei, n, C, rank, world)
+        auto = build_partition(ei, n, C, rank, world, scheme="auto", aggr=aggr)     # every rank must take the same scheme
+        q.put(_pack((rank, part.bounds, out.detach(), xl.grad.detach(), gp, costs["halo_rows"], type(auto).__name__,
+                     choose_scheme(costs, aggr))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("aggr,kw", [("max", {}), ("add", {}), ("mean", {}), ("max", {"eps": 1e-3}),
+                                     ("mean", {"eps": 1e-3})])
+@_retry_rendezvous()
+def test_local_first_split_scheme_for_max_add_mean(aggr, kw):
+    """The partial aggregations over the local-source and the remote-source edges merged elementwise (dist.
+    _split_composed_aggregate): outputs, input gradients and the gradient of a learnable p equal the oracle's on the whole
+    graph; keywords the scheme does not handle are refused, not dropped; ``build_partition("auto")`` takes the same
+    scheme on every rank."""
+    from oracle import sparse_ref
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_composed_worker, args=(r, world, port, aggr, kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    rk = dict(kw)
+    p_ref = None
+    if rk.get("learn_p"):
+        p_ref = torch.tensor([rk["p"]], dtype=torch.float64, requires_grad=True)
+        rk["p"] = p_ref
+    rk.pop("learn_p", None)
+    ref = sparse_ref.gen_propagate(x, ei, aggr=aggr, **rk)
+    (ref * probe).sum().backward()
+    bounds = res[0][1]
+    for rank, b, out, gx, gp, halo, auto_cls, chosen in res:
+        lo, hi = bounds[rank], bounds[rank + 1]
+        torch.testing.assert_close(out, ref[lo:hi].detach(), rtol=1e-9, atol=1e-11)
+        torch.testing.assert_close(gx, x.grad[lo:hi], rtol=1e-9, atol=1e-11)
+    if p_ref is not None:
+        torch.testing.assert_close(sum(r[4] for r in res), p_ref.grad, rtol=1e-8, atol=1e-10)
+    assert len({r[6] for r in res}) == 1, "the ranks disagree on the scheme build_partition('auto') took"
