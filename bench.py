@@ -169,6 +169,53 @@ def emulate_ranks(args, dev, ei, n, C, worlds, t1_ms):
     gen = torch.Generator(device=dev).manual_seed(7)
     for W in worlds:
         entry = {}
+        bounds_w = ddist.balanced_bounds(torch.bincount(ei[1], minlength=n), W)
+        # ---- halo and local-first (split): what each rank's kernels run on, and what it receives (round 6) -----------
+        costs = [ddist.exchange_bytes(ei, n, C, r, W, bounds=bounds_w) for r in range(W)]
+        entry["exchange_bytes_per_rank"] = costs
+        worst = dict(costs[0])
+        worst["halo"] = max(c["halo"] for c in costs)
+        if min(c["local_source_edges"] * 4 - c["edges"] for c in costs) < 0:
+            worst["local_source_edges"] = 0
+        entry["auto_scheme"] = ddist.choose_scheme(worst, args.aggr, {"t": args.t})
+        links = min(W - 1, 7)
+        ms_h, halo_rows, ms_loc, ms_rem, loc_e, rem_e = [], [], [], [], [], []
+        for r in range(W):
+            gh, n_halo = ddist.HaloGraph.local_graph(ei, n, r, W, bounds=bounds_w)
+            x_in = torch.randn(gh.n_src, C, device=dev, generator=gen).requires_grad_(True)
+            g_out = torch.randn(gh.n_dst, C, device=dev, generator=gen)
+            ms_h.append(time_local(gh, x_in, g_out))
+            halo_rows.append(n_halo)
+            del gh, x_in
+            sg = ddist.SplitGraph.from_edge_index(ei, n, r, W, bounds=bounds_w)
+            x_loc = torch.randn(sg.local.n_src, C, device=dev, generator=gen).requires_grad_(True)
+            x_rem = torch.randn(sg.remote.n_src, C, device=dev, generator=gen).requires_grad_(True)
+            ms_loc.append(time_local(sg.local, x_loc, g_out) if sg.local.n_edges else 0.0)
+            ms_rem.append(time_local(sg.remote, x_rem, g_out) if sg.remote.n_edges else 0.0)
+            loc_e.append(sg.local.n_edges)
+            rem_e.append(sg.remote.n_edges)
+            del sg, x_loc, x_rem, g_out
+            torch.cuda.empty_cache()
+        recv_h = max(halo_rows) * C * 4
+        recv_ag = costs[0]["allgather"]
+        proj_h, proj_s = {}, {}
+        for bw in (40, 60, 77):
+            t_h = 2 * recv_h / (links * bw * 1e9) * 1e3
+            proj_h[f"{bw}GBs_per_link"] = dict(exchange_ms=t_h, speedup_no_overlap=t1_ms / (max(ms_h) + t_h),
+                                               speedup_full_overlap=t1_ms / max(max(ms_h), t_h))
+            t_a = 2 * recv_ag / (links * bw * 1e9) * 1e3
+            # local-first: the local-source part runs while the rows travel, the remote-source part after them
+            step = max(max(max(a, t_a) + b for a, b in zip(ms_loc, ms_rem)), 0.0)
+            proj_s[f"{bw}GBs_per_link"] = dict(exchange_ms=t_a, speedup_local_part_hides_exchange=t1_ms / step)
+        entry["halo"] = dict(local_fwd_bwd_ms_per_rank=ms_h, local_ms_max=max(ms_h), halo_rows_per_rank=halo_rows,
+                             halo_fraction_of_remote_rows=[h / max(n - c["rows"], 1) for h, c in zip(halo_rows, costs)],
+                             bytes_received_per_rank_per_direction=recv_h, links_used=links,
+                             compute_only_speedup=t1_ms / max(ms_h), projection=proj_h)
+        entry["split"] = dict(local_part_ms_per_rank=ms_loc, remote_part_ms_per_rank=ms_rem,
+                              local_source_edges_per_rank=loc_e, remote_source_edges_per_rank=rem_e,
+                              local_source_fraction=sum(loc_e) / max(sum(loc_e) + sum(rem_e), 1),
+                              bytes_received_per_rank_per_direction=recv_ag, links_used=links,
+                              compute_only_speedup=t1_ms / max(a + b for a, b in zip(ms_loc, ms_rem)), projection=proj_s)
         for scheme in ("allgather", "transposed"):
             wn = 1
             if scheme == "transposed":

@@ -40,7 +40,7 @@ if which.startswith("deepergcn"):
         ei = synth.undirected_random_graph(n, sp["n_undirected"] // 100, sp["seed"] + 1, device=dev)
     x, y = torch.randn(n, cin, device=dev), torch.randint(0, ncls, (n,), device=dev)
     m = fuse.fuse_model(arch_restated.DeeperGCN(num_layers=L, in_channels=cin, hidden=128, num_tasks=ncls, dropout=0.5).to(dev).train())
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed, fused=True)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -50,7 +50,7 @@ elif which.startswith("resgcn28"):
     m = arch_restated.DenseDeepGCN(n_blocks=28, channels=64, k=16, in_channels=9, n_classes=13).to(dev).train()
     x = torch.cat([torch.rand(8, 3, 4096, 1), torch.rand(8, 6, 4096, 1)], 1).to(dev)
     y = torch.randint(0, 13, (8, 4096), device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed, fused=True)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -70,7 +70,7 @@ else:
                                      impl="product").to(dev).train()
     if "product" not in which:        # *_product: install() alone, the fused edge-GEMM path of eff_gcn_modules.rev
         m = fuse.fuse_model(m)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graphed, fused=True)
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -842,7 +842,7 @@ extern "C" int dgcn_dense_edge_reduce_bwd_inv_f32(const float* P, int64_t ldp, c
   if (B == 0) return DGCN_OK;
   const InvWs W = inv_layout(workspace, B, N, C, k);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  zero_async(W.cnt, static_cast<size_t>(B) * N * sizeof(int32_t), s);      // a kernel, not a memset node: dgcn_common.h
+  if (const int zrc = zero_async(W.cnt, static_cast<size_t>(B) * N * sizeof(int32_t), s)) return zrc;   // a kernel, not a memset node: dgcn_common.h
   EdgeParams E{};
   E.P = P; E.Q = Q; E.ldp = ldp; E.ldq = ldq; E.idx = idx; E.ib = idx_sb; E.in_ = idx_sn; E.ik = idx_sk;
   E.B = B; E.N = N; E.C = C; E.k = k; E.act = act; E.slope = slope;

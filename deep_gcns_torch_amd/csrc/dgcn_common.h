@@ -99,12 +99,13 @@ static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __rest
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
 }
 
-static inline void zero_async(void* p, size_t bytes, hipStream_t s) {       // bytes % 4 == 0, p 4-byte aligned
+static inline int zero_async(void* p, size_t bytes, hipStream_t s) {        // bytes % 4 == 0, p 4-byte aligned
   const size_t n = bytes / 4;
-  if (n == 0) return;
+  if (n == 0) return DGCN_OK;
   size_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(zero_words_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, static_cast<uint32_t*>(p), n);
+  return launch_status();                      // (the hipMemsetAsync this replaced returned its error too: ADVICE r5)
 }
 
 // Grid size for a wave-per-item kernel: enough workgroups to keep every CU's 32 wave

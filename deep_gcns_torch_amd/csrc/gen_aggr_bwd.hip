@@ -810,7 +810,7 @@ int gen_aggr_bwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
     if (!workspace) return DGCN_E_NULL;
     P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                           dgcn_gen_aggr_bwd_workspace_bytes(g, channels) - kTicketBytes);
-    zero_async(P.ticket, kTicketBytes, static_cast<hipStream_t>(stream));     // a kernel, not a memset node: dgcn_common.h
+    if (const int zrc = zero_async(P.ticket, kTicketBytes, static_cast<hipStream_t>(stream))) return zrc;   // a kernel, not a memset node: dgcn_common.h
   }
   const int grid = bwd_grid(g, channels, vec4, enc != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);

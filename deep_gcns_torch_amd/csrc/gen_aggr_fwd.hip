@@ -673,7 +673,7 @@ int gen_aggr_fwd_impl(const dgcn_graph* g, const float* x, int64_t x_stride,
     if (!workspace) return DGCN_E_NULL;
     P.ticket = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) +
                                           dgcn_gen_aggr_fwd_workspace_bytes(g, channels) - kTicketBytes);
-    zero_async(P.ticket, kTicketBytes, static_cast<hipStream_t>(stream));     // a kernel, not a memset node: dgcn_common.h
+    if (const int zrc = zero_async(P.ticket, kTicketBytes, static_cast<hipStream_t>(stream))) return zrc;   // a kernel, not a memset node: dgcn_common.h
   }
 
   const int per_wave = vec4 ? kWave / subgroup_width(lpr, (g->n_work ? g->n_work : g->n_dst), g->n_edges) : 1;   // items walked side by side by one wave

@@ -504,6 +504,25 @@ class HaloGraph:
     def n_halo(self) -> int:
         return sum(self.recv_counts)
 
+    @staticmethod
+    def local_graph(edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, bounds: Optional[List[int]] = None,
+                    need_transpose: bool = True):
+        """``(Graph over [own rows | halo rows], n_halo)`` of one rank WITHOUT the index exchange (no collective): what
+        the rank's kernels run on.  ``bench.py --emulate-ranks`` times it for every rank on one GPU."""
+        src, dst = edge_index[0], edge_index[1]
+        if bounds is None:
+            bounds = balanced_bounds(torch.bincount(dst, minlength=num_nodes), world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        mine = (dst >= lo) & (dst < hi)
+        lsrc, ldst = src[mine], dst[mine] - lo
+        is_local = (lsrc >= lo) & (lsrc < hi)
+        uniq, inverse = torch.unique(lsrc[~is_local], return_inverse=True)
+        col = torch.empty_like(lsrc)
+        col[is_local] = lsrc[is_local] - lo
+        col[~is_local] = (hi - lo) + inverse
+        n_halo = int(uniq.numel())
+        return Graph(col, ldst, n_src=hi - lo + n_halo, n_dst=hi - lo, need_transpose=need_transpose), n_halo
+
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int,
                         bounds: Optional[List[int]] = None, group=None, need_transpose: bool = True) -> "HaloGraph":

@@ -156,6 +156,11 @@ def fuse_model_class(cls) -> bool:
         return False
     setattr(cls, _ORIG, cls.forward)
     cls.forward = repl
+    # said once per class: install() routes a model file's layer loop differently than the file reads
+    import logging
+    logging.getLogger("deep_gcns_torch_amd").info(
+        "%s.%s.forward now runs through deep_gcns_torch_amd.fuse (same parameters, state_dict and values; "
+        "install(fuse_models=False) or fuse.unfuse_model_class restores the file's own loop)", cls.__module__, cls.__name__)
     return True
 
 

@@ -64,14 +64,21 @@ class options:
             self._kw[name] = v
 
     def __enter__(self):
-        self._prev = getattr(_TLS, "options", None)
-        merged = dict(self._prev or {})
+        # the previous overrides go on a PER-THREAD stack, not on this object: one captured_options() object is re-entered
+        # from autograd's thread (checkpoint recomputation, reversible layers), possibly nested or concurrently
+        # (retain_graph double backward, DataParallel replicas sharing a closure) -- ADVICE r5
+        prev = getattr(_TLS, "options", None)
+        stack = getattr(_TLS, "opt_stack", None)
+        if stack is None:
+            stack = _TLS.opt_stack = []
+        stack.append(prev)
+        merged = dict(prev or {})
         merged.update(self._kw)
         _TLS.options = merged
         return self
 
     def __exit__(self, *exc):
-        _TLS.options = self._prev
+        _TLS.options = _TLS.opt_stack.pop()
         return False
 
 

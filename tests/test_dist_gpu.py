@@ -130,6 +130,13 @@ def test_local_first_split_states_on_the_hip_kernels(world, rank):
     ob, lb = ops.softmax_state_forward(x_full, sg.remote, t)
     out, L = merge_softmax_states(oa, la, (sg.local.deg > 0).unsqueeze(1), ob, lb, (sg.remote.deg > 0).unsqueeze(1))
     torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-6)
+    # the merge as ONE HIP launch (dgcn_softmax_state_merge_f32, in place in the local state) against the torch formula,
+    # rows with edges on one side only included (the power-law graph has them on every rank)
+    one_sided = int(((sg.local.deg > 0) ^ (sg.remote.deg > 0)).sum())
+    assert one_sided > 0
+    out_k, L_k = ops.softmax_state_merge(oa.clone(), la.clone(), sg.local, ob, lb, sg.remote)
+    torch.testing.assert_close(out_k, out, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(L_k, L, rtol=2e-6, atol=1e-6)
     gs = max(1.0, float(xf.grad.abs().max()))
     for prep in (None, ops.softmax_state_prepare(probe, L)):        # two-gather form, single-gather form
         g_rem = ops.softmax_state_backward(x_full, sg.remote, probe, L, t, prep=prep)
