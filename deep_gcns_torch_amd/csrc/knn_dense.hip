@@ -1743,6 +1743,9 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
       for (int rt = 0; rt < 2; ++rt) {
         const float4 tf4 = *reinterpret_cast<const float4*>(tauf + rt * 16 + lk * 4);
         const float4 sr4 = *reinterpret_cast<const float4*>(sq + rt * 16 + lk * 4);
+#ifdef KNNF_FULL_WAIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         const float tfv[4] = {tf4.x, tf4.y, tf4.z, tf4.w};
         const float srv[4] = {sr4.x, sr4.y, sr4.z, sr4.w};
 #pragma unroll
@@ -1752,7 +1755,7 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
             const int k = rt * 8 + reg * 2 + t;                      // slot: row = rt * 16 + lk * 4 + reg, candidate c0 + 16 t
             const float dist = (srv[reg] + (-2.f * acc[rt][t][reg])) + sj[t];
             bool hit = dist <= tfv[reg];
-            if constexpr (EXCL) hit = hit && (c0 + 16 * t) != i0 + rt * 16 + lk * 4 + reg;
+
             bits |= hit ? (1u << k) : 0u;
             dl[k * kWave + lane] = dist;
           }
@@ -1765,6 +1768,7 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
           const float dist = dl[k * kWave + lane];                   // (written by this lane: no barrier needed)
           const int r = (k >> 3) * 16 + lk * 4 + ((k >> 1) & 3);
           const int c = c0 + ((k & 1) << 4);
+          if (EXCL && c == i0 + r) continue;                          // exclude_self: the query point is not a candidate
           const int pos = atomicAdd(&cnt[r], 1);
           if (pos < CAP)
             *reinterpret_cast<uint2*>(lbase + static_cast<uint32_t>(r * CAP + pos) * 8u) =
@@ -1856,10 +1860,25 @@ __global__ __launch_bounds__(kSelWaves * kWave) void knn_select_lists_kernel(con
   if (c < 0) return;
 #endif
   if (c < P.K || c > CAP) {   // hand the row to the exact kernel
+#ifdef KNNF_DEBUG_REDO
+    if (lane < P.Kout) P.nn_out[row * P.Kout + lane] = -7 - c;      // (debug builds: mark the row instead)
+    return;
+#endif
     if (lane == 0) P.redo[1 + atomicAdd(&P.redo[0], 1)] = static_cast<int>(row);
     return;
   }
   const uint2* list = P.lists + row * CAP;
+#ifdef KNNF_DEBUG_REDO
+  if (lane == 0 && P.ctr_out) P.ctr_out[row * P.Kout + P.Kout - 1] = c;       // (debug builds: the list length, read by the host)
+  KnnParams Q = P;
+  Q.ctr_out = nullptr;
+  if (c <= 2 * kWave) filter_select_list<2, 512>(Q, list, sa, sb, c, b, i, lane);
+  else if (c <= 4 * kWave) filter_select_list<4, 512>(Q, list, sa, sb, c, b, i, lane);
+  else if (c <= 8 * kWave) filter_select_list<8, 512>(Q, list, sa, sb, c, b, i, lane);
+  else if (c <= 12 * kWave) filter_select_list<12, 1024>(Q, list, sa, sb, c, b, i, lane);
+  else filter_select_list<16, 1024>(Q, list, sa, sb, c, b, i, lane);
+  return;
+#endif
   if (c <= 2 * kWave) filter_select_list<2, 512>(P, list, sa, sb, c, b, i, lane);
   else if (c <= 4 * kWave) filter_select_list<4, 512>(P, list, sa, sb, c, b, i, lane);
   else if (c <= 8 * kWave) filter_select_list<8, 512>(P, list, sa, sb, c, b, i, lane);
