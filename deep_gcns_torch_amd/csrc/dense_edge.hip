@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWgThreads, 2) void vertex_gemm_kernel(const GemmPa
 
 int gemm_grid(int64_t tiles) {
   const int64_t groups = (tiles + kWavesPerWg - 1) / kWavesPerWg;
-  return static_cast<int>(groups < 2 * kNumCU ? groups : 2 * kNumCU);
+  return static_cast<int>(groups < 2 * num_cus() ? groups : 2 * num_cus());
 }
 
 // ---------------------------------------------------------------------------------------
@@ -653,7 +653,7 @@ int bwd_nsplit(int B, int N, int C) {
   if (static_cast<size_t>(N) * kBwdSlice * 4 > 158u * 1024u) return 0;  // slice does not fit LDS: atomic path
   // one 128 KB workgroup per CU: aim for exactly one round of <= 256 workgroups
   const int base = B * ((C + kBwdSlice - 1) / kBwdSlice);
-  int ns = kNumCU / base;
+  int ns = num_cus() / base;
   if (ns < 1) ns = 1;
   if (ns > 16) ns = 16;
   while (ns > 1 && (N + ns - 1) / ns < 64) --ns;

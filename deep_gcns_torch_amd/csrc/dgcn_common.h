@@ -12,11 +12,30 @@ namespace dgcn {
 constexpr int kWave = 64;
 constexpr int kWgThreads = 256;           // 4 waves, one per SIMD
 constexpr int kWavesPerWg = kWgThreads / kWave;
-constexpr int kNumCU = 256;               // MI355X (SPX mode).  Used for GRID CAPS and partial-buffer sizing only: every kernel
+constexpr int kNumCU = 256;               // MI355X (SPX mode): the fallback of num_cus() below.  GRID CAPS and partial-buffer sizing only: every kernel
                                           // strides over its work, so on a partitioned (CPX: 32 CUs) device the grids are merely
                                           // larger than needed -- results are unaffected.  A compile-time constant on purpose: the
                                           // *_num_partials sizing calls and the launches must agree whatever device is current.
-constexpr int kNumXCD = 8;
+constexpr int kNumXCD = 8;                // XCDs of the SPX device: sizes the per-XCD work queues in DEVICE code (arrays), so it stays a
+                                          // constant; on a CPX partition (one XCD) the eight queues are merely drained by one die
+
+// Compute units of the device the process runs on, read ONCE (first use; function-local static = thread-safe) from
+// hipGetDeviceProperties of the then-current device -- SURVEY.md 8(b)'s call_once cache.  Grid caps and partial-buffer
+// sizes use it, so that the *_num_partials sizing calls and the launches agree whatever device is current later; without
+// a device (the CPU-only build container: tests/test_abi.py calls the sizing functions there) it is kNumCU.
+inline int num_cus() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        prop.multiProcessorCount <= 0) {
+      (void)hipGetLastError();                 // (no device: not an error of the caller's launch)
+      return kNumCU;
+    }
+    return prop.multiProcessorCount;
+  }();
+  return n;
+}
 
 #define DGCN_NEG_INF (-__builtin_inff())
 
@@ -113,7 +132,7 @@ static inline int zero_async(void* p, size_t bytes, hipStream_t s) {        // b
 // of tiny workgroups.
 inline int grid_for_waves(int64_t n_items, int waves_per_cu_target = 32) {
   int64_t wgs = (n_items + kWavesPerWg - 1) / kWavesPerWg;
-  const int64_t cap = static_cast<int64_t>(kNumCU) * waves_per_cu_target / kWavesPerWg * 4;
+  const int64_t cap = static_cast<int64_t>(num_cus()) * waves_per_cu_target / kWavesPerWg * 4;
   if (wgs > cap) wgs = cap;
   if (wgs < 1) wgs = 1;
   return static_cast<int>(wgs);

@@ -383,7 +383,7 @@ extern "C" int dgcn_edgeconv_bwd_input_f32(const float* dpq, const float* conv_w
   EbInputParams P{dpq, conv_w, g, gsb, gsc, gsn, res_scale, dx, B, C, N, Cout};
   const int64_t tiles = static_cast<int64_t>(B) * ((N + 15) / 16);
   const int64_t groups = (tiles + kWavesPerWg - 1) / kWavesPerWg;
-  const int grid = static_cast<int>(groups < 2 * kNumCU ? groups : 2 * kNumCU);     // persistent: see the kernel
+  const int grid = static_cast<int>(groups < 2 * num_cus() ? groups : 2 * num_cus());     // persistent: see the kernel
   hipLaunchKernelGGL(edgeconv_bwd_input_kernel, dim3(grid), dim3(kWgThreads), 0, static_cast<hipStream_t>(stream), P);
   return launch_status();
 }

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kMbWaves * kWave) void egemm_max_bwd_weight_kernel(
 }
 
 inline int mb_rows_per_wg(int n_dst) {
-  const int even = (n_dst + kNumCU - 1) / kNumCU;
+  const int even = (n_dst + num_cus() - 1) / num_cus();
   return even > kMbMinRows ? even : kMbMinRows;
 }
 

@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(kWgThreads) void egemm_fixup_kernel(const EgParams 
 
 // item length: one item per wave slot of the chip, a multiple of the 16-edge batch, at least kEgMinItem
 inline int eg_item_len(int n_edges, int waves_per_cu) {
-  const int64_t slots = static_cast<int64_t>(kNumCU) * waves_per_cu;
+  const int64_t slots = static_cast<int64_t>(num_cus()) * waves_per_cu;
   int64_t len = (n_edges + slots - 1) / slots;
   len = (len + kEgM - 1) / kEgM * kEgM;
   return static_cast<int>(len < kEgMinItem ? kEgMinItem : len);
@@ -1173,7 +1173,7 @@ int launch_egemm(const EgParams& P, const EgLayout& L, hipStream_t s) {
   int per_cu = static_cast<int>(kEgLdsBytes / L.lds_bytes);
   if (per_cu > 2) per_cu = 2;
   int grid = (P.n_items + L.nwaves - 1) / L.nwaves;
-  if (grid > kNumCU * per_cu) grid = kNumCU * per_cu;
+  if (grid > num_cus() * per_cu) grid = num_cus() * per_cu;
   hipLaunchKernelGGL((egemm_fwd_kernel<NT, KC>), dim3(grid), dim3(L.nwaves * kWave), L.lds_bytes, s, P);
   return DGCN_OK;
 }
@@ -1195,7 +1195,7 @@ int launch_egemm_bf16_mode(const EgParams& P, hipStream_t s) {
   int nwaves = w3 ? 12 : kEgMaxWaves;
   if (const int w = eg_tuning().waves; w >= 1 && w <= nwaves) nwaves = w;
   int grid = (P.n_items + nwaves - 1) / nwaves;
-  if (grid > kNumCU) grid = kNumCU;                 // the weight planes fill the LDS: one workgroup per CU
+  if (grid > num_cus()) grid = num_cus();                 // the weight planes fill the LDS: one workgroup per CU
   if constexpr (kHasW3) {
     if (w3) {
       hipLaunchKernelGGL((egemm_fwd_bf16_w3_kernel<NT, KC, MODE>), dim3(grid), dim3(nwaves * kWave), lds, s, P);

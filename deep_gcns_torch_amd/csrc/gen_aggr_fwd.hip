@@ -597,7 +597,7 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
   if (enc_uniform_walk(P, vec)) {
     // persistent grid: four waves per SIMD (the kernels' register budget), items claimed from the ticket counter
     const int n_items = P.g.n_work ? P.g.n_work : P.g.n_rows;
-    const int pgrid = min((n_items + kWavesPerWg - 1) / kWavesPerWg, kNumCU * 4);
+    const int pgrid = min((n_items + kWavesPerWg - 1) / kWavesPerWg, num_cus() * 4);
     if (P.C <= 128) launch_enc_fwd<MODE, 2>(P, pgrid, s); else launch_enc_fwd<MODE, 4>(P, pgrid, s);
   } else if (vec == 4) {
     // (LPR, SW) pairs: SW = LPR * edge groups per row (kEdgeGroups) when the graph has enough rows to fill the

@@ -340,7 +340,7 @@ inline bool rl_shape(int K, int C, RlShape* S) {
 inline int rl_grid_x(int64_t rows, int ncols) {
   const int64_t nbatch = (rows + kRlM - 1) / kRlM;
   int64_t gx = (nbatch + kRlWaves - 1) / kRlWaves;
-  int64_t cap = kNumCU / ncols;
+  int64_t cap = num_cus() / ncols;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   return static_cast<int>(gx < 1 ? 1 : gx);

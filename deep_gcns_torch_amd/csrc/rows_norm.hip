@@ -322,7 +322,7 @@ int pick_vec(int C, int64_t ld, const void* a, const void* b, const void* c, con
 
 int stream_grid(int64_t rows, int rpp) {
   int64_t wgs = (rows + rpp - 1) / rpp;
-  const int64_t cap = static_cast<int64_t>(kNumCU) * 16;
+  const int64_t cap = static_cast<int64_t>(num_cus()) * 16;
   if (wgs > cap) wgs = cap;
   return static_cast<int>(wgs < 1 ? 1 : wgs);
 }

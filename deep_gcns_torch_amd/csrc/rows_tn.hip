@@ -337,7 +337,7 @@ inline bool tn_shape(int C, int K, TnShape* S) {
 inline int tn_grid(int64_t rows) {
   const int64_t steps = rows / kTnStep;               // whole steps; the last workgroup takes the rows % 32 too
   int64_t g = (steps + 7) / 8;                        // at least eight steps per workgroup
-  if (g > kNumCU) g = kNumCU;
+  if (g > num_cus()) g = num_cus();
   return static_cast<int>(g < 1 ? 1 : g);
 }
 
