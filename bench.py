@@ -116,8 +116,12 @@ def cpu_baseline_range(graph, x_dev, channels, t, aggr, shape_name, frac=64, cou
     e0, e1 = int(rp[0]), int(rp[-1])
     src = graph.col[e0:e1].long().cpu()
     dst = torch.repeat_interleave(torch.arange(hi - lo), rp[1:] - rp[:-1])
-    ei_r = torch.stack([src, dst])
-    x = x_dev.detach().cpu().requires_grad_(True)
+    # the range's edges gather from the source rows they REFERENCE (relabelled): with the full 2.4 M-row x requiring grad,
+    # index_select's backward zero-filled and index_added a full (N, C) gradient per step and charged it to E / 64 edges
+    # (the CPU time per edge, and so the GPU / CPU ratio, was inflated)
+    uniq, src_r = torch.unique(src, return_inverse=True)
+    ei_r = torch.stack([src_r, dst])
+    x = x_dev.detach().cpu()[uniq].clone().requires_grad_(True)
     go = torch.randn(hi - lo, channels, generator=torch.Generator().manual_seed(0))
     E_r = e1 - e0
 
@@ -135,8 +139,9 @@ def cpu_baseline_range(graph, x_dev, channels, t, aggr, shape_name, frac=64, cou
     torch.set_num_threads(ncores)
     return dict(value=sweep[best], unit="edges/s", cores=best, kind="port",
                 sample=f"the headline workload itself ('{shape_name}' graph, C={channels}, {aggr} t={t}, fwd+bwd) restricted to "
-                       f"destination rows [{lo}, {hi}) = 1/{frac} of the rows: {E_r} edges whose sources are anywhere in the "
-                       f"{n} rows (oracle/sparse_ref.py on torch CPU ops; rows are independent, SURVEY.md 8(d) 'chunk by "
+                       f"destination rows [{lo}, {hi}) = 1/{frac} of the rows: {E_r} edges whose {uniq.numel()} distinct sources lie anywhere in the "
+                       f"{n} rows (gathered from their own compact array since round 6: the denominator changed, rounds 5 and 6 "
+                       f"are not comparable; oracle/sparse_ref.py on torch CPU ops; rows are independent, SURVEY.md 8(d) 'chunk by "
                        f"destination range'); 1 rep per thread count after a warm-up, thread sweep "
                        f"{ {k: round(v) for k, v in sweep.items()} } edges/s on a {ncores}-thread host",
                 thread_sweep_edges_per_s={str(k): v for k, v in sweep.items()})

@@ -304,8 +304,8 @@ def test_filter_kernels_give_the_same_exact_answer_every_call(N, C, K, d, exclud
     """Twelve calls on the same cloud, each against the oracle's distances.  Round 6's first ``exclude_self`` form of the
     32-row kernel (the self compare among the 16 flag compares of a tile pair) was RIGHT on most calls and wrong on a few
     rows of others -- in the C = 32 instantiation only, always rows 13 / 29 of a workgroup, one tile's 16 candidates
-    entered the list with |x_i|^2 missing from their distance (found by reading the lists back: scratch script in the
-    round's log; nothing in the source explains it, the exclusion now sits in the append rounds).  A single call cannot
+    entered the list with |x_i|^2 missing from their distance (found by reading the lists back:
+    benchmarks/knn_list_readback.py; nothing in the source explains it, the exclusion now sits in the append rounds).  A single call cannot
     see such a fault."""
     from deep_gcns_torch_amd import dense_ops, synth
     from oracle import dense_ref
