@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const BnFinali
     const int c = c0 + cc;
     double s1 = 0.0, s2 = 0.0;
     if (P.training && c < P.C) {
-#pragma unroll 4
+#pragma unroll 8
       for (int p = r; p < P.nparts; p += kFinRows) {
         s1 += static_cast<double>(P.stats[(static_cast<int64_t>(p) * 2) * P.C + c]);
         s2 += static_cast<double>(P.stats[(static_cast<int64_t>(p) * 2 + 1) * P.C + c]);
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const BnBw
     const int c = c0 + cc;
     double s1 = 0.0, s2 = 0.0;
     if (c < P.C) {
-#pragma unroll 4
+#pragma unroll 8
       for (int p = r; p < P.nparts; p += kFinRows) {
         s1 += static_cast<double>(P.partial[(static_cast<int64_t>(p) * 2) * P.C + c]);
         s2 += static_cast<double>(P.partial[(static_cast<int64_t>(p) * 2 + 1) * P.C + c]);

@@ -30,6 +30,15 @@ __global__ __launch_bounds__(kRpWaves * 64) void reduce_partials_kernel(const fl
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < width) {
     int s = wave;
+    // eight rows' loads in flight per lane (the partials come from workgroups on every XCD: this workgroup reads them from
+    // memory, and a round trip per four rows was most of the launch), four accumulators, fixed order
+    for (; s + 7 * kRpWaves < nparts; s += 8 * kRpWaves) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = parts[static_cast<int64_t>(s + u * kRpWaves) * width + col];
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
     for (; s + 3 * kRpWaves < nparts; s += 4 * kRpWaves) {
       a0 += parts[static_cast<int64_t>(s) * width + col];
       a1 += parts[static_cast<int64_t>(s + kRpWaves) * width + col];
