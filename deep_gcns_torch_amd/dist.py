@@ -772,10 +772,10 @@ def _split_composed_aggregate(x_local, sg, aggr, group, local_aggregate, kw):
     autograd function), the (n, C) merge is elementwise torch whose backward autograd derives:
       add:   a + b                      mean: (add_a + add_b) / max(deg, 1)
       max:   the larger of the two partial maxima (a row without edges in one set takes the other's)
-    The remote rows travel while the local-source part runs.  (Power-mean is NOT composed from partial outputs: the
-    reference clamps the mean of m^p to [1e-7, 100] before the root, torch_message.py:70-74, so a partial output whose
-    mean fell below the clamp -- every message of the part at eps -- no longer determines sum m^p; measured 4 % error on
-    such rows.  It stays on the all-gather scheme until the kernels export the pre-clamp sum.)"""
+    The remote rows travel while the local-source part runs.  (Power-mean is NOT composed from partial OUTPUTS: the
+    reference clamps the mean of m^p before the root, torch_message.py:70-74, so a partial output whose mean fell below
+    the clamp -- every message of the part at eps -- no longer determines sum m^p; measured 4 % error on such rows.  It
+    merges from the pre-clamp means instead: _SplitPowerAggregate.)"""
     holder = {}
     full = _AllGatherRowsAsync.apply(x_local, sg.max_rows, group, holder)
     base = aggr
@@ -801,9 +801,72 @@ _SPLIT_COMPOSED = ("add", "mean", "max")
 _SPLIT_KWARGS = {"t", "eps", "relu_eps", "learn_t", "learn_p", "p", "edge_attr", "edge_encoder", "dim_size", "add_root"}
 
 
+def _hip_power_state_fns():
+    from . import ops
+    return ops.power_state_forward, ops.power_state_backward
+
+
+class _SplitPowerAggregate(torch.autograd.Function):
+    """Power-mean over a SplitGraph with a fixed p: the two parts' PRE-CLAMP means (what the forward kernel saves anyway)
+    merge exactly with the degrees, q = (q_a deg_a + q_b deg_b) / deg, out = clamp(q)^(1/p) as on one GPU; the backward
+    forms the per-destination coefficient from the merged mean and hands it to the edge walk of each part (the remote
+    part first: its reduce-scatter flies during the local one)."""
+
+    @staticmethod
+    def forward(ctx, x_local, sg, group, p, state_fwd, state_bwd, msg_kw):
+        world = dist.get_world_size(group)
+        n_local, C = x_local.shape
+        mr = sg.max_rows
+        send = x_local.new_zeros(mr, C)
+        send[:n_local] = x_local.detach()
+        full = x_local.new_empty(world * mr, C)
+        tensor_coll = _supports_tensor_collectives(group)
+        if tensor_coll:
+            work = dist.all_gather_into_tensor(full, send, group=group, async_op=True)
+        else:
+            work = dist.all_gather(list(full.view(world, mr, C).unbind(0)), send, group=group, async_op=True)
+        xl = x_local.detach().contiguous()
+        _, qa = state_fwd(xl, sg.local, p, **msg_kw)     # runs while the remote rows are in flight
+        work.wait()
+        _, qb = state_fwd(full, sg.remote, p, **msg_kw)
+        da, db = sg.local.deg.unsqueeze(1).to(qa.dtype), sg.remote.deg.unsqueeze(1).to(qa.dtype)
+        deg = (da + db).clamp_min(1.0)
+        q = (qa * da + qb * db) / deg
+        r = q.clamp(1e-7, 10.0)                                              # torch_message.py:69-74 (ops.POW_LO / POW_HI)
+        out = r.pow(1.0 / p)
+        ctx.sg, ctx.group, ctx.p, ctx.state_bwd, ctx.tensor_coll, ctx.msg_kw = sg, group, p, state_bwd, tensor_coll, msg_kw
+        ctx.save_for_backward(xl, full, q, deg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, full, q, deg = ctx.saved_tensors
+        sg, group, p = ctx.sg, ctx.group, ctx.p
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        mr, C = sg.max_rows, xl.size(1)
+        r = q.clamp(1e-7, 10.0)
+        inr = ((q >= 1e-7) & (q <= 10.0)).to(g.dtype)
+        coef = (g * r.pow(1.0 / p - 1.0) * inr / deg).contiguous()
+        g_full = ctx.state_bwd(full, sg.remote, coef, q, p, **ctx.msg_kw).contiguous()
+        if ctx.tensor_coll:
+            back = g_full.new_empty(mr, C)
+            work = dist.reduce_scatter_tensor(back, g_full, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            tmp = g_full.clone()
+            work = dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            back = None
+        g_loc = ctx.state_bwd(xl, sg.local, coef, q, p, **ctx.msg_kw)
+        work.wait()
+        if back is None:
+            back = tmp.view(world, mr, C)[rank]
+        return g_loc + back[:xl.size(0)], None, None, None, None, None, None
+
+
 def split_supported(aggr: str, kw: dict) -> bool:
     """Node features only; softmax / softmax_sg with a fixed temperature (exact merge of the partial states from their
-    log-sum-exps, one HIP launch), add / mean / max (partial aggregations merged elementwise).  ``eps`` /
+    log-sum-exps, one HIP launch), power-mean with a fixed p (exact merge of the pre-clamp means), add / mean / max (partial
+    aggregations merged elementwise).  ``eps`` /
     ``relu_eps`` are passed on to the kernels; anything that changes the result and is not handled (``add_root``, a ``dim_size`` other than the
     partition's rows, an unknown keyword) makes the caller fall back to the all-gather scheme instead of being dropped."""
     if any(k not in _SPLIT_KWARGS for k in kw):
@@ -812,6 +875,8 @@ def split_supported(aggr: str, kw: dict) -> bool:
         return False
     if aggr in _SPLIT_COMPOSED:               # partial aggregations merged elementwise
         return True
+    if aggr == "power":                       # fixed p: merged from the pre-clamp means (_SplitPowerAggregate)
+        return not kw.get("learn_p") and not isinstance(kw.get("p", 1.0), torch.Tensor)
     return (aggr in ("softmax", "softmax_sg") and not kw.get("learn_t") and not isinstance(kw.get("t", 1.0), torch.Tensor)
             and not kw.get("learn_p"))
 
@@ -822,7 +887,7 @@ def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "soft
     temperature (BASELINE config 4); ``state_fns = (forward, backward)`` defaults to the HIP entry points
     (``ops.softmax_state_forward`` / ``_backward``), the gloo tests inject torch restatements."""
     if not split_supported(aggr, kw):
-        raise NotImplementedError("the local-first scheme covers softmax / softmax_sg with a fixed temperature and add / "
+        raise NotImplementedError("the local-first scheme covers softmax / softmax_sg / power with fixed t / p and add / "
                                   "mean / max on node features; use the allgather scheme otherwise")
     if kw.get("dim_size") not in (None, sg.n_local):
         raise ValueError(f"dim_size = {kw['dim_size']} but this rank's partition has {sg.n_local} destination rows")
@@ -832,8 +897,11 @@ def split_gen_aggregate(x_local: torch.Tensor, sg: SplitGraph, aggr: str = "soft
             local_aggregate = ops.gen_aggregate
         ckw = {k: v for k, v in kw.items() if k in ("eps", "relu_eps")}
         return _split_composed_aggregate(x_local, sg, aggr, group, local_aggregate, ckw)
-    fwd, bwd = state_fns or _hip_state_fns()
     msg_kw = {k: kw[k] for k in ("eps", "relu_eps") if k in kw}
+    if aggr == "power":
+        fwd, bwd = state_fns or _hip_power_state_fns()
+        return _SplitPowerAggregate.apply(x_local, sg, group, float(kw.get("p", 1.0)), fwd, bwd, msg_kw)
+    fwd, bwd = state_fns or _hip_state_fns()
     return _SplitSoftmaxAggregate.apply(x_local, sg, group, float(kw.get("t", 1.0)), fwd, bwd, msg_kw)
 
 

@@ -683,6 +683,55 @@ def softmax_state_backward(x: torch.Tensor, graph: Graph, g: torch.Tensor, L: to
     return grad_x
 
 
+def power_state_forward(x: torch.Tensor, graph: Graph, p: float = 1.0, relu_eps: bool = True, eps: float = 1e-7):
+    """``(out, q)`` of the power-mean aggregation over ``graph`` (no autograd): ``q[i, c]`` = the PRE-CLAMP mean of m^p over
+    the row's edges (what the forward kernel saves for its backward; 0 for a row without edges).  Two partial
+    aggregations over disjoint edge sets of the same destination rows merge exactly from q and the two degrees
+    (``dist.SplitGraph``); the partial OUTPUTS do not (the reference clamps the mean before the root,
+    gcn_lib/sparse/torch_message.py:70-74)."""
+    lib = _lib.load()
+    dev = _lib.require_device(x)
+    x = _rows_f32(x)
+    C = x.size(1)
+    if x.size(0) != graph.n_src:
+        raise ValueError(f"x has {x.size(0)} rows, graph expects {graph.n_src}")
+    out = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+    q = torch.empty(graph.n_dst, C, device=dev, dtype=torch.float32)
+    ws_bytes = lib.dgcn_gen_aggr_fwd_workspace_bytes(graph.c_struct, C)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+    msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_gen_aggr_fwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_POWER, msg, 0,
+                                       1.0, float(p), float(eps), None, None, out.data_ptr(), q.data_ptr(), None, None,
+                                       _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_gen_aggr_fwd_f32")
+    return out, q
+
+
+def power_state_backward(x: torch.Tensor, graph: Graph, coef: torch.Tensor, q: torch.Tensor, p: float = 1.0,
+                         relu_eps: bool = True, eps: float = 1e-7) -> torch.Tensor:
+    """grad_x (graph.n_src, C) of the power-mean aggregation for a GIVEN per-destination coefficient
+    ``coef = g r^(1/p - 1) 1[lo <= q <= hi] / max(deg, 1)`` (r = clamp(q)): the caller forms it from the MERGED mean and
+    the total degree of a split aggregation; the edge walk is the one of ``_GenAggregate.backward``."""
+    lib = _lib.load()
+    dev = _lib.require_device(x, coef, q)
+    x = _rows_f32(x)
+    C = x.size(1)
+    coef = coef.float().contiguous()
+    q = q.float().contiguous()
+    grad_x = torch.empty(graph.n_src, C, device=dev, dtype=torch.float32)
+    ws_bytes = lib.dgcn_gen_aggr_bwd_workspace_bytes(graph.c_struct, C)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8) if ws_bytes else None
+    msg = _lib.MSG_RELU_EPS if relu_eps else _lib.MSG_IDENTITY
+    with _lib.device_ctx(dev):
+        rc = lib.dgcn_gen_aggr_bwd_f32(graph.c_struct, x.data_ptr(), x.stride(0), None, C, _lib.AGGR_POWER, msg, 0,
+                                       1.0, float(p), float(eps), None, None, coef.data_ptr(), q.data_ptr(), None,
+                                       None, None, None, None, grad_x.data_ptr(), None,
+                                       _lib.ptr(ws), ws_bytes, _lib.current_stream_handle(dev))
+    _lib.check(rc, "dgcn_gen_aggr_bwd_f32")
+    return grad_x
+
+
 def encoder_fusable(x: torch.Tensor, edge_feat: torch.Tensor, weight: Optional[torch.Tensor], narrow: bool = False) -> bool:
     """Whether ``Linear(edge_feat)`` can be folded into the aggregation kernels.
 

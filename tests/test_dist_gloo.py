@@ -493,7 +493,7 @@ def _split_composed_worker(rank, world, port, aggr, kw, q):
         part = build_partition(ei, n, C, rank, world, scheme="split")
         assert isinstance(part, SplitGraph) and split_supported(aggr, kw)
         assert not split_supported(aggr, dict(kw, add_root=True)) and not split_supported(aggr, dict(kw, bogus=1))
-        assert not split_supported("power", {"p": 2.0})             # (clamped partial means do not merge: dist.py)
+        assert split_supported("power", {"p": 2.0}) and not split_supported("power", {"p": 2.0, "learn_p": True})
         xl = x[part.lo:part.hi].clone().requires_grad_(True)
         pk = dict(kw)
         p_param = None
@@ -556,3 +556,77 @@ def test_local_first_split_scheme_for_max_add_mean(aggr, kw):
     if p_ref is not None:
         torch.testing.assert_close(sum(r[4] for r in res), p_ref.grad, rtol=1e-8, atol=1e-10)
     assert len({r[6] for r in res}) == 1, "the ranks disagree on the scheme build_partition('auto') took"
+
+
+def _power_state_fwd_torch(x, graph, p, eps=1e-7):
+    """(out, q) of the power-mean aggregation over ``graph`` in plain torch (what ops.power_state_forward returns):
+    gcn_lib/sparse/torch_message.py:66-80 with q = the pre-clamp mean."""
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+    m = (torch.relu(x[graph.col.long()]) + eps).clamp(1e-7, 10.0)
+    q = torch.zeros(graph.n_dst, x.size(1), dtype=x.dtype).index_add_(0, dst, m.pow(p)) / deg.clamp_min(1).unsqueeze(1)
+    return q.clamp(1e-7, 10.0).pow(1.0 / p), q
+
+
+def _power_state_bwd_torch(x, graph, coef, q, p, eps=1e-7):
+    deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+    dst = torch.repeat_interleave(torch.arange(graph.n_dst), deg)
+    src = graph.col.long()
+    z = x[src]
+    m = torch.relu(z) + eps
+    inside = ((m >= 1e-7) & (m <= 10.0)).to(x.dtype)
+    dz = coef[dst] * m.clamp(1e-7, 10.0).pow(p - 1.0) * inside * (z > 0).to(x.dtype)
+    return torch.zeros(graph.n_src, x.size(1), dtype=x.dtype).index_add_(0, src, dz)
+
+
+def _split_power_worker(rank, world, port, p, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_gcns_torch_amd.dist import build_partition, aggregate
+        torch.set_num_threads(2)
+        n, C = 257, 16
+        ei = synth.tricky_graph()
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(n, C, generator=g, dtype=torch.float64)
+        probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+        part = build_partition(ei, n, C, rank, world, scheme="split")
+        xl = x[part.lo:part.hi].clone().requires_grad_(True)
+        out = aggregate(xl, part, aggr="power", p=p, state_fns=(_power_state_fwd_torch, _power_state_bwd_torch))
+        (out * probe[part.lo:part.hi]).sum().backward()
+        q.put(_pack((rank, part.bounds, out.detach(), xl.grad.detach())))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,p", [(2, 2.0), (3, 1.0), (3, 3.0)])
+@_retry_rendezvous()
+def test_local_first_split_scheme_for_power_mean(world, p):
+    """Power-mean over dist.SplitGraph merges from the two parts' pre-clamp means and degrees (rows whose partial mean sits
+    under the reference's clamp -- every message of a part at eps -- included: the tricky graph has them): outputs and
+    input gradients equal the oracle's on the whole graph."""
+    from oracle import sparse_ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_power_worker, args=(r, world, port, p, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([_unpack(q.get(timeout=120)) for _ in range(world)], key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    n, C = 257, 16
+    ei = synth.tricky_graph()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    probe = torch.randn(n, C, generator=g, dtype=torch.float64)
+    ref = sparse_ref.gen_propagate(x, ei, aggr="power", p=p)
+    (ref * probe).sum().backward()
+    bounds = res[0][1]
+    for rank, b, out, gx in res:
+        lo, hi = bounds[rank], bounds[rank + 1]
+        torch.testing.assert_close(out, ref[lo:hi].detach(), rtol=1e-9, atol=1e-12)
+        torch.testing.assert_close(gx, x.grad[lo:hi], rtol=1e-9, atol=1e-12)

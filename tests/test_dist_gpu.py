@@ -146,6 +146,41 @@ def test_local_first_split_states_on_the_hip_kernels(world, rank):
         torch.testing.assert_close(total, xf.grad, rtol=1e-4, atol=2e-6 * gs)
 
 
+@pytest.mark.parametrize("world,rank,p", [(2, 1, 2.0), (4, 2, 1.0), (8, 5, 3.0)])
+def test_local_first_power_states_on_the_hip_kernels(world, rank, p):
+    """Power-mean over dist.SplitGraph on the device without a collective: the two parts' pre-clamp means
+    (ops.power_state_forward) merged with the degrees equal the one-launch aggregation of the all-gather scheme's
+    rectangular graph for the same rank, and the two gradient launches (ops.power_state_backward with the coefficient
+    formed from the MERGED mean) add up to its gradient."""
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.dist import PartitionedGraph, SplitGraph
+    dev = torch.device("cuda:0")
+    n, C = 3001, 64
+    ei = synth.powerlaw_graph(n, 20_000, seed=21, exponent=2.2).to(dev)
+    part = PartitionedGraph.from_edge_index(ei, n, rank, world)
+    sg = SplitGraph.from_edge_index(ei, n, rank, world)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x_full = torch.randn(world * part.max_rows, C, device=dev, generator=gen)
+    probe = torch.randn(part.n_local, C, device=dev, generator=gen)
+    lo_p = rank * part.max_rows
+    xf = x_full.clone().requires_grad_(True)
+    ref = ops.gen_aggregate(xf, part.graph, aggr="power", p=p)
+    (ref * probe).sum().backward()
+    x_loc = x_full[lo_p:lo_p + part.n_local].contiguous()
+    _, qa = ops.power_state_forward(x_loc, sg.local, p)
+    _, qb = ops.power_state_forward(x_full, sg.remote, p)
+    da, db = sg.local.deg.unsqueeze(1), sg.remote.deg.unsqueeze(1)
+    deg = (da + db).clamp_min(1.0)
+    q = (qa * da + qb * db) / deg
+    r = q.clamp(ops.POW_LO, ops.POW_HI)
+    torch.testing.assert_close(r.pow(1.0 / p), ref.detach(), rtol=2e-5, atol=1e-6)
+    coef = probe * r.pow(1.0 / p - 1.0) * ((q >= ops.POW_LO) & (q <= ops.POW_HI)).float() / deg
+    total = ops.power_state_backward(x_full, sg.remote, coef, q, p)
+    total[lo_p:lo_p + part.n_local] += ops.power_state_backward(x_loc, sg.local, coef, q, p)
+    gs = max(1.0, float(xf.grad.abs().max()))
+    torch.testing.assert_close(total, xf.grad, rtol=1e-4, atol=2e-6 * gs)
+
+
 def _hip_local(x_full, graph, aggr="softmax", **kw):
     """local_aggregate for a gloo (CPU tensor) job whose per-rank compute runs on the GPU's HIP kernels."""
     from deep_gcns_torch_amd import ops
