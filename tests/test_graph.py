@@ -109,3 +109,32 @@ def test_locality_ordered_synthetic_graph_keeps_partitions_mostly_local():
     uniform = synth.undirected_random_graph(n, 200_000, seed=3)
     assert remote_rows(ei) < 0.5 * (hi - lo)
     assert remote_rows(uniform) > 2 * (hi - lo)
+
+
+def test_exchange_bytes_and_choose_scheme_follow_the_graphs_locality():
+    """dist.exchange_bytes counts what each multi-GPU scheme makes a rank receive from the edge list alone (no process
+    group); dist.choose_scheme turns the counts into the scheme build_partition("auto") takes: the halo exchange on a
+    locality-ordered graph, the channel-transposed scheme on a graph whose partitions reference every row, the
+    local-first / all-gather pair where the channel count rules the transposed scheme out."""
+    import torch
+    from deep_gcns_torch_amd import dist as ddist, synth
+    n, C, W = 20_000, 128, 8
+    local = synth.local_graph(n, 150_000, seed=1)
+    uniform = synth.undirected_random_graph(n, 150_000, seed=1)
+    for r in (0, 3, 7):
+        cl = ddist.exchange_bytes(local, n, C, r, W)
+        cu = ddist.exchange_bytes(uniform, n, C, r, W)
+        assert cl["edges"] == cl["local_source_edges"] + cl["remote_source_edges"]
+        assert cl["halo"] == cl["halo_rows"] * C * 4 and cl["allgather"] == cl["split"]
+        assert cl["halo_rows"] < 0.5 * (n - cl["rows"]) <= cu["halo_rows"] / 0.9       # few remote rows vs nearly all
+        assert cl["local_source_edges"] > 0.8 * cl["edges"] and cu["local_source_edges"] < 0.25 * cu["edges"]
+        assert ddist.choose_scheme(cl, "softmax_sg", {"t": 0.1}) == "halo"
+        assert ddist.choose_scheme(cu, "softmax_sg", {"t": 0.1}) == "transposed"
+    # 100 channels at W = 8: no channel split -> the all-gather volume; as the local-first scheme only where enough edges
+    # have a local source and the aggregator has an associative partial state
+    c100 = ddist.exchange_bytes(uniform, n, 100, 0, W)
+    assert "transposed" not in c100 and ddist.choose_scheme(c100, "softmax_sg", {"t": 0.1}) == "allgather"
+    half = dict(c100, local_source_edges=c100["edges"] // 2)
+    assert ddist.choose_scheme(half, "max", {}) == "split" and ddist.choose_scheme(half, "power", {"p": 2.0}) == "split"
+    assert ddist.choose_scheme(half, "softmax", {"learn_t": True}) == "allgather"
+    assert ddist.choose_scheme(half, "power", {"p": 2.0, "learn_p": True}) == "allgather"
