@@ -1526,7 +1526,6 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
   const int64_t plane = static_cast<int64_t>(P.B) * Np * UNITS;
   const i4v* pb = P.planes + static_cast<int64_t>(b) * Np * UNITS;
   const float* sqn = P.sqnorm + static_cast<int64_t>(b) * N;
-  uint2* lists = P.lists + (static_cast<int64_t>(b) * N + i0) * CAP;
 
   if (tid < TM) {
     sq[tid] = sqn[min(i0 + tid, N - 1)];
@@ -1723,7 +1722,9 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
     // 2 - 3 times per pair at K = 16 (9 at K = 432) with as many lanes as have hits.  Lists are unordered sets: the order
     // of the appends does not reach the output.
     float* dl = reinterpret_cast<float*>(big) + wave * (16 * kWave);  // [16 slots][64 lanes], where the sample keys were
-    char* const lbase = reinterpret_cast<char*>(lists);
+    // (the list base is formed here, not at the top of the kernel: a 64-bit value live across the prologue was the one
+    //  spilled VGPR pair of the C = 64 instantiations)
+    char* const lbase = reinterpret_cast<char*>(P.lists + (static_cast<int64_t>(b) * N + i0) * CAP);
     auto epilogue = [&](int q, const f32x4 (&acc)[2][2], const float (&sj)[2]) {
 #ifdef KNNF_NO_APPEND
       {
@@ -1838,7 +1839,11 @@ __global__ __launch_bounds__(kF2Waves * kWave, 4) void knn_filter2_kernel(const 
   if (tid < TM && i0 + tid < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tid] = -1;   // (select + redo skipped)
   return;
 #endif
-  if (tid < TM && i0 + tid < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tid] = cnt[tid];
+  {
+    int tr = tid;
+    asm volatile("" : "+v"(tr));                // (recomputed here: kept from the kernel's first lines, i0 + tid was the one spilled VGPR)
+    if (tr < TM && i0 + tr < N) P.list_cnt[static_cast<int64_t>(b) * N + i0 + tr] = cnt[tr];
+  }
 }
 
 // ---- the select of knn_filter2_kernel's lists: one wave per query row, any row order, high occupancy --------------------
