@@ -325,6 +325,29 @@ def test_filter_kernels_give_the_same_exact_answer_every_call(N, C, K, d, exclud
         assert torch.equal(ei, first), f"call {rep} differs from call 0"
 
 
+@pytest.mark.parametrize("N,C,K,d,exclude_self", [(4096, 64, 224, 14, False), (2048, 32, 48, 3, True), (1100, 64, 16, 1, False)])
+def test_the_16_row_filter_kernel_with_lds_lists_stays_exact(N, C, K, d, exclude_self):
+    """``dense_ops.KNN_GLOBAL_LISTS = False`` (a workspace without room for the candidate lists) selects rounds 4 - 5's
+    kernel -- kept for A/B measurements (benchmarks/knn_time.py --lds-lists): same exact answer, same ids as the 32-row
+    kernel."""
+    from deep_gcns_torch_amd import dense_ops, synth
+    from oracle import dense_ref
+    x = synth.lattice_cloud(2, C, N, seed=N + K)
+    dist = dense_ref.pairwise_distance(x.transpose(2, 1).squeeze(-1))
+    if exclude_self:
+        dist.diagonal(dim1=1, dim2=2).fill_(float("inf"))
+    want = torch.sort(dist, dim=2).values[:, :, :K:d]
+    xd = x.to(_dev())
+    new = dense_ops.knn_edge_index(xd, K // d, d, exclude_self=exclude_self)
+    dense_ops.KNN_GLOBAL_LISTS = False
+    try:
+        old = dense_ops.knn_edge_index(xd, K // d, d, exclude_self=exclude_self)
+    finally:
+        dense_ops.KNN_GLOBAL_LISTS = True
+    assert torch.equal(torch.gather(dist, 2, old[0].cpu()), want)
+    assert torch.equal(old, new)
+
+
 _KNN_TRUTH = {}
 
 
