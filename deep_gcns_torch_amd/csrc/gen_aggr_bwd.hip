@@ -581,12 +581,15 @@ __global__ __launch_bounds__(kWgThreads) void softmax_bwd_prep_kernel(const floa
   }
 }
 
+constexpr int kMergeCh = 16;                       // channels per merge wave (as in gen_aggr_fwd.hip)
+constexpr int kMergeGroups = kWave / kMergeCh;     // piece groups per merge wave
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const BwdParams P) {
-  // one wave per (split row, block of 64 channels); the pieces of a row own consecutive items and slots
-  // (graph_build.hip work_fill_kernel): no dependent index loads, eight partial rows in flight, summed in piece order
+  // one wave per (split row, block of 16 channels): four piece groups x 16 channels, every group sums a contiguous
+  // quarter of the row's pieces, 16 partial rows in flight, and two shuffles add the groups in a fixed order.  The
+  // pieces of a row own consecutive items and slots (graph_build.hip work_fill_kernel): no dependent index loads.
   const int lane = lane_id();
   const int C = P.C;
-  const int cblocks = (C + kWave - 1) / kWave;
+  const int cblocks = (C + kMergeCh - 1) / kMergeCh;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
   if (wave >= P.g.n_split * cblocks) return;
   const int i0 = uni(P.g.split_item[wave / cblocks]);
@@ -595,16 +598,22 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_bwd_merge_kernel(const Bw
   const int rbeg = uni(P.g.rowptr[row]), rend = uni(P.g.rowptr[row + 1]);
   const int chunk = uni(P.g.work_end[i0]) - uni(P.g.work_beg[i0]);
   const int npieces = (rend - rbeg + chunk - 1) / chunk;
-  const int c = (wave % cblocks) * kWave + lane;
-  if (c >= C) return;
+  const int c_raw = (wave % cblocks) * kMergeCh + (lane & (kMergeCh - 1));
+  const int c = min(c_raw, C - 1);                 // every lane stays in the shuffles; lanes past C do not write
+  const int grp = lane / kMergeCh;
+  const int per = (npieces + kMergeGroups - 1) / kMergeGroups;
+  const int pbeg = min(grp * per, npieces), pend = min(pbeg + per, npieces);
   float acc = 0.f;
-  for (int i = 0; i < npieces; i += 16) {
+  for (int i = pbeg; i < pend; i += 16) {
     float v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = (i + k < npieces) ? P.ws[static_cast<int64_t>(slot0 + i + k) * C + c] : 0.f;
+    for (int k = 0; k < 16; ++k) v[k] = (i + k < pend) ? P.ws[static_cast<int64_t>(slot0 + i + k) * C + c] : 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc += v[k];
   }
+#pragma unroll
+  for (int off = kMergeCh; off < kWave; off <<= 1) acc += __shfl_xor(acc, off);
+  if (grp != 0 || c_raw >= C) return;
   P.grad_x[static_cast<int64_t>(row) * C + c] = P.groot ? acc + P.groot[static_cast<int64_t>(row) * C + c] : acc;
 }
 template <int MODE, int VEC, int LPR, int SW>
@@ -644,7 +653,7 @@ void launch_bwd_mode(const BwdParams& P, int vec, int lpr, int grid, hipStream_t
     launch_bwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
-    const int mwaves = P.g.n_split * ((P.C + kWave - 1) / kWave);
+    const int mwaves = P.g.n_split * ((P.C + kMergeCh - 1) / kMergeCh);
     const int mg = (mwaves + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL(gen_aggr_bwd_merge_kernel, dim3(mg), dim3(kWgThreads), 0, s, P);
   }

@@ -480,16 +480,19 @@ void launch_enc_fwd(const FwdParams& P, int grid, hipStream_t s) {
   hipLaunchKernelGGL((gen_aggr_enc_fwd_kernel<MODE, VEC, false>), dim3(grid), dim3(kWgThreads), 0, s, P);
 }
 
-// Merge the partial slots of split (hub) rows: one wave per split row (its first work item is listed in
-// split_item), lanes over channels, slots folded in work-list order -> deterministic.
+// Merge the partial slots of split (hub) rows.  One wave per (split row, block of 16 channels): the lanes are four
+// piece groups x 16 channels, every group folds a contiguous quarter of the row's pieces (a 11,000-edge row of a
+// small graph is 179 pieces: 3 batches of loads per lane instead of 12 behind one another), then the four partial
+// states meet through two shuffles and group 0 writes.  The pieces of a row own CONSECUTIVE items and slots
+// (graph_build.hip work_fill_kernel), so nothing here depends on a loaded index; the fold order is fixed ->
+// deterministic.
+constexpr int kMergeCh = 16;                       // channels per merge wave
+constexpr int kMergeGroups = kWave / kMergeCh;     // piece groups per merge wave
 template <int MODE>
 __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const FwdParams P) {
   const int lane = lane_id();
   const int C = P.C;
-  // one wave per (split row, block of 64 channels): the pieces of a row own CONSECUTIVE items and slots
-  // (graph_build.hip work_fill_kernel), so nothing here depends on a loaded index; the partial states are fetched
-  // four pieces at a time and folded in piece order -> deterministic
-  const int cblocks = (C + kWave - 1) / kWave;
+  const int cblocks = (C + kMergeCh - 1) / kMergeCh;
   const int wave = blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
   if (wave >= P.g.n_split * cblocks) return;
   const float p = P.p_dev ? *P.p_dev : P.p;
@@ -501,23 +504,26 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
   const int chunk = uni(P.g.work_end[i0]) - uni(P.g.work_beg[i0]);          // every piece but the last is this long
   const int npieces = (rend - rbeg + chunk - 1) / chunk;
   {
-    const int c = (wave % cblocks) * kWave + lane;
-    if (c >= C) return;
+    const int c_raw = (wave % cblocks) * kMergeCh + (lane & (kMergeCh - 1));
+    const int c = min(c_raw, C - 1);               // every lane stays in the shuffles; lanes past C do not write
+    const int grp = lane / kMergeCh;
+    const int per = (npieces + kMergeGroups - 1) / kMergeGroups;
+    const int pbeg = min(grp * per, npieces), pend = min(pbeg + per, npieces);
     State<1> st;
     state_init<MODE, 1>(st);
     constexpr int NQ = (MODE == DGCN_AGGR_MAX) ? 2 : 4;
     constexpr int PB = (MODE == DGCN_AGGR_MAX) ? 16 : 8;       // pieces in flight (32 loads)
-    for (int i = 0; i < npieces; i += PB) {
+    for (int i = pbeg; i < pend; i += PB) {
       float v[PB][4];
 #pragma unroll
       for (int k = 0; k < PB; ++k) {
-        const float* ws = P.ws + (static_cast<int64_t>(slot0 + min(i + k, npieces - 1)) * 4) * C + c;
+        const float* ws = P.ws + (static_cast<int64_t>(slot0 + min(i + k, pend - 1)) * 4) * C + c;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[k][q] = ws[static_cast<int64_t>(q) * C];
       }
 #pragma unroll
       for (int k = 0; k < PB; ++k) {
-        if (i + k < npieces) {
+        if (i + k < pend) {
           State<1> o;
           state_init<MODE, 1>(o);
           o.a[0] = v[k][0];
@@ -530,6 +536,12 @@ __global__ __launch_bounds__(kWgThreads) void gen_aggr_fwd_merge_kernel(const Fw
         }
       }
     }
+#pragma unroll
+    for (int off = kMergeCh; off < kWave; off <<= 1) {
+      const State<1> o = state_shfl_xor<MODE, 1>(st, off);
+      state_merge<MODE, 1>(st, o);
+    }
+    if (grp != 0 || c_raw >= C) return;
     const int64_t o = static_cast<int64_t>(row) * C + c;
     float res, x1 = 0.f, x2 = 0.f;
     if constexpr (MODE == DGCN_AGGR_SOFTMAX) {
@@ -615,7 +627,7 @@ void launch_fwd_mode(const FwdParams& P, int vec, int lpr, int grid, hipStream_t
     launch_fwd_ea<MODE, 1, 64, 64>(P, grid, s);
   }
   if (P.g.n_work && P.g.n_split > 0) {
-    const int mwaves = P.g.n_split * ((P.C + kWave - 1) / kWave);
+    const int mwaves = P.g.n_split * ((P.C + kMergeCh - 1) / kMergeCh);
     const int mg = (mwaves + kWavesPerWg - 1) / kWavesPerWg;
     hipLaunchKernelGGL((gen_aggr_fwd_merge_kernel<MODE>), dim3(mg), dim3(kWgThreads), 0, s, P);
   }
