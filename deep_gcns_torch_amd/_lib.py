@@ -192,6 +192,9 @@ _SIGNATURES = {
     "dgcn_rows_tn_num_partials": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32]),
     "dgcn_rows_tn_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dgcn_rows_tn_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p]),
     "dgcn_rows_msgnorm_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                             C.c_int64, C.c_int32, C.c_void_p]),
     "dgcn_rows_msgnorm_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,

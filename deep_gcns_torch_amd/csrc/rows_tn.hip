@@ -45,7 +45,9 @@ struct TnParams {
   int64_t ldx;
   int64_t rows;
   int C, K;
-  float* part;        // [gridDim.x][C][K]
+  float* part;        // [gridDim.x][part_stride]: the (C, K) partial, then (colsum_of != 0) the column sums of G or X
+  int64_t part_stride;
+  int colsum_of;      // 0: none; 1: column sums of G (C values); 2: of X (K values) -- the bias gradient of the Linear
   int64_t steps_per_wg;
 };
 
@@ -83,6 +85,11 @@ __device__ __forceinline__ void tn_load_waves(const TnParams& P, const TnRange& 
   i4v* region[TI];             // A or B planes
   int unit0[TI];               // the thread's unit of column 4 q (j = 0) inside a plane
   int pstride[TI];             // units between planes
+  // column sums (P.colsum_of): the thread already holds 8 rows x 4 columns of its task per step -- the sums cost 8 adds
+  // per column and step here instead of a pass of their own over the matrix
+  bool want[TI];
+  int ngroups[TI], col0[TI];
+  f4v cs[TI];
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     const int t = pw + kTnLoadWaves * i;
@@ -99,6 +106,10 @@ __device__ __forceinline__ void tn_load_waves(const TnParams& P, const TnRange& 
     pstride[i] = is_g ? AU : BU;
     region[i] = is_g ? Ab : Bb;
     unit0[i] = tile * 64 + tn_unit(tile & 1, gj, 4 * (q & 3));
+    want[i] = live[i] && P.colsum_of == (is_g ? 1 : 2);
+    ngroups[i] = groups;
+    col0[i] = 64 * b;
+    cs[i] = f4v{0.f, 0.f, 0.f, 0.f};
   }
   struct Stage { f4v v[8]; };
   auto fetch = [&](int i, int64_t step, Stage& S) {
@@ -119,6 +130,10 @@ __device__ __forceinline__ void tn_load_waves(const TnParams& P, const TnRange& 
   };
   auto park = [&](int i, int buf, const Stage& S) {
     if (live[i]) {
+      if (want[i]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[i] = cs[i] + S.v[e];
+      }
       i4v* u = region[i] + buf * 3 * pstride[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -176,6 +191,21 @@ __device__ __forceinline__ void tn_load_waves(const TnParams& P, const TnRange& 
       park(1, 0, S1);
     }
     __syncthreads();
+  }
+  if (P.colsum_of) {
+    // the four row groups of the wave meet by shuffle (fixed order), row group 0 writes its existing column groups
+    float* cdst = P.part + static_cast<int64_t>(blockIdx.x) * P.part_stride + static_cast<int64_t>(P.C) * P.K;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = cs[i][j];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        cs[i][j] = v;
+      }
+      if (want[i] && gj == 0 && q < ngroups[i]) *reinterpret_cast<f4v*>(cdst + col0[i] + 4 * q) = cs[i];
+    }
   }
 }
 
@@ -251,7 +281,7 @@ __device__ __forceinline__ void tn_mma_waves(const TnParams& P, const TnRange& R
     if (wave_live) compute(0);
   }
   // ---- this workgroup's partial: D layout, lane (n, q) holds channels 16 mt + 4 q + j, column 16 nt + n ----
-  float* part = P.part + static_cast<int64_t>(blockIdx.x) * C * K;
+  float* part = P.part + static_cast<int64_t>(blockIdx.x) * P.part_stride;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -289,10 +319,13 @@ __global__ __launch_bounds__(kTnThreads) void rows_tn_kernel(const TnParams P) {
 
 // dst[c][k] = sum_s part[s][c][k], s ascending within 16 interleaved groups, the groups in a fixed tree: deterministic.
 // 16 lanes x 16 groups per block so that a few hundred partials of a 16 k-element matrix still fill the chip (one thread
-// per output walking 256 partials one after the other took 62 us).
+// per output walking 256 partials one after the other took 62 us).  Elements past the matrix (mat_total .. total) are the
+// column sums the loaders left behind the partial: they go to `tail`.  `transposed`: dst[k][c] (row stride ldo) -- the
+// caller asked for (X^T G)^T.
 template <typename V>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const V* __restrict__ parts, int nparts, int64_t total,
-                                                         int64_t row_len, float* __restrict__ dst, int64_t ldo) {
+                                                         int64_t mat_total, int64_t row_len, float* __restrict__ dst,
+                                                         int64_t ldo, int transposed, float* __restrict__ tail) {
   __shared__ V red[16][16];
   const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * 16 + o;          // output index in units of V
@@ -316,7 +349,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const V* __restrict__ pa
     for (int q = 1; q < 16; ++q) r = r + red[q][o];
     constexpr int W = sizeof(V) / 4;
     const int64_t e = idx * W;                       // element index in the (C, K) matrix, row_len = K
-    *reinterpret_cast<V*>(dst + (e / row_len) * ldo + (e % row_len)) = r;
+    if (e >= mat_total) {
+      *reinterpret_cast<V*>(tail + (e - mat_total)) = r;
+    } else if (!transposed) {
+      *reinterpret_cast<V*>(dst + (e / row_len) * ldo + (e % row_len)) = r;
+    } else {
+      const float* rf = reinterpret_cast<const float*>(&r);
+#pragma unroll
+      for (int w = 0; w < W; ++w) dst[((e + w) % row_len) * ldo + (e + w) / row_len] = rf[w];
+    }
   }
 }
 
@@ -366,16 +407,28 @@ extern "C" int32_t dgcn_rows_tn_num_partials(int64_t rows, int32_t C, int32_t K)
   return tn_grid(rows);
 }
 
-extern "C" int dgcn_rows_tn_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C,
-                                int32_t K, float* partials, float* out, int64_t ldo, void* stream) {
+// out = G^T X (C, K) [or its transpose (K, C) with `transposed`], and with colsum_of = 1 / 2 the column sums of G (C) /
+// of X (K) into `colsum` from the same pass over the rows (the bias gradient of the Linear whose weight gradient this is).
+// `partials`: dgcn_rows_tn_num_partials(rows, C, K) x (C K + (colsum_of == 1 ? C : colsum_of == 2 ? K : 0)) floats.
+extern "C" int dgcn_rows_tn_colsum_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C,
+                                       int32_t K, float* partials, float* out, int64_t ldo, int32_t transposed,
+                                       int32_t colsum_of, float* colsum, void* stream) {
   if (!g || !x || !partials || !out) return DGCN_E_NULL;
+  if (colsum_of < 0 || colsum_of > 2) return DGCN_E_MODE;
+  if (colsum_of && !colsum) return DGCN_E_NULL;
   TnShape S;
-  if (rows <= 0 || !tn_shape(C, K, &S) || ldg < C || ldx < K || ldo < K || ldg % 4 != 0 || ldx % 4 != 0) return DGCN_E_SHAPE;
+  if (rows <= 0 || !tn_shape(C, K, &S) || ldg < C || ldx < K || ldo < (transposed ? C : K) || ldg % 4 != 0 || ldx % 4 != 0)
+    return DGCN_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(g) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u)) return DGCN_E_ALIGN;
+  if (colsum_of && ((reinterpret_cast<uintptr_t>(partials) & 15u) || (reinterpret_cast<uintptr_t>(colsum) & 15u)))
+    return DGCN_E_ALIGN;
   // the loaders address a step with 32-bit byte offsets from its first row
   if (ldg * 4 * kTnStep > 0x7fffffffLL || ldx * 4 * kTnStep > 0x7fffffffLL) return DGCN_E_SHAPE;
+  const int64_t mat_total = static_cast<int64_t>(C) * K;
+  const int64_t total = mat_total + (colsum_of == 1 ? C : colsum_of == 2 ? K : 0);
   TnParams P;
   P.g = g; P.ldg = ldg; P.x = x; P.ldx = ldx; P.rows = rows; P.C = C; P.K = K; P.part = partials;
+  P.part_stride = total; P.colsum_of = colsum_of;
   const int grid = tn_grid(rows);
   const int64_t steps = rows / kTnStep;
   P.steps_per_wg = (steps + grid - 1) / grid;
@@ -395,16 +448,21 @@ extern "C" int dgcn_rows_tn_f32(const float* g, int64_t ldg, const float* x, int
     }
   }
   if (rc != DGCN_OK) return rc;
-  const int64_t total = static_cast<int64_t>(C) * K;
   const bool wide = K % 4 == 0 && ldo % 4 == 0 && !(reinterpret_cast<uintptr_t>(partials) & 15u) &&
-                    !(reinterpret_cast<uintptr_t>(out) & 15u);
+                    !(reinterpret_cast<uintptr_t>(out) & 15u) && (!colsum_of || !(reinterpret_cast<uintptr_t>(colsum) & 15u));
   if (wide) {
     const int64_t t4 = total / 4;
     hipLaunchKernelGGL(tn_reduce_kernel<f4v>, dim3(static_cast<unsigned>((t4 + 15) / 16)), dim3(256), 0, s,
-                       reinterpret_cast<const f4v*>(partials), grid, t4, static_cast<int64_t>(K), out, ldo);
+                       reinterpret_cast<const f4v*>(partials), grid, t4, mat_total, static_cast<int64_t>(K), out, ldo,
+                       transposed ? 1 : 0, colsum);
   } else {
     hipLaunchKernelGGL(tn_reduce_kernel<float>, dim3(static_cast<unsigned>((total + 15) / 16)), dim3(256), 0, s,
-                       partials, grid, total, static_cast<int64_t>(K), out, ldo);
+                       partials, grid, total, mat_total, static_cast<int64_t>(K), out, ldo, transposed ? 1 : 0, colsum);
   }
   return launch_status();
+}
+
+extern "C" int dgcn_rows_tn_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C,
+                                int32_t K, float* partials, float* out, int64_t ldo, void* stream) {
+  return dgcn_rows_tn_colsum_f32(g, ldg, x, ldx, rows, C, K, partials, out, ldo, 0, 0, nullptr, stream);
 }

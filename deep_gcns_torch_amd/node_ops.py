@@ -511,9 +511,11 @@ class _RowsLinear(torch.autograd.Function):
         C, K = weight.shape
         gx = gw = gb = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        # the bias gradient g.sum(0) leaves the weight gradient's pass over g (rows_tn's loading waves)
+        tn_b = need_b and ctx.needs_input_grad[1] and g.dim() == 2
         if ctx.needs_input_grad[0]:
-            # dX = G W on the same kernel (reduction over C); its sweep over G also yields the bias gradient
-            fuse_b = need_b and C <= 128 and bool(_lib.load().dgcn_rows_linear_supported(C, K))
+            # dX = G W on the same kernel (reduction over C); without a weight gradient its sweep over G yields the bias's
+            fuse_b = need_b and not tn_b and C <= 128 and bool(_lib.load().dgcn_rows_linear_supported(C, K))
             if _lib.load().dgcn_rows_linear_supported(C, K):
                 gx, _, xsum = _rl_launch(g, weight.detach(), True, None, None, False, False, fuse_b)
                 if fuse_b:
@@ -521,7 +523,10 @@ class _RowsLinear(torch.autograd.Function):
             else:
                 gx = g @ weight
         if ctx.needs_input_grad[1]:
-            gw = rows_tn(g, x)
+            if tn_b:
+                gw, gb = rows_tn(g, x, with_colsum=True)
+            else:
+                gw = rows_tn(g, x)
         if need_b and gb is None:
             gb = g.sum(0)
         gres = None
@@ -551,34 +556,47 @@ def rows_matmul(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 ROWS_TN_KERNEL = True      # False: library split-K GEMM for the weight gradients (A/B measurements)
 
 
-def rows_tn(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def _rows_tn_kernel_ok(g: torch.Tensor, x: torch.Tensor) -> bool:
+    return bool(ROWS_TN_KERNEL and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2
+                and x.dim() == 2 and g.size(0) == x.size(0) and g.size(0) >= ROWS_LINEAR_MIN_ROWS and g.stride(1) == 1
+                and x.stride(1) == 1 and max(g.stride(0), x.stride(0)) < (1 << 22)
+                and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+                and _lib.load().dgcn_rows_tn_supported(g.size(1), x.size(1)))
+
+
+def rows_tn(g: torch.Tensor, x: torch.Tensor, with_colsum: bool = False):
     """``g.T @ x`` for (rows, C), (rows, K) with rows >> C, K: the weight gradient of a row-wise Linear (no autograd).
     csrc/rows_tn.hip on device rows (min(C, K) <= 128, max(C, K) <= 256, both multiples of 4, unit column strides,
-    16-byte aligned rows); anything else: the split-K library GEMM."""
+    16-byte aligned rows); anything else: the split-K library GEMM.
+    ``with_colsum``: returns ``(g.T @ x, g.sum(0))`` -- the Linear's bias gradient leaves the same pass over the rows (the
+    kernel's loading waves hold every element of ``g`` once), no launch of its own."""
     from .nn_util import splitk_xt_g
     C, K = g.size(1), x.size(1)
-    if C > 128 and K <= 128 and g.dim() == 2 and x.dim() == 2:
-        return rows_tn(x, g).t().contiguous()      # the kernel's first operand is the narrow one: (x^T g)^T
-    if not (ROWS_TN_KERNEL and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2
-            and x.dim() == 2 and g.size(0) == x.size(0) and g.size(0) >= ROWS_LINEAR_MIN_ROWS and g.stride(1) == 1
-            and x.stride(1) == 1 and max(g.stride(0), x.stride(0)) < (1 << 22)
-            and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
-            and _lib.load().dgcn_rows_tn_supported(C, K)):
+    # the kernel's first operand is the narrow one: a wide g (> 128 columns) goes second and the result is written
+    # transposed by the partial-sum launch, (x^T g)^T
+    swap = C > 128 and K <= 128 and g.dim() == 2 and x.dim() == 2
+    a, b = (x, g) if swap else (g, x)
+    if not _rows_tn_kernel_ok(a, b):
         if ROWS_TN_KERNEL and g.is_cuda and g.dim() == 2 and g.dtype == torch.float32:
             warn_library_gemm("the weight gradient g^T x", g.size(0), C, K,
                               "it takes min(C, K) <= 128, max(C, K) <= 256, both multiples of 4, 16-byte aligned fp32 rows")
-        return splitk_xt_g(g.contiguous(), x.contiguous())
+        out = splitk_xt_g(g.contiguous(), x.contiguous())
+        return (out, g.sum(0)) if with_colsum else out
     lib = _lib.load()
     dev = g.device
     rows = g.size(0)
-    nparts = lib.dgcn_rows_tn_num_partials(rows, C, K)
-    parts = torch.empty(nparts, C, K, device=dev, dtype=torch.float32)
+    Ca, Kb = a.size(1), b.size(1)
+    nparts = lib.dgcn_rows_tn_num_partials(rows, Ca, Kb)
+    parts = torch.empty(nparts, Ca * Kb + (C if with_colsum else 0), device=dev, dtype=torch.float32)
     out = torch.empty(C, K, device=dev, dtype=torch.float32)
+    colsum = torch.empty(C, device=dev, dtype=torch.float32) if with_colsum else None
     with _lib.device_ctx(dev):
         stream = _lib.current_stream_handle(dev)
-        _lib.check(lib.dgcn_rows_tn_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), rows, C, K,
-                                        parts.data_ptr(), out.data_ptr(), K, stream), "dgcn_rows_tn_f32")
-    return out
+        _lib.check(lib.dgcn_rows_tn_colsum_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), rows, Ca, Kb,
+                                               parts.data_ptr(), out.data_ptr(), K, 1 if swap else 0,
+                                               (2 if swap else 1) if with_colsum else 0, _lib.ptr(colsum), stream),
+                   "dgcn_rows_tn_colsum_f32")
+    return (out, colsum) if with_colsum else out
 
 
 def rows_linear(x, weight, bias=None, residual=None, want_stats: bool = False):

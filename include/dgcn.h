@@ -685,6 +685,16 @@ int32_t dgcn_rows_tn_supported(int32_t C, int32_t K);
 int32_t dgcn_rows_tn_num_partials(int64_t rows, int32_t C, int32_t K);
 int dgcn_rows_tn_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C, int32_t K,
                      float* partials, float* out, int64_t ldo, void* stream);
+/* The same pass also yields the bias gradient of that Linear (the `g.sum(0)` of gcn_lib/sparse/torch_nn.py:50-71's
+ * backward): colsum_of = 1 -> colsum[c] = sum_r g[r][c] (C values), 2 -> colsum[k] = sum_r x[r][k] (K values), 0 -> none
+ * (colsum may be null).  The loading waves already hold every element once; no extra pass over the rows, no extra
+ * launch.  transposed != 0 writes out as (K, C) with row stride ldo >= C -- (x^T g)^T for callers whose wide operand
+ * (> 128 columns) has to be the kernel's second one.
+ *   partials: dgcn_rows_tn_num_partials(rows, C, K) x (C K + [colsum_of == 1 ? C : colsum_of == 2 ? K : 0]) floats,
+ *   16-byte aligned when colsum_of != 0 (DGCN_E_ALIGN otherwise), colsum 16-byte aligned. */
+int dgcn_rows_tn_colsum_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t C, int32_t K,
+                            float* partials, float* out, int64_t ldo, int32_t transposed, int32_t colsum_of,
+                            float* colsum, void* stream);
 
 #ifdef __cplusplus
 }

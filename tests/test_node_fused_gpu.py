@@ -88,6 +88,60 @@ def test_rows_tn_weight_gradient(rows, C, K, strided):
     torch.testing.assert_close(out, lib_out, rtol=1e-4, atol=1e-5 * nat)
 
 
+@pytest.mark.parametrize("rows,C,K", [(5000, 128, 128), (13253, 224, 112), (13253, 112, 224), (4100, 112, 224),
+                                      (2500, 100, 40), (2049, 20, 132), (3000, 44, 128), (2111, 128, 256),
+                                      (5003, 256, 64), (2050, 132, 20), (169343, 128, 128)])
+def test_rows_tn_bias_gradient_from_the_same_pass(rows, C, K):
+    """``rows_tn(g, x, with_colsum=True)``: the loading waves of the weight-gradient kernel also leave ``g.sum(0)`` (the
+    bias gradient of gcn_lib/sparse/torch_nn.py:50-71's Linear) -- in both operand orders (a g wider than 128 columns is
+    the kernel's second operand and the result is written transposed), remainder rows and partial column blocks
+    included; the matrix itself is bit-identical to the call without the sums."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(rows + 3 * C + K)
+    g = torch.randn(rows, C, generator=gen) + 0.25
+    x = torch.randn(rows, K, generator=gen)
+    gd, xd = g.to(dev), x.to(dev)
+    out, gb = node_ops.rows_tn(gd, xd, with_colsum=True)
+    plain = node_ops.rows_tn(gd, xd)
+    assert out.shape == (C, K) and gb.shape == (C,) and out.is_contiguous()
+    assert torch.equal(out, plain)
+    ref = g.double().t() @ x.double()
+    nat = float((g.double().abs().t() @ x.double().abs()).max())
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-6 * nat)
+    ref_b = g.double().sum(0)
+    torch.testing.assert_close(gb.cpu().double(), ref_b, rtol=1e-6, atol=2e-7 * float(g.double().abs().sum(0).max()))
+    out2, gb2 = node_ops.rows_tn(gd, xd, with_colsum=True)
+    assert torch.equal(out, out2) and torch.equal(gb, gb2)            # fixed summation order
+
+
+def test_rows_linear_backward_takes_its_bias_gradient_from_rows_tn():
+    """The Linear's backward is three launches (dX, g^T x, its partial sum) and its gradients match float64."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(11)
+    for cin, cout in ((112, 224), (224, 112), (128, 128)):
+        x = torch.randn(13253, cin, generator=gen)
+        w = torch.randn(cout, cin, generator=gen) / cin ** 0.5
+        b = torch.randn(cout, generator=gen)
+        up = torch.randn(13253, cout, generator=gen)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        (torch.nn.functional.linear(xr, wr, br) * up.double()).sum().backward()
+        xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+        y = node_ops.rows_linear(xd, wd, bd)
+        calls = []
+        orig = node_ops.rows_tn
+        node_ops.rows_tn = lambda *a, **k: (calls.append(k), orig(*a, **k))[1]
+        try:
+            (y * up.to(dev)).sum().backward()
+        finally:
+            node_ops.rows_tn = orig
+        assert calls == [{"with_colsum": True}]
+        torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=2e-5, atol=1e-5 * float(xr.grad.abs().max()))
+        torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=2e-5, atol=1e-5 * float(wr.grad.abs().max()))
+        torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=2e-5, atol=1e-5 * float(br.grad.abs().max()))
+
+
 @pytest.mark.parametrize("rows", [7, 32, 40, 65, 8 * 32 * 3 + 31])
 def test_rows_tn_short_row_counts_through_the_abi(rows):
     """Whole steps, the zero-filled remainder step and workgroup ranges of dgcn_rows_tn_f32 at row counts the host wrapper
