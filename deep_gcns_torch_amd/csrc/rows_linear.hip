@@ -45,16 +45,21 @@ struct RlParams {
   int64_t ldy;
   int K, C;
   int relu;
+  int late;           // the residual joins AFTER the product chain (EPI 3): res + (x W^T + bias) rounded once, as an
+                      // elementwise pass behind the GEMM would -- the reversible couplings, whose 112 layers would
+                      // otherwise accumulate one rounding at the residual's magnitude per MFMA of every layer
+  int negate;         // (late only) y = res - (x W^T + bias): the inverse of the additive coupling, x_i = y_i - F_i(.)
   float* col_stats;   // [gridDim.x][2][C] partial sum y | sum y^2, or null
   float* xcol_sum;    // [gridDim.x][K] partial column sums of X (XSUM kernels), or null
 };
 
 // EPI: 0 = bias + residual; 1 = the same + per-channel sum y | sum y^2 partials; 2 = partial column sums of X (the bias
-// gradient when X is the upstream gradient), no residual
+// gradient when X is the upstream gradient), no residual; 3 = residual added / subtracted from behind the product chain
 template <int NT, int KC, int EPI>
 __global__ __launch_bounds__(kRlThreads) void rows_linear_kernel(const RlParams P) {
   constexpr bool STATS = EPI == 1;
   constexpr bool XSUM = EPI == 2;
+  constexpr bool LATE = EPI == 3;
   constexpr bool HALF = NT >= 8;            // weight fragments in one half-and-half buffer instead of two full ones
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int SU = 4 * KC + 2;            // row stride of a weight plane in 16-byte units
@@ -125,10 +130,10 @@ __global__ __launch_bounds__(kRlThreads) void rows_linear_kernel(const RlParams 
     f1 = (o + 4 < K) ? *reinterpret_cast<const f4v*>(p + 4) : f4v{0.f, 0.f, 0.f, 0.f};
   };
   // residual rows of a batch in the D layout (lane (n, q): rows 4 q + j, channels 16 ct + n)
-  auto load_res = [&](int64_t bt, f4v (&rr)[NT]) {
+  auto load_res = [&](int64_t bt, f4v (&rr)[NT], bool late_call) {
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) rr[ct] = f4v{0.f, 0.f, 0.f, 0.f};
-    if (XSUM || !P.res) return;
+    if (XSUM || !P.res || (LATE && !late_call)) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int64_t row = bt * kRlM + 4 * kq + j;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kRlThreads) void rows_linear_kernel(const RlParams 
   if (bt < nbatch) {
 #pragma unroll
     for (int sb = 0; sb < KC; ++sb) load_block(bt, sb, ra[sb][0], ra[sb][1]);
-    load_res(bt, rc);
+    load_res(bt, rc, false);
   }
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bx[0][ct] = wb[ct * 16 * SU];       // plane 1 of block 0
@@ -163,7 +168,9 @@ __global__ __launch_bounds__(kRlThreads) void rows_linear_kernel(const RlParams 
       const float bv = (P.bias && ch < C) ? P.bias[ch] : 0.f;      // L1-resident; not worth 8 registers
       acc[ct] = rc[ct] + bv;
     }
-    load_res(btl, rc);
+    load_res(btl, rc, false);
+    f4v rl[NT];                                       // (LATE) this batch's residual rows, met again behind the chain
+    if constexpr (LATE) load_res(bt, rl, true);
     const bool xs_ok = bt * kRlM + n < P.rows;
     __builtin_amdgcn_sched_barrier(0);
 
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(kRlThreads) void rows_linear_kernel(const RlParams 
         for (int ct = 0; ct < NT; ++ct) {
           if (cbase + ct * 16 + n < C) {
             float v = acc[ct][j];
+            if constexpr (LATE) v = P.negate ? rl[ct][j] - v : rl[ct][j] + v;
             if (P.relu) v = fmaxf(v, 0.f);
             yp[ct * 16] = v;
             if constexpr (STATS) {
@@ -358,6 +366,7 @@ int rl_launch_epi(const RlParams& P, const RlShape& S, hipStream_t s) {
 
 template <int NT, int KC>
 int rl_launch(const RlParams& P, const RlShape& S, hipStream_t s) {
+  if (P.late) return rl_launch_epi<NT, KC, 3>(P, S, s);
   if (P.xcol_sum) return rl_launch_epi<NT, KC, 2>(P, S, s);
   if (P.col_stats) return rl_launch_epi<NT, KC, 1>(P, S, s);
   return rl_launch_epi<NT, KC, 0>(P, S, s);
@@ -387,12 +396,14 @@ extern "C" int dgcn_rows_linear_f32(const float* x, int64_t ldx, int64_t rows, c
   RlShape S;
   if (rows < 0 || !rl_shape(K, C, &S)) return DGCN_E_SHAPE;
   if (xcol_sum && (res || col_stats)) return DGCN_E_MODE;       // the column-sum launch is the plain input-gradient GEMM
+  if (relu < 0 || relu > 7 || ((relu & 6) && (xcol_sum || col_stats || (relu & 1) || !res))) return DGCN_E_MODE;
   if (ldx < K || ldy < C || (res && ldr < C) || ldw < (w_trans ? C : K)) return DGCN_E_SHAPE;
   if ((reinterpret_cast<uintptr_t>(x) & 15u) || ldx % 4 != 0) return DGCN_E_ALIGN;
   if (rows == 0) return DGCN_OK;
   RlParams P;
   P.x = x; P.ldx = ldx; P.rows = rows; P.w = w; P.ldw = ldw; P.w_trans = w_trans ? 1 : 0;
-  P.bias = bias; P.res = res; P.ldr = ldr; P.y = y; P.ldy = ldy; P.K = K; P.C = C; P.relu = relu ? 1 : 0;
+  P.bias = bias; P.res = res; P.ldr = ldr; P.y = y; P.ldy = ldy; P.K = K; P.C = C;
+  P.relu = (relu & 1) ? 1 : 0; P.negate = (relu & 2) ? 1 : 0; P.late = (relu & 6) ? 1 : 0;
   P.col_stats = col_stats; P.xcol_sum = xcol_sum;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (S.nt == 4) {

@@ -4,9 +4,11 @@ backward step used by ``gcn_revop.InvertibleCheckpointFunction``.
     forward :  y_0 = x_0 + F_0(x_1 + ... + x_{g-1}),   y_i = x_i + F_i(y_{i-1})
     inverse :  x_i = y_i - F_i(y_{i-1})  (i = g-1 .. 1),   x_0 = y_0 - F_0(x_1 + ... + x_{g-1})
 """
+import inspect
+
 import torch
 
-from ... import ops
+from ... import node_ops, ops
 from .gcn_revop import InvertibleModuleWrapper  # noqa: F401  (model_rev.py reaches it as memgcn.InvertibleModuleWrapper)
 
 __all__ = ["GroupAdditiveCoupling", "InvertibleModuleWrapper"]
@@ -17,6 +19,31 @@ def _sum_of(parts):
     """``sum(parts)`` without the launch for ``0 + parts[0]`` when there is one part (group = 2: the input of F_0 is the
     other group itself, the same values bit for bit).  For passes that record no graph only."""
     return parts[0] if len(parts) == 1 else sum(parts)
+
+
+FOLD_COUPLING = True      # x_i +/- F_i(.) in the epilogue of F_i's last Linear (False: an elementwise launch; A/B)
+
+
+def _takes_residual(fm) -> bool:
+    """Whether the wrapped block's forward has the ``residual`` extension (rev_layer.BasicBlock and subclasses)."""
+    ok = getattr(type(fm), "_dgcn_takes_residual", None)
+    if ok is None:
+        try:
+            ok = "residual" in inspect.signature(type(fm).forward).parameters
+        except (TypeError, ValueError):
+            ok = False
+        try:
+            type(fm)._dgcn_takes_residual = ok
+        except (AttributeError, TypeError):
+            pass
+    return ok
+
+
+def _offer(fm, res, out, negate):
+    """The coupling's add / subtract offered to F_i's last Linear (node_ops.CouplingResidual), or None."""
+    if not (FOLD_COUPLING and res.is_cuda and res.dtype == torch.float32 and res.dim() == 2 and _takes_residual(fm)):
+        return None
+    return node_ops.CouplingResidual(res, out, negate)
 
 
 class GroupAdditiveCoupling(torch.nn.Module):
@@ -51,11 +78,15 @@ class GroupAdditiveCoupling(torch.nn.Module):
             # the reversible wrapper's forward (no graph): every y_i is written straight into its columns of the result
             y = torch.empty_like(x)
             for i, yv in enumerate(torch.chunk(y, self.group, dim=1)):
+                cr = _offer(self.Fms[i], xs[i], yv, False)
+                kw = {} if cr is None else {"residual": cr}
                 if _stashes is None:
-                    y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
+                    f = self.Fms[i](y_in, edge_index, *extra[i], **kw)
                 else:
                     with ops.stash_aggregation(_stashes[i], "record"):
-                        y_in = torch.add(xs[i], self.Fms[i](y_in, edge_index, *extra[i]), out=yv)
+                        f = self.Fms[i](y_in, edge_index, *extra[i], **kw)
+                # (folded: F_i's last Linear wrote x_i + F_i into the column block itself)
+                y_in = yv if (cr is not None and cr.used) else torch.add(xs[i], f, out=yv)
             return y
         ys = []
         y_in = sum(xs[1:])
@@ -110,6 +141,7 @@ class GroupAdditiveCoupling(torch.nn.Module):
         wgrads = [None] * len(weights)
         xs = [None] * g
         gx = [None] * g
+        own_version = [False] * g
         flat = y.dim() == 2 and dim in (-1, 1) and not torch.is_grad_enabled()
         if flat:                                       # x and grad_x are assembled in place, column block by column block
             x_buf, gx_buf = torch.empty_like(y), torch.empty_like(grad_y)
@@ -118,7 +150,10 @@ class GroupAdditiveCoupling(torch.nn.Module):
         for i in range(g - 1, -1, -1):
             Fm = self.Fms[i]
             with torch.enable_grad():
-                src = ys[i - 1] if i != 0 else sum(xs[1:])
+                # F_0's input is the sum of the other groups: with one other group whose x_1 came out of the folded
+                # epilogue -- a tensor with its own version counter over that column block of x -- it is that tensor
+                # itself; a plain view of x_buf would fail autograd's version check once x_0 is written next to it
+                src = ys[i - 1] if i != 0 else (xs[1] if (g == 2 and own_version[1]) else sum(xs[1:]))
                 leaf = src.detach().requires_grad_(True)
                 leaves, views = [], []
                 call_args = []
@@ -141,10 +176,16 @@ class GroupAdditiveCoupling(torch.nn.Module):
                 for cm in ctxs:
                     cm.__enter__()
                 try:
-                    out = Fm(leaf, edge_index, *call_args)
+                    cr = _offer(Fm, ys[i], xv[i], True) if flat else None
+                    out = Fm(leaf, edge_index, *call_args, **({} if cr is None else {"residual": cr}))
                     if flat:
                         with torch.no_grad():
-                            xs[i] = torch.sub(ys[i], out, out=xv[i])
+                            if cr is not None and cr.used:
+                                # ``out`` holds y_i - F_i (the values of x_i, in place in x's column block) and the
+                                # graph of F_i: differentiated below with the gradient that reaches F_i's output
+                                xs[i], own_version[i] = out.detach(), True
+                            else:
+                                xs[i] = torch.sub(ys[i], out, out=xv[i])
                             total = gxv[i].copy_(gys[i]) if carry is None else torch.add(gys[i], carry, out=gxv[i])
                     else:
                         xs[i] = ys[i] - out.detach()

@@ -38,7 +38,9 @@ class BasicBlock(nn.Module):
         self.norm = norm_layer(norm, in_channels)
         self.dropout = SharedDropout()
 
-    def forward(self, x, edge_index, dropout_mask=None, edge_emb=None):
+    def forward(self, x, edge_index, dropout_mask=None, edge_emb=None, residual=None):
+        """``residual`` (extension, ``node_ops.CouplingResidual`` from the additive coupling): handed to the convolution,
+        whose last Linear may fold ``x_i +/- F_i(.)`` into its epilogue (GENBlock; the offer is ignored otherwise)."""
         shared = isinstance(self.dropout, SharedDropout)
         if shared and dropout_mask is not None:
             self.dropout.set_mask(dropout_mask)
@@ -49,6 +51,8 @@ class BasicBlock(nn.Module):
                                           mask=self.dropout.mask if self.training else None)
         else:
             out = self.dropout(F.relu(self.norm(x)))
+        if residual is not None and type(self.gcn) is GENConv:
+            return self.gcn(out, edge_index, edge_emb, residual=residual)
         if edge_emb is not None:
             return self.gcn(out, edge_index, edge_emb)
         return self.gcn(out, edge_index)

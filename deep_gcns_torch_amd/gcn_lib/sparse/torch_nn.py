@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from ...nn_util import TallLinear
-from ...node_ops import BatchNorm1d, LayerNorm
+from ...node_ops import BatchNorm1d, CouplingResidual, LayerNorm
 from ...utils.data_util import get_atom_feature_dims, get_bond_feature_dims
 
 __all__ = ["act_layer", "norm_layer", "MultiSeq", "MLP", "AtomEncoder", "BondEncoder"]
@@ -80,6 +80,8 @@ class MLP(nn.Sequential):
         (extension) returns ``(y, stats)`` with the last Linear's output statistics for the caller's next BatchNorm1d."""
         mods = list(self._modules.values())
         last_lin = max((i for i, m in enumerate(mods) if isinstance(m, TallLinear)), default=-1)
+        if isinstance(residual, CouplingResidual) and last_lin != len(mods) - 1:
+            residual = None                       # an offer, not a request: the coupling adds it itself
         ext = residual is not None or want_stats
         if ext and last_lin != len(mods) - 1:
             raise ValueError("residual / want_stats need the MLP to end with its Linear (last_lin=True)")

@@ -72,6 +72,6 @@ class TallLinear(nn.Linear):
             y = _TallLinearFn.apply(x, self.weight, self.bias)
         else:
             y = super().forward(x)
-        if residual is not None:
+        if residual is not None and not isinstance(residual, node_ops.CouplingResidual):   # (left to the coupling: not folded)
             y = y + residual
         return (y, None) if want_stats else y

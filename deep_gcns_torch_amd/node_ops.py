@@ -428,10 +428,12 @@ def rows_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return x.size(1) == K and bool(_lib.load().dgcn_rows_linear_supported(K, C))
 
 
-def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum, out=None):
+def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum, out=None, negate=False, late=False):
     """y = x @ (w^T | w) + bias + res on the matrix pipe; returns (y, stats or None, xsum partials or None).
-    ``out``: write the result there (contiguous fp32 (rows, C)); ``out is res`` accumulates in place -- every element is
-    read (one 16-row batch ahead) and written by the same wave, rows of different waves are disjoint."""
+    ``out``: write the result there (fp32 (rows, C), unit column stride); ``out is res`` accumulates in place -- every
+    element is read (one 16-row batch ahead) and written by the same wave, rows of different waves are disjoint.
+    ``late``: the residual joins behind the product chain (rounded once at its magnitude, as a separate add would);
+    ``negate``: y = res - (x @ w^T + bias), likewise."""
     lib = _lib.load()
     dev = x.device
     if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
@@ -454,7 +456,8 @@ def _rl_launch(x, w, w_trans, bias, res, relu, want_stats, want_xsum, out=None):
     with _lib.device_ctx(dev):
         _lib.check(lib.dgcn_rows_linear_f32(x.data_ptr(), x.stride(0), rows, w.data_ptr(), w.stride(0), 1 if w_trans else 0,
                                             _lib.ptr(bias), _lib.ptr(res), res.stride(0) if res is not None else 0,
-                                            y.data_ptr(), y.stride(0), K, C, 1 if relu else 0, _lib.ptr(stats), _lib.ptr(xsum),
+                                            y.data_ptr(), y.stride(0), K, C, (1 if relu else 0) | (2 if negate else 0) | (4 if late else 0),
+                                            _lib.ptr(stats), _lib.ptr(xsum),
                                             _lib.current_stream_handle(dev)), "dgcn_rows_linear_f32")
     return y, stats, xsum
 
@@ -484,13 +487,47 @@ class residual_gradient_is_last_use:
         return False
 
 
+class CouplingResidual:
+    """What the additive coupling of the reversible layers (eff_gcn_modules/rev/memgcn.py) hands down as ``residual`` to
+    the block it wraps: ``out = res + F(.)`` (forward, ``y_i = x_i + F_i``) or ``out = res - F(.)`` (``negate``: the
+    inverse, ``x_i = y_i - F_i``) is to be written straight into ``out`` -- a column block of the tensor the coupling
+    assembles -- by the epilogue of F's LAST Linear instead of by an elementwise pass behind it.  Whoever folds it sets
+    ``used`` and returns a tensor that aliases ``out``; a level that cannot (library GEMM, other shapes) ignores it and
+    the coupling does the add itself.  ``res`` takes no gradient here.  Under autograd the returned tensor carries the
+    VALUES ``res -/+ F`` and the graph of ``F``: the coupling differentiates F through it with the gradient that
+    reaches F's output (memgcn.fused_backward)."""
+    __slots__ = ("res", "out", "negate", "used")
+
+    def __init__(self, res, out, negate=False):
+        self.res, self.out, self.negate, self.used = res, out, bool(negate), False
+
+    def fits(self, rows, C, dev) -> bool:
+        r, o = self.res, self.out
+        return (not self.used and r.shape == (rows, C) and o.shape == (rows, C) and r.dtype == torch.float32
+                and o.dtype == torch.float32 and r.device == dev and o.device == dev and r.stride(1) == 1
+                and o.stride(1) == 1 and not r.requires_grad)
+
+
+def _alias_with_own_version(t: torch.Tensor) -> torch.Tensor:
+    """A tensor over the same memory whose version counter is its own: writes to OTHER column blocks of the buffer ``t`` is
+    a view of do not invalidate what autograd saved of this one (the blocks are disjoint)."""
+    return torch.empty(0, device=t.device, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
+
+
 class _RowsLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, want_stats: bool):
+    def forward(ctx, x, weight, bias, residual, want_stats: bool, coupling=None):
         ctx.res_view = _RES_GRAD_VIEW.on
         ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) statistics output
         w = weight.detach()
         b = None if bias is None else bias.detach().float().contiguous()
+        if coupling is not None:
+            _rl_launch(x, w, False, b, coupling.res, False, False, False, out=coupling.out, negate=coupling.negate,
+                       late=True)
+            coupling.used = True
+            ctx.save_for_backward(x, weight)
+            ctx.has_bias = bias is not None
+            return _alias_with_own_version(coupling.out), None
         y, stats, _ = _rl_launch(x, w, False, b, residual, False, want_stats, False)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -503,7 +540,7 @@ class _RowsLinear(torch.autograd.Function):
     def backward(ctx, g, _gstats):
         from .nn_util import splitk_xt_g
         if g is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         g = g.float()
         if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
@@ -532,7 +569,7 @@ class _RowsLinear(torch.autograd.Function):
         gres = None
         if ctx.needs_input_grad[3]:
             gres = g.view_as(g) if ctx.res_view else g      # (see residual_gradient_is_last_use)
-        return gx, gw, gb, gres, None
+        return gx, gw, gb, gres, None, None
 
 
 def rows_matmul_accumulate_(acc: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -603,6 +640,10 @@ def rows_linear(x, weight, bias=None, residual=None, want_stats: bool = False):
     """``x @ weight.T + bias [+ residual]`` for (rows, K) node features; with ``want_stats`` also the per-workgroup
     partial sums (parts, 2, C) of the result and its square (hand them to the following BatchNorm1d as ``stats``).
     Returns ``y`` or ``(y, stats)``."""
+    if isinstance(residual, CouplingResidual):
+        cr = residual if (not want_stats and x.dim() == 2 and residual.fits(x.size(0), weight.size(0), x.device)) else None
+        y, stats = _RowsLinear.apply(x, weight, bias, None, bool(want_stats), cr)
+        return (y, stats) if want_stats else y
     y, stats = _RowsLinear.apply(x, weight, bias, residual, bool(want_stats))
     return (y, stats) if want_stats else y
 

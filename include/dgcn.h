@@ -662,6 +662,12 @@ int dgcn_rows_msgnorm_bwd_f32(const float* g, const float* x, int64_t ldx, const
  *   w_trans 0: w is the nn.Linear weight (C, K), row stride ldw;  1: w is (K, C), row stride ldw -- the input
  *              gradient dX = G W of a Linear(C_in = C here ... ) is this call with x = G and w = its weight
  *   bias (C) or NULL; res (rows, C) row stride ldr or NULL; y (rows, C) row stride ldy
+ *   relu      bit 0: the ReLU above.  Bits 1 and 2 (res required; no ReLU, col_stats or xcol_sum; DGCN_E_MODE
+ *              otherwise) are the additive coupling of the reversible layers (eff_gcn_modules/rev/memgcn.py:36-52)
+ *              written where the caller assembles its rows (ldy = the full row): bit 2: y = res + (x W^T + bias) with
+ *              the residual joining BEHIND the product chain (one rounding at its magnitude, as the elementwise pass
+ *              it replaces -- 112 stacked couplings accumulate the difference); bit 1: y = res - (x W^T + bias), the
+ *              inverse x_i = y_i - F_i(.), likewise
  *   col_stats NULL or [dgcn_rows_linear_num_partials][2][C]: per-workgroup sum y | sum y^2 (what dgcn_bn_finalize_f32
  *              takes as `partial`, count = rows)
  *   xcol_sum  NULL or [dgcn_rows_linear_num_partials][K]: per-workgroup column sums of x (K <= 128, no res / col_stats):

@@ -646,3 +646,82 @@ def test_sum_partials_split_leaves_the_last_column_apart(shape):
     assert torch.equal(a, whole[:, :-1]) and torch.equal(b, whole[:, -1])
     a0, b0 = _lib.sum_partials_split(p[:0])
     assert not a0.any() and not b0.any()
+
+
+@pytest.mark.parametrize("rows,K,C,negate", [(13253, 224, 112, True), (13253, 224, 112, False), (5001, 64, 48, True),
+                                             (2049, 128, 128, True)])
+def test_rows_linear_writes_the_coupling_result_into_a_column_block(rows, K, C, negate):
+    """``CouplingResidual``: ``res -/+ (x W^T + b)`` from the Linear's epilogue, written into a column block of a wider
+    buffer (row stride 2 C) -- the additive coupling's ``x_i = y_i - F_i`` / ``y_i = x_i + F_i``
+    (eff_gcn_modules/rev/memgcn.py:36-52) without an elementwise pass; the neighbouring block stays untouched, the
+    returned tensor aliases the block and differentiates as F."""
+    from deep_gcns_torch_amd import node_ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=gen)
+    w = torch.randn(C, K, generator=gen) / K ** 0.5
+    b = torch.randn(C, generator=gen)
+    res_full = torch.randn(rows, 2 * C, generator=gen)
+    up = torch.randn(rows, C, generator=gen)
+    f = x.double() @ w.double().t() + b.double()
+    ref = res_full[:, C:].double() - f if negate else res_full[:, C:].double() + f
+    buf = torch.full((rows, 2 * C), 7.0, device=dev)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    cr = node_ops.CouplingResidual(res_full.to(dev)[:, C:], buf[:, C:], negate=negate)
+    y = node_ops.rows_linear(xd, wd, bd, cr)
+    assert cr.used and y.data_ptr() == buf[:, C:].data_ptr() and y.stride() == (2 * C, 1)
+    nat = float((x.double().abs() @ w.double().abs().t()).max()) + float(res_full.abs().max())
+    torch.testing.assert_close(buf[:, C:].cpu().double(), ref, rtol=1e-5, atol=2e-6 * nat)
+    assert bool((buf[:, :C] == 7.0).all())
+    # the graph behind the returned values is F's: gradients of x W^T + b, whatever the sign of the epilogue
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], up.to(dev))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    rx, rw, rb = torch.autograd.grad(torch.nn.functional.linear(xr, wr, br), [xr, wr, br], up.double())
+    for got, want in ((gx, rx), (gw, rw), (gb, rb)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=1e-5 * float(want.abs().max()))
+
+
+def test_additive_coupling_folds_its_adds_into_the_last_linear():
+    """GroupAdditiveCoupling over GENBlocks on device rows: forward and fused backward with the coupling's add / subtract
+    folded into F_i's last Linear give the values of the elementwise form (FOLD_COUPLING = False) -- the rebuilt input,
+    the input gradient, every weight gradient -- and launch no torch add / sub for them."""
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from deep_gcns_torch_amd import ops, synth
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import memgcn, rev_layer
+    dev = _dev()
+    torch.manual_seed(3)
+    N, C, g = 6000, 128, 2
+    ei = synth.powerlaw_graph(N, 40_000, 2, device=dev)
+    fms = torch.nn.ModuleList([rev_layer.GENBlock(C // g, C // g, aggr="max", norm="layer", mlp_layers=2) for _ in range(g)])
+    coupling = memgcn.GroupAdditiveCoupling(fms, group=g).to(dev).train()
+    x = torch.randn(N, C, device=dev)
+    gy = torch.randn(N, C, device=dev)
+    mask = (torch.rand(N, C // g, device=dev) > 0.2).float() / 0.8
+    weights = tuple(p for p in coupling.parameters())
+    res = {}
+    for fold in (True, False):
+        memgcn.FOLD_COUPLING = fold
+        calls = []
+        add, sub = torch.add, torch.sub
+        torch.add = lambda *a, **k: (calls.append("add"), add(*a, **k))[1]
+        torch.sub = lambda *a, **k: (calls.append("sub"), sub(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                y = coupling(x, ei, mask.repeat(1, g))
+                xb, gx, wg = coupling.fused_backward(y, gy, ei, (mask.repeat(1, g),), weights, [], ops.edge_grad_sink)
+        finally:
+            torch.add, torch.sub = add, sub
+            memgcn.FOLD_COUPLING = True
+        res[fold] = (y, xb, gx, wg, calls)
+    yf, xf, gxf, wgf, calls_f = res[True]
+    yu, xu, gxu, wgu, calls_u = res[False]
+    assert calls_u.count("sub") == g and calls_f.count("sub") == 0
+    assert calls_f.count("add") == calls_u.count("add") - g          # the forward's y_i = x_i + F_i
+    scale = float(yu.abs().max())
+    torch.testing.assert_close(yf, yu, rtol=0, atol=2e-6 * scale)
+    torch.testing.assert_close(xf, xu, rtol=0, atol=4e-6 * scale)
+    torch.testing.assert_close(xf, x, rtol=0, atol=2e-5 * scale)     # the coupling is inverted
+    torch.testing.assert_close(gxf, gxu, rtol=0, atol=1e-4 * float(gxu.abs().max()))
+    for a, b in zip(wgf, wgu):
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-4 * float(b.abs().max()) + 1e-12)
