@@ -134,12 +134,24 @@ class _ComposeEncoder(torch.autograd.Function):
         eb = None if enc_b is None else enc_b.detach().contiguous()
         C, H = lw.shape
         F = ew.size(1)
-        out_w = torch.empty(C, F, device=dev, dtype=torch.float32)
-        out_b = torch.empty(C, device=dev, dtype=torch.float32) if (lb is not None or eb is not None) else None
-        with _lib.device_ctx(dev):
-            _lib.check(lib.dgcn_enc_compose_fwd_f32(lw.data_ptr(), _lib.ptr(lb), ew.data_ptr(), _lib.ptr(eb), C, H, F,
-                                                    out_w.data_ptr(), _lib.ptr(out_b), _lib.current_stream_handle(dev)),
-                       "dgcn_enc_compose_fwd_f32")
+        # a function that runs twice per step on the same parameters (the reversible layers' forward and the grad-enabled
+        # evaluation inside their backward; a checkpointed layer): the second pass takes the first one's (W', b') from
+        # the pass's stash (ops.AggregationStash, record / replay) -- no launch; the graph is recorded all the same
+        from . import ops
+        stash = ops._active_stash()
+        key = ("compose", lw.data_ptr(), ew.data_ptr(), C, H, F)
+        kept = stash.extra.get(key) if (stash is not None and stash.mode == "replay") else None
+        if kept is not None:
+            out_w, out_b = kept[0].detach(), (None if kept[1] is None else kept[1].detach())
+        else:
+            out_w = torch.empty(C, F, device=dev, dtype=torch.float32)
+            out_b = torch.empty(C, device=dev, dtype=torch.float32) if (lb is not None or eb is not None) else None
+            with _lib.device_ctx(dev):
+                _lib.check(lib.dgcn_enc_compose_fwd_f32(lw.data_ptr(), _lib.ptr(lb), ew.data_ptr(), _lib.ptr(eb), C, H, F,
+                                                        out_w.data_ptr(), _lib.ptr(out_b),
+                                                        _lib.current_stream_handle(dev)), "dgcn_enc_compose_fwd_f32")
+            if stash is not None and stash.mode == "record":
+                stash.extra[key] = (out_w, out_b)
         ctx.save_for_backward(lw, ew, eb)
         ctx.has_lb = lb is not None
         if out_b is None:

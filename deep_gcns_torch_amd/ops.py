@@ -156,6 +156,7 @@ class AggregationStash:
 
     def __init__(self, node_sized_only: bool = False):
         self.items = []
+        self.extra = {}        # small by-products of the first pass that the second reuses by key (blocks._ComposeEncoder)
         self.pos = 0
         self.mode = None
         # True: an aggregation whose backward needs an (E, C) array of the forward (the fused edge encoder's
@@ -191,6 +192,7 @@ class stash_aggregation:
             self.stash.pos = 0
         else:
             self.stash.items.clear()
+            self.stash.extra.clear()
         _TLS.stash = self.stash
         return self.stash
 
