@@ -186,7 +186,9 @@ class GroupAdditiveCoupling(torch.nn.Module):
                                 xs[i], own_version[i] = out.detach(), True
                             else:
                                 xs[i] = torch.sub(ys[i], out, out=xv[i])
-                            total = gxv[i].copy_(gys[i]) if carry is None else torch.add(gys[i], carry, out=gxv[i])
+                            # (the last group's gradient is grad_y's own column block until F_0's input gradient
+                            #  joins it below: no copy into the buffer first)
+                            total = gys[i] if carry is None else torch.add(gys[i], carry, out=gxv[i])
                     else:
                         xs[i] = ys[i] - out.detach()
                         total = gys[i] if carry is None else gys[i] + carry
@@ -210,7 +212,16 @@ class GroupAdditiveCoupling(torch.nn.Module):
         # the gradient into F_0's input (the sum of the other groups) goes to every x_i, i >= 1
         if carry is not None:
             for i in range(1, g):
-                gx[i] = gx[i].add_(carry.detach()) if flat else gx[i] + carry
+                if not flat:
+                    gx[i] = gx[i] + carry
+                elif gx[i] is gys[i]:
+                    gx[i] = torch.add(gys[i], carry.detach(), out=gxv[i])
+                else:
+                    gx[i] = gx[i].add_(carry.detach())
+        if flat:
+            for i in range(g):
+                if gx[i] is gys[i]:                    # (one group, or no gradient into F_0's input)
+                    gxv[i].copy_(gys[i])
         x = x_buf if flat else torch.cat(xs, dim=dim)
         grad_x = gx_buf if flat else torch.cat(gx, dim=dim)
         wgrads = [torch.zeros_like(w) if gr is None else gr for w, gr in zip(weights, wgrads)]
