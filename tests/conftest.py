@@ -89,9 +89,11 @@ def gate(name, err, tol, what=""):
     assert err < tol, f"{name}: {err:.3e} >= {tol:.1e} {what}"
 
 
-@pytest.fixture(autouse=True)
+@pytest.fixture
 def identity_dropout_mask(monkeypatch):
-    """``tensor.bernoulli_(1.0)`` is the identity mask of the reversible models at dropout 0
+    """(Requested by the modules that run a reversible model at dropout 0 -- ``pytestmark = ... usefixtures`` --, not autouse:
+    every other test draws its masks from the real device generator)
+    ``tensor.bernoulli_(1.0)`` is the identity mask of the reversible models at dropout 0
     (examples/ogb_eff/ogbn_proteins/model_rev.py:101: ``zeros_like(h).bernoulli_(1 - dropout)``).  On the device it is
     "uniform < 1.0" with the uniform drawn from (0, 1]: an element is 0 with probability 2^-24 -- one zero in ~18 % of the
     13,253 x 224 masks (round 5: one row of one layer off by 4e-2 in a random step; the CPU generator, which produced the

@@ -9,6 +9,8 @@ from contextlib import redirect_stdout
 import pytest
 import torch
 
+pytestmark = pytest.mark.usefixtures("identity_dropout_mask")    # dropout-0 models: see conftest.py
+
 import ref_models
 from conftest import load_golden
 

@@ -13,7 +13,7 @@ import arch_restated
 import rev_restated
 from deep_gcns_torch_amd import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("identity_dropout_mask")]
 
 
 def _dev():
@@ -109,12 +109,14 @@ def test_fused_deepergcn_equals_the_model_files_loop(layers, norm, mlp_layers, m
         # what fp32 rounding does to these gradients through `layers` normalised layers: the same replay (same branches) in
         # float32 on the host against the float64 one -- the device (fp32 partial sums per workgroup for the BatchNorm
         # statistics, six-product bf16 GEMMs, another summation order in the aggregation) has to stay within an order of
-        # magnitude of that, floor 3e-4 (measured: 10 layers 1.0e-4 vs 1.3e-5 on the host, 28 layers 3.7e-3 vs 7.0e-4)
+        # magnitude of that (measured: 10 layers 1.0e-4 vs 1.3e-5 on the host, 28 layers 3.7e-3 vs 7.0e-4).  Round 6: the unit
+        # is max(3 x the host's float32 replay, 2e-4) -- was max(10 x, 3e-4); measured at most 0.52 of the new unit
+        # (profiles/r06_test_gates.json: 10 layers with two-layer MLPs, 1.04e-4)
         worst32 = max(attribution.gradient_errors(host_along(dec, torch.float32), ref64).values())
         from conftest import gate
         gate(f"fuse deepergcn {layers}-{norm}-{mlp_layers}-{mode}, {route}: worst parameter gradient vs float64 along its own ReLU "
-             f"decisions, in units of max(10 x the host's float32 replay [{worst32:.2e}], 3e-4)",
-             worst[1] / max(10 * worst32, 3e-4), 1.0, what=f"{worst[0]} {worst[1]:.3e}")
+             f"decisions, in units of max(3 x the host's float32 replay [{worst32:.2e}], 2e-4)",
+             worst[1] / max(3 * worst32, 2e-4), 1.0, what=f"{worst[0]} {worst[1]:.3e}")
         print(f"[fuse {layers}-{norm}-{mlp_layers}-{mode}] {route}: {dec.n_decisions()} ReLU decisions replayed, worst "
               f"gradient error {worst[1]:.2e} of max |grad| (host float32 replay: {worst32:.2e})")
     # an instance that does not qualify takes the model file's own forward: another block type, CPU tensors

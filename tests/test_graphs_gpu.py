@@ -9,7 +9,7 @@ import torch
 import rev_restated
 from deep_gcns_torch_amd import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("identity_dropout_mask")]
 
 
 def test_graphed_training_step_equals_eager_steps():

@@ -13,6 +13,8 @@ InvertibleModuleWrapper / GroupAdditiveCoupling / GENBlock files (oracle/make_go
 import pytest
 import torch
 
+pytestmark = pytest.mark.usefixtures("identity_dropout_mask")    # dropout-0 models: see conftest.py
+
 import rev_restated
 from conftest import load_golden
 

@@ -24,7 +24,7 @@ import torch
 import config_replays as cr
 import rev_restated
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("identity_dropout_mask")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HN_FACTOR = 4.0        # device error vs float64 <= max(this x the reference's float32 error vs float64, 1e-4 of the scale)
