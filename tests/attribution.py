@@ -411,3 +411,73 @@ def gradient_errors(model, ref_model, small=1e-2):
         scale = max(float(r.abs().max()), small * wide, 1e-300)
         out[k] = float((a.grad.detach().cpu().double() - r).abs().max()) / scale
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RevGCN (examples/ogb_eff/ogbn_proteins/model_rev.py) under MAX aggregation: float64 along ALL of a device pass's decisions
+# ---------------------------------------------------------------------------------------------------------------------
+def _forced_relu(x, mask):
+    """Value mask * max(x, tiny), gradient mask (see ReluDecisions.replaying)."""
+    m = mask.to(device=x.device, dtype=x.dtype)
+    return m * (x + (x.clamp_min(1e-30) - x).detach())
+
+
+def _forced_max_aggregate(a, ids, Wp, bp, feat, src_of_edge, has_edges, eps=1e-7):
+    """max_j relu(a[src_e] + W' f_e + b') + eps of gcn_lib/sparse/torch_vertex.py:56-85 / torch_message.py:46-47 with the
+    winner of every (row, channel) GIVEN (``ids``: original edge id, -1 = no neighbour passed the relu): a gather of
+    n * C winners instead of a reduction over E * C messages, differentiable in a, W', b'."""
+    n, C = ids.shape
+    valid = ids >= 0
+    e = ids.clamp_min(0).long()
+    cidx = torch.arange(C).expand(n, C)
+    z = a[src_of_edge[e], cidx] + (feat[e] * Wp.unsqueeze(0)).sum(-1) + bp
+    val = z + (z.clamp_min(1e-30) - z).detach() + eps
+    floor = torch.where(has_edges.unsqueeze(1), torch.full((), eps, dtype=a.dtype), torch.zeros((), dtype=a.dtype))
+    return torch.where(valid, val, floor.expand(n, C))
+
+
+def revgcn_max_backward_along(host, masks, ids, inputs, probe):
+    """Backward of ``sum(last_norm(h) * probe)`` of ``host`` -- a CPU float64 RevGCN (tests/rev_restated.py classes: they
+    hold the parameters; their own forward is not used) -- along the decisions of a device pass: ``masks`` = the on / off
+    mask of every ReLU site in call order (per layer and group: the block's norm -> ReLU, the MLP's norm -> ReLU; then the
+    model's final ReLU), ``ids`` = the arg-max edge ids of every aggregation launch in call order.  Every coupling function
+    is checkpointed (the decisions are indexed, not consumed in sequence, so the recomputation finds its own).  Leaves the
+    gradients on ``host``'s parameters; returns last_norm's output."""
+    from torch.utils.checkpoint import checkpoint
+    x, nidx, ei, feat = inputs["x"].double(), inputs["node_index"], inputs["edge_index"], inputs["edge_attr"].double()
+    n = x.size(0)
+    src_of_edge = ei[0]
+    has_edges = torch.bincount(ei[1], minlength=n) > 0
+    group = host.group
+    assert len(ids) == len(host.gcns) * group and len(masks) == 2 * len(ids) + 1
+
+    def coupling_fn(fm, k):
+        def f(xin, W_e, b_e):
+            a = _forced_relu(fm.norm(xin), masks[2 * k])
+            lin = fm.gcn.edge_encoder
+            Wp = lin.weight @ W_e
+            bp = lin.weight @ b_e + lin.bias
+            h = a + _forced_max_aggregate(a, ids[k], Wp, bp, feat, src_of_edge, has_edges)
+            mods = list(fm.gcn.mlp.children())
+            assert len(mods) == 4, "Linear, norm, ReLU, Linear"
+            h = _forced_relu(mods[1](mods[0](h)), masks[2 * k + 1])
+            return mods[3](h)
+        return f
+
+    feats = host.node_features[nidx].double()
+    if host.use_one_hot_encoding:
+        feats = torch.cat((feats, host.node_one_hot_encoder(x)), dim=1)
+    h = host.node_features_encoder(feats)
+    W_e, b_e = host.edge_encoder.weight, host.edge_encoder.bias
+    for L, wrapper in enumerate(host.gcns):
+        fms = wrapper._fn.Fms
+        xs = torch.chunk(h, group, dim=1)
+        y_in = sum(xs[1:])
+        ys = []
+        for g in range(group):
+            y_in = xs[g] + checkpoint(coupling_fn(fms[g], L * group + g), y_in, W_e, b_e, use_reentrant=False)
+            ys.append(y_in)
+        h = torch.cat(ys, dim=1)
+    hn = host.last_norm(h)
+    (hn * probe.double()).sum().backward()
+    return hn.detach()

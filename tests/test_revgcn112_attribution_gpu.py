@@ -1,0 +1,106 @@
+"""BASELINE config 5 at depth 112, MAX aggregation: every parameter gradient of the device step against float64 ALONG THE
+DEVICE'S OWN DECISIONS.
+
+tests/test_revgcn112_gpu.py holds the device to the reference's own float32-vs-float64 error (two correct float32 runs of
+this model differ per parameter by whole gradient terms: a ReLU within rounding of zero, two arg-max candidates within
+rounding of each other).  Here those decisions are taken out of the comparison instead: a recording pass of the device
+model stores the on / off mask of all 449 ReLU sites (13,253 x 112 / 224 each) and the arg-max edge id of all 224
+aggregation launches (13,253 x 112 each), and the float64 host evaluation (tests/attribution.revgcn_max_backward_along)
+is forced through the same branches -- what is left between the two gradients is fp32 rounding through 224 coupling
+functions, and it has to be SMALL for every parameter, not just as small as the reference's own float32 noise.
+
+Measured (round 6): all 2,248 parameter gradients of the 112-layer model within 3.8e-6 of their scale (median 1.2e-6),
+last_norm's output within 9.2e-7 of its max, along 0.5 G decisions.  One subtlety decides the result: the gradient is
+formed by the BACKWARD's evaluation of every coupling function on the REBUILT input (x_i = y_i - F_i, off the forward's
+by 4e-7 relative at this depth), and 10 of the 0.33 G ReLU pre-activations take the other branch there than in the forward
+pass -- replaying the FORWARD's masks leaves 2.7e-3 on `gcns.69._fn.Fms.0.norm.bias`; the reference's own reversible
+scheme (eff_gcn_modules/rev/gcn_revop.py:98-140) recomputes on rebuilt inputs in the same way.
+Host memory: ~34 GB for the float64 evaluation at 112 layers (every coupling function checkpointed).
+"""
+import os
+
+import pytest
+import torch
+
+import attribution
+import config_replays as cr
+import rev_restated
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("identity_dropout_mask")]
+
+GRAD_TOL = 2e-5          # max |device - float64 along the device's decisions| / scale, EVERY parameter (BASELINE's fp32 tolerance is
+                         # 1e-4; measured: 2.2e-6 at 8 layers, 3.8e-6 at 112 -- profiles/r06_test_gates.json)
+
+
+@pytest.mark.parametrize("layers", [8, 112])
+def test_revgcn_max_gradients_along_the_device_decisions(layers):
+    import deep_gcns_torch_amd
+    deep_gcns_torch_amd.install()
+    from conftest import gate
+    from deep_gcns_torch_amd import fuse, ops
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
+    dev = torch.device("cuda:0")
+    inp = cr.revgcn_inputs()
+    kw = dict(num_layers=layers, hidden=224, aggr="max", dropout=0.0, node_table=inp["table"])
+    host = rev_restated.RevGCNModelFile(impl="restated", **kw)
+    cr.formula_init(host, seed=5)
+    m = rev_restated.RevGCNModelFile(impl="product", **kw)
+    m.load_state_dict(host.state_dict())
+    m.node_features = inp["table"].to(dev)
+    m = fuse.fuse_model(m.to(dev).train())
+    x, nidx, ei, ea = (inp[k].to(dev) for k in ("x", "node_index", "edge_index", "edge_attr"))
+    probe = inp["probe"].to(dev)
+
+    # ---- the arg-max ids: a pass without graph and without kept aggregations (the wrapper's own stashes would take the
+    #      launches); the step below keeps and replays exactly these (deterministic kernels, same inputs) ----
+    stash = ops.AggregationStash(node_sized_only=True)
+    saved = gcn_revop.KEEP_AGGREGATION
+    gcn_revop.KEEP_AGGREGATION = False
+    try:
+        with torch.no_grad(), ops.stash_aggregation(stash, "record"):
+            m(x, nidx, ei, ea)
+    finally:
+        gcn_revop.KEEP_AGGREGATION = saved
+    ids = [kept[1].cpu() for _, kept in stash.items]
+    assert len(ids) == 2 * layers and all(t.dtype == torch.int32 and t.shape == (inp["n"], 112) for t in ids)
+    stash.items.clear()
+
+    # ---- the step as shipped, every ReLU site recorded.  The gradient is formed by the BACKWARD's grad-enabled evaluation
+    #      of every coupling function, whose input is the REBUILT one (x_i = y_i - F_i: off the forward's by the
+    #      reconstruction's rounding, 4e-7 relative at this depth) -- a pre-activation within that distance of zero takes
+    #      the other branch there, and it is that branch the gradient follows (the LayerNorm backward recomputes its ReLU
+    #      mask from the input it saved).  Sites in call order: the forward's 4 x layers + 1, then the backward's, last layer
+    #      first, last group first, within a block norm -> ReLU then the MLP's ----
+    dec = attribution.ReluDecisions()
+    keep = {}
+    hook = m.last_norm.register_forward_hook(lambda mod, i, o: keep.__setitem__("hn", o))
+    with dec.recording():
+        m(x, nidx, ei, ea)
+        hook.remove()
+        (keep["hn"] * probe).sum().backward()
+        torch.cuda.synchronize()
+    group = 2
+    assert len(dec.masks) == 2 * (2 * group * layers) + 1, len(dec.masks)
+    fwd_masks, bwd_masks = dec.masks[:2 * group * layers], dec.masks[2 * group * layers + 1:]
+    masks = [None] * (2 * group * layers) + [dec.masks[2 * group * layers]]
+    v = 0
+    for L in range(layers - 1, -1, -1):
+        for g in range(group - 1, -1, -1):
+            k = L * group + g
+            masks[2 * k], masks[2 * k + 1] = bwd_masks[v], bwd_masks[v + 1]
+            v += 2
+    flipped = sum(int((a != b).sum()) for a, b in zip(fwd_masks, masks[:-1]))
+
+    # ---- float64 along the same branches ----
+    host = host.double().train()
+    hn64 = attribution.revgcn_max_backward_along(host, masks, ids, inp, inp["probe"])
+    hn_err = float((keep["hn"].detach().cpu().double() - hn64).abs().max() / hn64.abs().max())
+    errs = attribution.gradient_errors(m, host)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    n_dec = sum(int(t.numel()) for t in masks) + sum(int(t.numel()) for t in ids)
+    print(f"[revgcn{layers} max] {n_dec} decisions replayed ({flipped} ReLU sites where the backward's evaluation on the "
+          f"rebuilt input took the other branch than the forward); last_norm output {hn_err:.2e} of its max; worst parameter gradient "
+          f"{worst[1]:.2e} of its scale ({worst[0]}); median {sorted(errs.values())[len(errs) // 2]:.2e}")
+    gate(f"revgcn{layers} max, fused route: last_norm output vs float64 along the device's decisions (max error / max)", hn_err, 1e-4)
+    gate(f"revgcn{layers} max, fused route: worst parameter gradient vs float64 along the device's decisions (max error / scale), "
+         f"all {len(errs)} parameters", worst[1], GRAD_TOL, what=worst[0])

@@ -34,6 +34,9 @@ GRAD_FACTOR = 2.0      # every kept parameter gradient (max error / max |gradien
                        # since round 6 on the reference itself: a second float32 run with the edge order permuted is off
                        # by up to 45x the first run's error on individual parameters, its worst hit by 2x:
                        # tests/golden/make_revgcn112_perm.py, tests/test_oracle_golden.py::test_two_float32_runs...)
+                       # The STRICT statement for max aggregation is tests/test_revgcn112_attribution_gpu.py: along the
+                       # device's own ReLU / arg-max decisions every one of the 2,248 parameter gradients is within 3.8e-6
+                       # of its scale of the float64 evaluation -- what this factor absorbs is decisions, not arithmetic.
 DRIFT_FACTOR = 8.0     # rebuilt layer-0 input: relative L2 error <= this x the reference's float32 drift
 
 
