@@ -436,11 +436,14 @@ def _forced_max_aggregate(a, ids, Wp, bp, feat, src_of_edge, has_edges, eps=1e-7
     return torch.where(valid, val, floor.expand(n, C))
 
 
-def revgcn_max_backward_along(host, masks, ids, inputs, probe):
+def revgcn_max_backward_along(host, masks, ids, inputs, probe, aggr="max"):
     """Backward of ``sum(last_norm(h) * probe)`` of ``host`` -- a CPU float64 RevGCN (tests/rev_restated.py classes: they
     hold the parameters; their own forward is not used) -- along the decisions of a device pass: ``masks`` = the on / off
     mask of every ReLU site in call order (per layer and group: the block's norm -> ReLU, the MLP's norm -> ReLU; then the
-    model's final ReLU), ``ids`` = the arg-max edge ids of every aggregation launch in call order.  Every coupling function
+    model's final ReLU), ``ids`` = the arg-max edge ids of every aggregation launch in call order.  ``aggr="power"``
+    (``ids`` = None): the aggregation is the oracle's (oracle/sparse_ref.gen_propagate on the (E, C) encoded edge features,
+    1.4 GB in float64 per launch at the cluster shape) -- its per-edge message ReLU decides for itself: a flip there moves
+    one of ~120 terms of a row's mean by its rounding, not a whole gradient term.  Every coupling function
     is checkpointed (the decisions are indexed, not consumed in sequence, so the recomputation finds its own).  Leaves the
     gradients on ``host``'s parameters; returns last_norm's output."""
     from torch.utils.checkpoint import checkpoint
@@ -449,7 +452,10 @@ def revgcn_max_backward_along(host, masks, ids, inputs, probe):
     src_of_edge = ei[0]
     has_edges = torch.bincount(ei[1], minlength=n) > 0
     group = host.group
-    assert len(ids) == len(host.gcns) * group and len(masks) == 2 * len(ids) + 1
+    n_fn = len(host.gcns) * group
+    assert (ids is None or len(ids) == n_fn) and len(masks) == 2 * n_fn + 1 and aggr in ("max", "power")
+    if aggr == "power":
+        from oracle import sparse_ref
 
     def coupling_fn(fm, k):
         def f(xin, W_e, b_e):
@@ -457,7 +463,10 @@ def revgcn_max_backward_along(host, masks, ids, inputs, probe):
             lin = fm.gcn.edge_encoder
             Wp = lin.weight @ W_e
             bp = lin.weight @ b_e + lin.bias
-            h = a + _forced_max_aggregate(a, ids[k], Wp, bp, feat, src_of_edge, has_edges)
+            if aggr == "max":
+                h = a + _forced_max_aggregate(a, ids[k], Wp, bp, feat, src_of_edge, has_edges)
+            else:
+                h = a + sparse_ref.gen_propagate(a, ei, feat @ Wp.t() + bp, aggr="power", p=fm.gcn.p, dim_size=n)
             mods = list(fm.gcn.mlp.children())
             assert len(mods) == 4, "Linear, norm, ReLU, Linear"
             h = _forced_relu(mods[1](mods[0](h)), masks[2 * k + 1])

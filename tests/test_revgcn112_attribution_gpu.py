@@ -16,6 +16,8 @@ by 4e-7 relative at this depth), and 10 of the 0.33 G ReLU pre-activations take 
 pass -- replaying the FORWARD's masks leaves 2.7e-3 on `gcns.69._fn.Fms.0.norm.bias`; the reference's own reversible
 scheme (eff_gcn_modules/rev/gcn_revop.py:98-140) recomputes on rebuilt inputs in the same way.
 Host memory: ~34 GB for the float64 evaluation at 112 layers (every coupling function checkpointed).
+``power`` (8 layers): the ReLU sites are forced, the aggregation is the oracle's in float64 with its own per-edge message
+ReLU -- see the comment at its gate.
 """
 import os
 
@@ -32,8 +34,11 @@ GRAD_TOL = 2e-5          # max |device - float64 along the device's decisions| /
                          # 1e-4; measured: 2.2e-6 at 8 layers, 3.8e-6 at 112 -- profiles/r06_test_gates.json)
 
 
-@pytest.mark.parametrize("layers", [8, 112])
-def test_revgcn_max_gradients_along_the_device_decisions(layers):
+@pytest.mark.parametrize("aggr,layers,route", [("max", 8, "fused"), ("max", 112, "fused"), ("max", 112, "product"),
+                                               ("power", 8, "fused")])
+def test_revgcn_gradients_along_the_device_decisions(aggr, layers, route):
+    """route: ``fused`` = the default install (composed per-edge encoders); ``product`` = the model file's own forward on this
+    package's eff_gcn_modules.rev (the (E, 448) edge embedding exists, every layer's encoder is the fused edge GEMM)."""
     import deep_gcns_torch_amd
     deep_gcns_torch_amd.install()
     from conftest import gate
@@ -41,29 +46,33 @@ def test_revgcn_max_gradients_along_the_device_decisions(layers):
     from deep_gcns_torch_amd.eff_gcn_modules.rev import gcn_revop
     dev = torch.device("cuda:0")
     inp = cr.revgcn_inputs()
-    kw = dict(num_layers=layers, hidden=224, aggr="max", dropout=0.0, node_table=inp["table"])
+    kw = dict(num_layers=layers, hidden=224, aggr=aggr, dropout=0.0, node_table=inp["table"], learn_p=aggr == "power", p=1.0)
     host = rev_restated.RevGCNModelFile(impl="restated", **kw)
     cr.formula_init(host, seed=5)
     m = rev_restated.RevGCNModelFile(impl="product", **kw)
     m.load_state_dict(host.state_dict())
     m.node_features = inp["table"].to(dev)
-    m = fuse.fuse_model(m.to(dev).train())
+    m = m.to(dev).train()
+    if route == "fused":
+        m = fuse.fuse_model(m)
     x, nidx, ei, ea = (inp[k].to(dev) for k in ("x", "node_index", "edge_index", "edge_attr"))
     probe = inp["probe"].to(dev)
 
-    # ---- the arg-max ids: a pass without graph and without kept aggregations (the wrapper's own stashes would take the
-    #      launches); the step below keeps and replays exactly these (deterministic kernels, same inputs) ----
-    stash = ops.AggregationStash(node_sized_only=True)
-    saved = gcn_revop.KEEP_AGGREGATION
-    gcn_revop.KEEP_AGGREGATION = False
-    try:
-        with torch.no_grad(), ops.stash_aggregation(stash, "record"):
-            m(x, nidx, ei, ea)
-    finally:
-        gcn_revop.KEEP_AGGREGATION = saved
-    ids = [kept[1].cpu() for _, kept in stash.items]
-    assert len(ids) == 2 * layers and all(t.dtype == torch.int32 and t.shape == (inp["n"], 112) for t in ids)
-    stash.items.clear()
+    ids = None
+    if aggr == "max":
+        # ---- the arg-max ids: a pass without graph and without kept aggregations (the wrapper's own stashes would take the
+        #      launches); the step below keeps and replays exactly these (deterministic kernels, same inputs) ----
+        stash = ops.AggregationStash(node_sized_only=True)
+        saved = gcn_revop.KEEP_AGGREGATION
+        gcn_revop.KEEP_AGGREGATION = False
+        try:
+            with torch.no_grad(), ops.stash_aggregation(stash, "record"):
+                m(x, nidx, ei, ea)
+        finally:
+            gcn_revop.KEEP_AGGREGATION = saved
+        ids = [kept[1].cpu() for _, kept in stash.items]
+        assert len(ids) == 2 * layers and all(t.dtype == torch.int32 and t.shape == (inp["n"], 112) for t in ids)
+        stash.items.clear()
 
     # ---- the step as shipped, every ReLU site recorded.  The gradient is formed by the BACKWARD's grad-enabled evaluation
     #      of every coupling function, whose input is the REBUILT one (x_i = y_i - F_i: off the forward's by the
@@ -93,14 +102,19 @@ def test_revgcn_max_gradients_along_the_device_decisions(layers):
 
     # ---- float64 along the same branches ----
     host = host.double().train()
-    hn64 = attribution.revgcn_max_backward_along(host, masks, ids, inp, inp["probe"])
+    hn64 = attribution.revgcn_max_backward_along(host, masks, ids, inp, inp["probe"], aggr=aggr)
     hn_err = float((keep["hn"].detach().cpu().double() - hn64).abs().max() / hn64.abs().max())
     errs = attribution.gradient_errors(m, host)
     worst = max(errs.items(), key=lambda kv: kv[1])
-    n_dec = sum(int(t.numel()) for t in masks) + sum(int(t.numel()) for t in ids)
-    print(f"[revgcn{layers} max] {n_dec} decisions replayed ({flipped} ReLU sites where the backward's evaluation on the "
+    n_dec = sum(int(t.numel()) for t in masks) + sum(int(t.numel()) for t in (ids or []))
+    print(f"[revgcn{layers} {aggr} {route}] {n_dec} decisions replayed ({flipped} ReLU sites where the backward's evaluation on the "
           f"rebuilt input took the other branch than the forward); last_norm output {hn_err:.2e} of its max; worst parameter gradient "
           f"{worst[1]:.2e} of its scale ({worst[0]}); median {sorted(errs.values())[len(errs) // 2]:.2e}")
-    gate(f"revgcn{layers} max, fused route: last_norm output vs float64 along the device's decisions (max error / max)", hn_err, 1e-4)
-    gate(f"revgcn{layers} max, fused route: worst parameter gradient vs float64 along the device's decisions (max error / scale), "
-         f"all {len(errs)} parameters", worst[1], GRAD_TOL, what=worst[0])
+    gate(f"revgcn{layers} {aggr}, {route} route: last_norm output vs float64 along the device's decisions (max error / max)", hn_err, 1e-4)
+    # power: the aggregation's per-edge message ReLU (E x C = 177 M decisions per launch) is NOT forced -- the host's float64
+    # pass decides for itself, and ~300 of the 2.8 G pre-activations of 8 layers lie within fp32 rounding of zero.  One such
+    # flip removes one term from a sum of 1.6 M signed terms (the encoder bias' gradient): ~1e-3 of the sum, not a rounding
+    # error and not a kernel bug; measured 2.1e-4.  Under max every decision is forced and the strict tolerance applies.
+    tol = GRAD_TOL if aggr == "max" else 1e-3
+    gate(f"revgcn{layers} {aggr}, {route} route: worst parameter gradient vs float64 along the device's decisions (max error / scale), "
+         f"all {len(errs)} parameters", worst[1], tol, what=worst[0])
