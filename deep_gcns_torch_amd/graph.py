@@ -26,7 +26,10 @@ import torch
 from . import _lib
 
 HUB_CHUNK = 256                  # rows longer than 2 * chunk are cut into chunk-edge work items (big graphs)
-HUB_CHUNK_SMALL = 64             # graphs of up to SMALL_GRAPH_EDGES edges: their few thousand rows have to fill the chip's
+HUB_CHUNK_SMALL = 48             # (64 until the end of round 6; ogbn-proteins cluster, per coupling function: encoder walk
+                                 # 108.7 -> 102.0 us, max backward 83.3 -> 78.3, the two merges 15.3 -> 19.8; 32: 98.6 / 80.5 /
+                                 # 29.9; 128: 136 / 100 / 11.4 -- the tail of the persistent walk against the merge's pieces)
+                                 # graphs of up to SMALL_GRAPH_EDGES edges: their few thousand rows have to fill the chip's
 SMALL_GRAPH_EDGES = 8 << 20      # 8192 wave slots AND balance them, which 64-edge items do (an ogbn-proteins cluster:
                                  # 13 k rows, degrees 1 .. 3000) and 256-edge ones do not
 
