@@ -436,14 +436,16 @@ def _forced_max_aggregate(a, ids, Wp, bp, feat, src_of_edge, has_edges, eps=1e-7
     return torch.where(valid, val, floor.expand(n, C))
 
 
-def revgcn_max_backward_along(host, masks, ids, inputs, probe, aggr="max"):
+def revgcn_max_backward_along(host, masks, ids, inputs, probe, aggr="max", edge_masks=None):
     """Backward of ``sum(last_norm(h) * probe)`` of ``host`` -- a CPU float64 RevGCN (tests/rev_restated.py classes: they
     hold the parameters; their own forward is not used) -- along the decisions of a device pass: ``masks`` = the on / off
     mask of every ReLU site in call order (per layer and group: the block's norm -> ReLU, the MLP's norm -> ReLU; then the
     model's final ReLU), ``ids`` = the arg-max edge ids of every aggregation launch in call order.  ``aggr="power"``
     (``ids`` = None): the aggregation is the oracle's (oracle/sparse_ref.gen_propagate on the (E, C) encoded edge features,
     1.4 GB in float64 per launch at the cluster shape) -- its per-edge message ReLU decides for itself: a flip there moves
-    one of ~120 terms of a row's mean by its rounding, not a whole gradient term.  Every coupling function
+    one of ~120 terms of a row's mean by its rounding, not a whole gradient term -- unless ``edge_masks`` gives the device's
+    own: per launch a callable returning the (E, C) bool array ``z_e > 0`` of the device's pre-activations (the fused edge
+    GEMM keeps them for its backward), then the message is ``mask * max(z, tiny) + eps``.  Every coupling function
     is checkpointed (the decisions are indexed, not consumed in sequence, so the recomputation finds its own).  Leaves the
     gradients on ``host``'s parameters; returns last_norm's output."""
     from torch.utils.checkpoint import checkpoint
@@ -465,8 +467,12 @@ def revgcn_max_backward_along(host, masks, ids, inputs, probe, aggr="max"):
             bp = lin.weight @ b_e + lin.bias
             if aggr == "max":
                 h = a + _forced_max_aggregate(a, ids[k], Wp, bp, feat, src_of_edge, has_edges)
-            else:
+            elif edge_masks is None:
                 h = a + sparse_ref.gen_propagate(a, ei, feat @ Wp.t() + bp, aggr="power", p=fm.gcn.p, dim_size=n)
+            else:
+                z = a.index_select(0, ei[0]) + (feat @ Wp.t() + bp)
+                msg = _forced_relu(z, edge_masks[k]()) + 1e-7
+                h = a + sparse_ref.gen_aggregate_messages(msg, ei[1], n, "power", 1.0, fm.gcn.p, None, False)
             mods = list(fm.gcn.mlp.children())
             assert len(mods) == 4, "Linear, norm, ReLU, Linear"
             h = _forced_relu(mods[1](mods[0](h)), masks[2 * k + 1])
