@@ -277,3 +277,38 @@ def test_kept_aggregation_memory_is_bounded_by_the_budget():
     held = kept_after_forward(12, "auto", budget)
     assert budget <= held < budget + per_layer                                   # auto: stops at the budget
     assert kept_after_forward(12, "auto", None) == 12 * per_layer                # default budget (1/8 of HBM): all kept
+
+
+def test_coupling_residual_offer_is_ignored_where_it_cannot_be_folded():
+    """``node_ops.CouplingResidual`` is an OFFER: a block that cannot write ``res +/- F`` from its last Linear's epilogue (CPU
+    tensors here; the library GEMM below 2,048 rows or an MLP that does not end with its Linear on the device) returns the
+    plain ``F`` and leaves ``used`` unset -- the coupling then adds itself (eff_gcn_modules/rev/memgcn.py)."""
+    _install()
+    from deep_gcns_torch_amd import node_ops
+    from deep_gcns_torch_amd.eff_gcn_modules.rev import memgcn, rev_layer
+    from gcn_lib.sparse import torch_message
+    saved = torch_message.GenMessagePassing.propagate
+    torch_message.GenMessagePassing.propagate = _oracle_propagate
+    try:
+        torch.manual_seed(0)
+        n, C = 50, 16
+        ei = torch.randint(0, n, (2, 300))
+        blk = rev_layer.GENBlock(C, C, aggr="max", norm="layer", mlp_layers=2).train()
+        x, res = torch.randn(n, C), torch.randn(n, C)
+        mask = torch.ones(n, C)
+        out = torch.full((n, C), 7.0)
+        cr = node_ops.CouplingResidual(res, out, negate=True)
+        y = blk(x, ei, mask, None, residual=cr)
+        assert not cr.used and bool((out == 7.0).all())
+        torch.testing.assert_close(y, blk(x, ei, mask), rtol=0, atol=0)
+        # the coupling on CPU tensors makes no offer at all and inverts exactly as before
+        fms = torch.nn.ModuleList([blk, rev_layer.GENBlock(C, C, aggr="max", norm="layer", mlp_layers=2).train()])
+        coupling = memgcn.GroupAdditiveCoupling(fms, group=2)
+        h = torch.randn(n, 2 * C)
+        with torch.no_grad():
+            yy = coupling(h, ei, torch.ones(n, 2 * C))
+            hh = coupling.inverse(yy, ei, torch.ones(n, 2 * C))
+        torch.testing.assert_close(hh, h, rtol=0, atol=1e-5)
+        assert memgcn._offer(blk, res, out, False) is None
+    finally:
+        torch_message.GenMessagePassing.propagate = saved
