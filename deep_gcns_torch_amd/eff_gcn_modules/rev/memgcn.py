@@ -4,8 +4,6 @@ backward step used by ``gcn_revop.InvertibleCheckpointFunction``.
     forward :  y_0 = x_0 + F_0(x_1 + ... + x_{g-1}),   y_i = x_i + F_i(y_{i-1})
     inverse :  x_i = y_i - F_i(y_{i-1})  (i = g-1 .. 1),   x_0 = y_0 - F_0(x_1 + ... + x_{g-1})
 """
-import inspect
-
 import torch
 
 from ... import node_ops, ops
@@ -25,18 +23,10 @@ FOLD_COUPLING = True      # x_i +/- F_i(.) in the epilogue of F_i's last Linear 
 
 
 def _takes_residual(fm) -> bool:
-    """Whether the wrapped block's forward has the ``residual`` extension (rev_layer.BasicBlock and subclasses)."""
-    ok = getattr(type(fm), "_dgcn_takes_residual", None)
-    if ok is None:
-        try:
-            ok = "residual" in inspect.signature(type(fm).forward).parameters
-        except (TypeError, ValueError):
-            ok = False
-        try:
-            type(fm)._dgcn_takes_residual = ok
-        except (AttributeError, TypeError):
-            pass
-    return ok
+    """Whether the wrapped block understands the ``residual`` extension: this package's rev_layer.BasicBlock and its
+    subclasses only (a foreign block with a parameter of that name must not be handed a CouplingResidual)."""
+    from . import rev_layer
+    return isinstance(fm, rev_layer.BasicBlock)
 
 
 def _offer(fm, res, out, negate):
