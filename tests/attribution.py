@@ -260,6 +260,16 @@ def dense_mrconv_attribution(x, edge_index, conv_weight, conv_bias, bn_weight, b
 # ---------------------------------------------------------------------------------------------------------------------
 # whole models: the float64 reference follows the device run's ReLU decisions
 # ---------------------------------------------------------------------------------------------------------------------
+def passed_value(x, tiny=1e-30):
+    """``max(x, tiny)`` with gradient 1 everywhere: what a ReLU that the DEVICE run let through hands on when the host's
+    pre-activation is (rounding-level) negative -- a POSITIVE number, so that later ReLUs (the message ReLU of the
+    aggregation) pass it as they did on the device.  Not ``x + (x.clamp_min(tiny) - x).detach()``: for x = -9e-8 that is
+    ``-9e-8 + 9e-8 = 0`` exactly (the tiny is absorbed), the next ReLU's gradient at 0 is 0, and ONE such element cut a whole
+    term out of a 28-layer stack's gradients (7e-4 of a LayerNorm bias' scale; three of them 6.7e-3 -- found at the end of
+    round 6 by perturbing the inputs of the host replay: the response jumped by 10^4 between 1e-7 and 4e-7)."""
+    return torch.where(x > tiny, x, (x - x.detach()) + tiny)
+
+
 class ReluDecisions:
     """The on / off decision of every ReLU of a model pass, recorded in call order and replayed into another pass.
 
@@ -343,8 +353,8 @@ class ReluDecisions:
                 m = m.to(device=x.device, dtype=x.dtype)
                 # value m * max(x, tiny), gradient m: where the device run let a pre-activation through that is
                 # (rounding-level) negative here, later ReLUs -- the message ReLU of the aggregation -- must see a
-                # positive number as they did on the device, not a negative one
-                return m * (x + (x.clamp_min(1e-30) - x).detach())
+                # positive number as they did on the device, not a negative one and not an exact zero (passed_value)
+                return m * passed_value(x)
             self._patch(forced)
             try:
                 yield self
@@ -419,7 +429,7 @@ def gradient_errors(model, ref_model, small=1e-2):
 def _forced_relu(x, mask):
     """Value mask * max(x, tiny), gradient mask (see ReluDecisions.replaying)."""
     m = mask.to(device=x.device, dtype=x.dtype)
-    return m * (x + (x.clamp_min(1e-30) - x).detach())
+    return m * passed_value(x)
 
 
 def _forced_max_aggregate(a, ids, Wp, bp, feat, src_of_edge, has_edges, eps=1e-7):
@@ -431,7 +441,7 @@ def _forced_max_aggregate(a, ids, Wp, bp, feat, src_of_edge, has_edges, eps=1e-7
     e = ids.clamp_min(0).long()
     cidx = torch.arange(C).expand(n, C)
     z = a[src_of_edge[e], cidx] + (feat[e] * Wp.unsqueeze(0)).sum(-1) + bp
-    val = z + (z.clamp_min(1e-30) - z).detach() + eps
+    val = passed_value(z) + eps
     floor = torch.where(has_edges.unsqueeze(1), torch.full((), eps, dtype=a.dtype), torch.zeros((), dtype=a.dtype))
     return torch.where(valid, val, floor.expand(n, C))
 

@@ -108,19 +108,18 @@ def test_fused_deepergcn_equals_the_model_files_loop(layers, norm, mlp_layers, m
         worst = max(errs.items(), key=lambda kv: kv[1])
         # what fp32 rounding does to these gradients through `layers` normalised layers: the same replay (same branches) in
         # float32 on the host against the float64 one -- the device (fp32 partial sums per workgroup for the BatchNorm
-        # statistics, six-product bf16 GEMMs, another summation order in the aggregation) has to stay within an order of
-        # magnitude of that, floor 3e-4 (measured: 10 layers 1.0e-4 vs 1.3e-5 on the host, 28 layers 3.7e-3 vs 7.0e-4).
-        # Round 6 tried max(3 x, 2e-4) as the unit and took it back: the 28-layer stack sits at EITHER 5e-6 OR 4e-3 of its
-        # scale (`norms.19.bias`) depending on nothing but the summation order inside 9 hub rows -- 64-edge work items
-        # (5e-6) against 48-edge ones (4.1e-3; round 5 measured 3.7e-3 with 64) -- while every aggregation on this graph is
-        # within 2e-7 of the float64 oracle either way, all 28 ReLU sites are forced (none is recomputed: the pre-activation
-        # sits outside the checkpoint) and the host's own float32 replay is off by 7e-4: the stack amplifies rounding by
-        # 10^3 - 10^4 through its training-mode BatchNorm layers, it does not take another branch
+        # statistics, six-product bf16 GEMMs, another summation order in the aggregation) has to stay within 3x that,
+        # floor 1e-5.  Measured (profiles/r06_test_gates.json): 28 layers 6.5e-6 on the device, 8.4e-6 on the host.
+        # Rounds 3 - 5 gated this at max(10 x the host replay, 3e-4) and measured up to 3.7e-3 at 28 layers, "explained" by
+        # flipped decisions and later by rounding amplified through the BatchNorm layers.  It was the INSTRUMENT: its forced
+        # ReLU handed an exact 0 instead of a tiny positive number to the message ReLU wherever the device had let a
+        # pre-activation through that is rounding-level negative on the host (attribution.passed_value), which cut one
+        # gradient term per such element -- in the device comparison AND in the host's float32 yardstick (7e-4)
         worst32 = max(attribution.gradient_errors(host_along(dec, torch.float32), ref64).values())
         from conftest import gate
         gate(f"fuse deepergcn {layers}-{norm}-{mlp_layers}-{mode}, {route}: worst parameter gradient vs float64 along its own ReLU "
-             f"decisions, in units of max(10 x the host's float32 replay [{worst32:.2e}], 3e-4)",
-             worst[1] / max(10 * worst32, 3e-4), 1.0, what=f"{worst[0]} {worst[1]:.3e}")
+             f"decisions, in units of max(3 x the host's float32 replay [{worst32:.2e}], 1e-5)",
+             worst[1] / max(3 * worst32, 1e-5), 1.0, what=f"{worst[0]} {worst[1]:.3e}")
         print(f"[fuse {layers}-{norm}-{mlp_layers}-{mode}] {route}: {dec.n_decisions()} ReLU decisions replayed, worst "
               f"gradient error {worst[1]:.2e} of max |grad| (host float32 replay: {worst32:.2e})")
     # an instance that does not qualify takes the model file's own forward: another block type, CPU tensors
