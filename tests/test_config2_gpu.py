@@ -75,11 +75,34 @@ def _device_run():
 
     handles = [km.register_forward_hook(knn_hook) for km in _knn_modules(m)]
     handles += [blk.register_forward_hook(feat_hook) for blk in [m.head] + list(m.backbone)]
-    logits = m(x)
-    loss = torch.nn.functional.cross_entropy(logits, inp["target"].to(dev))
-    loss.backward()
+    # the step's DECISIONS, for the float64 evaluation along them (third test of this file): per edge convolution the
+    # P | Q rows, neighbour ids and arg-max / arg-min slots its kernels keep for their backward (the per-edge ReLU's input is
+    # the single fp32 addition P_i + Q_j: its sign is reproduced exactly from these); the masks of the head's three ReLU
+    # modules; the arg-max of the global max-pool
+    import attribution
+    from deep_gcns_torch_amd import dense_ops
+    conv_dec, pool = [], {}
+    orig_fwd = dense_ops._EdgeConv2dFused.forward
+
+    def fwd(ctx, *a, **k):
+        out = orig_fwd(ctx, *a, **k)
+        x3, W2, pq, idx, amax, amin, vmax, vmin, bnbuf, gamma = ctx.to_save
+        conv_dec.append(dict(pq=pq, idx=idx, amax=amax, amin=amin, gamma=gamma.detach().clone()))
+        return out
+    dense_ops._EdgeConv2dFused.forward = staticmethod(fwd)
+    handles.append(m.fusion_block.register_forward_hook(
+        lambda mod, a, out: pool.__setitem__("argmax", out.detach().flatten(2).argmax(2))))
+    head_relus = attribution.ReluDecisions()
+    try:
+        with head_relus.recording():
+            logits = m(x)
+            loss = torch.nn.functional.cross_entropy(logits, inp["target"].to(dev))
+            loss.backward()
+    finally:
+        dense_ops._EdgeConv2dFused.forward = orig_fwd
     for h in handles:
         h.remove()
+    assert len(conv_dec) == 28 and len(head_relus.masks) == 3, (len(conv_dec), len(head_relus.masks))
     assert len(graphs) == 28 and len(feats) == 28
     vs_rank64 = []
     for ei, (xin, k, d) in zip(graphs, knn_in):
@@ -87,7 +110,7 @@ def _device_run():
         vs_rank64.append(int((_rank64_ids(xin, k, d) != ei[0]).sum()))
     _RUN.update(model=m, sd=sd, inp=inp, x=x, logits=logits.detach(), loss=float(loss.detach()), graphs=graphs, feats=feats,
                 grads={k: p.grad.detach().clone() for k, p in m.named_parameters()}, grad_x=x.grad.detach().clone(),
-                knn_vs_rank64=vs_rank64)
+                knn_vs_rank64=vs_rank64, conv_dec=conv_dec, head_relus=head_relus, pool_argmax=pool["argmax"])
     return _RUN
 
 
@@ -155,6 +178,101 @@ def test_step_equals_the_float64_replay_along_its_own_graphs():
     # the discrete part: ids vs the float64 ranking of each block's own input
     gate("config 2 kNN in the loop: worst per-block fraction of ids that differ from the float64 ranking of the same features",
          max(counts) / total, 6e-3)
+
+
+def test_step_equals_float64_along_its_own_graphs_and_decisions():
+    """The strict form of the test above: the float64 evaluation is forced through the device step's graphs AND through every
+    discontinuity behind them -- the per-edge ReLU of all 28 edge convolutions (33.5 M decisions per block: the sign of the
+    single fp32 addition P_i + Q_j the kernel takes, reproduced bit for bit from the rows it keeps), the neighbour that wins
+    each (point, channel) maximum (arg-max, or arg-min where the BatchNorm scale is negative), the head's three ReLU layers
+    and the arg-max of the global max-pool (gcn_lib/dense/torch_vertex.py:31-35, torch_nn.py:48-60; examples/sem_seg_dense/
+    architecture.py:40-55).  What is left between the device's float32 step and this evaluation is rounding, and it has to
+    be small for the logits, the input gradient and EVERY parameter gradient -- no yardstick from the reference's own noise."""
+    run = _device_run()
+    import attribution
+    from gcn_lib.dense import torch_edge, torch_vertex
+    from oracle import dense_ref
+    dev = _dev()
+    def replay(dtype):
+        mm = arch_restated.DenseDeepGCN(n_blocks=28, channels=64, k=16)
+        mm.load_state_dict(run["sd"])
+        mm.to(dtype).to(dev).train()
+        feed = iter(run["graphs"])
+        decs = iter(run["conv_dec"])
+
+        def forced_edgeconv(self, x, edge_index, res_scale=None):
+            d = next(decs)
+            conv, bn = self.nn[0], self.nn[2]
+            assert isinstance(bn, torch.nn.BatchNorm2d) and isinstance(self.nn[1], torch.nn.ReLU)
+            nbr = edge_index[0]
+            B, N, k = nbr.shape
+            Cout = conv.out_channels
+            # the device's per-edge decisions: sign of P_i + Q_j, one fp32 addition
+            P, Q = d["pq"][..., :Cout], d["pq"][..., Cout:]
+            Qj = Q[torch.arange(B, device=dev).view(B, 1, 1), nbr]                     # (B, N, k, Cout)
+            on = ((P.unsqueeze(2) + Qj) > 0).permute(0, 3, 1, 2)                       # (B, Cout, N, k)
+            x_i = dense_ref.batched_index_select(x, edge_index[1])
+            x_j = dense_ref.batched_index_select(x, nbr)
+            u = conv(torch.cat([x_i, x_j - x_i], dim=1))
+            r = on.to(u.dtype) * attribution.passed_value(u)
+            y = bn(r)
+            slot = torch.where((d["gamma"] >= 0).view(1, 1, Cout), d["amax"].long(), d["amin"].long())     # (B, N, Cout)
+            out = torch.gather(y, 3, slot.permute(0, 2, 1).unsqueeze(-1))
+            return torch_vertex._with_skip(out, x, res_scale)
+
+        pool_idx = run["pool_argmax"]
+
+        def forced_pool(t, kernel_size, *a, **k):
+            B, C = t.shape[:2]
+            assert tuple(kernel_size) == tuple(t.shape[2:]) and pool_idx.shape == (B, C)
+            return torch.gather(t.flatten(2), 2, pool_idx.unsqueeze(-1)).view(B, C, 1, 1)
+
+        saved = (torch_edge.DenseDilatedKnnGraph.forward, torch_vertex.EdgeConv2d.forward, torch.max_pool2d)
+        torch_edge.DenseDilatedKnnGraph.forward = lambda self, x: next(feed)
+        torch_vertex.EdgeConv2d.forward = forced_edgeconv
+        torch.max_pool2d = forced_pool
+        try:
+            with run["head_relus"].replaying():
+                xin = run["inp"]["inputs"].to(dtype).to(dev).requires_grad_(True)
+                out = mm(xin)
+                loss = torch.nn.functional.cross_entropy(out, run["inp"]["target"].to(dev))
+                loss.backward()
+        finally:
+            torch_edge.DenseDilatedKnnGraph.forward, torch_vertex.EdgeConv2d.forward, torch.max_pool2d = saved
+        return dict(logits=out.detach(), loss=float(loss.detach()), grad_x=xin.grad,
+                    grads={name: p.grad for name, p in mm.named_parameters()})
+
+    r64 = replay(torch.float64)
+    r32 = replay(torch.float32)          # the yardstick: torch's float32 kernels through the SAME branches
+
+    def rel_max(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+    def errors(got):
+        pp = {name: rel_max(got["grads"][name], g) for name, g in r64["grads"].items()}
+        return dict(logits=rel_max(got["logits"], r64["logits"]), loss=abs(got["loss"] - r64["loss"]),
+                    gx=rel_max(got["grad_x"], r64["grad_x"]), worst=max(pp.values()), worst_name=max(pp, key=pp.get),
+                    median=sorted(pp.values())[len(pp) // 2])
+
+    e_dev = errors(dict(logits=run["logits"], loss=run["loss"], grad_x=run["grad_x"], grads=run["grads"]))
+    e_32 = errors(r32)
+    n_dec = 28 * 8 * 64 * 4096 * 16 + 28 * 8 * 64 * 4096 + sum(int(t.numel()) for t in run["head_relus"].masks) + 8 * 1024
+    for who, e in (("the device step", e_dev), ("torch float32 through the same branches", e_32)):
+        print(f"[config 2] float64 along the device's graphs AND its {n_dec} decisions vs {who}: logits {e['logits']:.2e} of max "
+              f"|logit|, loss {e['loss']:.2e}, input gradient {e['gx']:.2e} of its max, parameter gradients worst {e['worst']:.2e} "
+              f"({e['worst_name']}) / median {e['median']:.2e}")
+    # With every branch fixed what remains is arithmetic: 28 blocks of training-mode BatchNorm over 33.5 M edge activations
+    # each.  torch's own float32 kernels through the same branches are the measure of that; the device has to be as good.
+    # measured (round 6): device 2.7e-4 / 1.1e-3 / 1.8e-3 / 6.4e-4, torch float32 1.9e-4 / 6.2e-4 / 3.7e-3 / 5.9e-4
+    # (logits / input gradient / worst / median parameter gradient); without the decisions forced the device's gradients
+    # are at 4.6e-3 / 1.9e-2 / 4.4e-3 (first test of this file)
+    F = 2.5
+    gate("config 2 along graphs and decisions: logits error / torch float32's through the same branches", e_dev["logits"] / e_32["logits"], F)
+    gate("config 2 along graphs and decisions: input-gradient error / torch float32's", e_dev["gx"] / e_32["gx"], F)
+    gate("config 2 along graphs and decisions: worst parameter-gradient error / torch float32's worst", e_dev["worst"] / e_32["worst"], F,
+         e_dev["worst_name"])
+    gate("config 2 along graphs and decisions: median parameter-gradient error / torch float32's median",
+         e_dev["median"] / e_32["median"], F)
 
 
 def test_divergence_from_the_reference_float64_run_is_the_reference_float32_runs():
