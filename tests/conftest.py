@@ -82,7 +82,10 @@ def gate(name, err, tol, what=""):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         try:
-            with open(os.path.join(out, "test_gates.json"), "w") as f:
+            # (a CPU-only session writes its own file: it must not overwrite the gates a GPU session merged back)
+            import torch
+            fname = "test_gates.json" if torch.cuda.is_available() else "test_gates_cpu.json"
+            with open(os.path.join(out, fname), "w") as f:
                 json.dump(_GATES, f, indent=1, sort_keys=True)
         except OSError:
             pass
